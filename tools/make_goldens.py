@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""
+Generate tests/golden/*.npz by RUNNING THE REFERENCE in the build container.
+
+    python tools/make_goldens.py            # needs /root/reference, scikit-learn, dill
+
+The reference (Hendrik1704/GPBayesTools-HIC) has no tests or golden vectors of
+its own, so parity is pinned by vectors captured here from the
+unmodified reference code (src/emulator.py, src/mcmc.py) and from the scikit-learn
+kernels it calls.  Only plain arrays (inputs + expected outputs) are written;
+no reference source, bytecode or pickled reference object enters the repo.
+
+`src/mcmc.py` imports `emcee` and `pocomc` at module level (src/mcmc.py:12,19);
+neither package is installed here.  The functions captured below
+(mvn_loglike, Chain.log_prior/log_likelihood/log_posterior/_predict) never call
+into them, so the two module names are bound to empty placeholder modules for the
+import only.  Sampler dynamics (emcee/pocoMC internals) are therefore NOT pinned.
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+OUT = os.path.join(REPO, "tests", "golden")
+REF = "/root/reference"
+
+sys.dont_write_bytecode = True
+_work = tempfile.mkdtemp(prefix="gpb_ref_work_")
+os.environ["WORKDIR"] = _work          # src/__init__.py:15-18 mkdirs cache/ at import
+os.environ.setdefault("LOGLEVEL", "warning")
+sys.path.insert(0, REF)
+
+from gpbayestools_hic_amd import synth  # noqa: E402
+
+
+def _import_reference():
+    emcee = types.ModuleType("emcee")
+    emcee.EnsembleSampler = type("EnsembleSampler", (), {})
+    sys.modules.setdefault("emcee", emcee)
+    sys.modules.setdefault("pocomc", types.ModuleType("pocomc"))
+    from src.emulator import Emulator
+    from src import mcmc
+    return Emulator, mcmc
+
+
+def g1_kernels():
+    from sklearn.gaussian_process import kernels as sk
+    rng = np.random.default_rng(101)
+    N, d, W = 40, 6, 16
+    X = synth.lhs(N, d, seed=102)
+    Xs = rng.random((W, d))
+    ls = rng.uniform(0.5, 2.5, d)
+    c, noise = 1.7, 0.03
+    theta = np.concatenate([[np.log(c)], np.log(ls), [np.log(noise)]])
+    out = dict(X=X, Xs=Xs, theta=theta)
+    for name, stat in (("rbf", sk.RBF(length_scale=ls)),
+                       ("m15", sk.Matern(length_scale=ls, nu=1.5)),
+                       ("m25", sk.Matern(length_scale=ls, nu=2.5))):
+        k = sk.ConstantKernel(c) * stat + sk.WhiteKernel(noise)
+        assert np.allclose(k.theta, theta)
+        K, G = k(X, eval_gradient=True)
+        out[f"{name}_K"] = K
+        out[f"{name}_G"] = G
+        out[f"{name}_Kcross"] = k(Xs, X)
+        out[f"{name}_diag"] = k.diag(Xs)
+    np.savez_compressed(os.path.join(OUT, "g1_kernels.npz"), **out)
+
+
+def g2_gpr():
+    from sklearn.gaussian_process import GaussianProcessRegressor as GPR
+    from sklearn.gaussian_process import kernels as sk
+    rng = np.random.default_rng(201)
+    N, d, W = 64, 8, 24
+    X = synth.lhs(N, d, seed=202)
+    z = np.sin(X @ rng.standard_normal(d)) + 0.05 * rng.standard_normal(N)
+    Xs = rng.random((W, d))
+    thetas = []
+    for i in range(3):
+        ls = rng.uniform(0.4, 3.0, d)
+        thetas.append(np.concatenate([[rng.uniform(-0.5, 0.8)], np.log(ls), [np.log(rng.uniform(0.02, 0.2))]]))
+    thetas = np.array(thetas)
+    out = dict(X=X, z=z, Xs=Xs, thetas=thetas, alpha=0.1)
+    for name, mk in (("rbf", lambda ls: sk.RBF(length_scale=ls)),
+                     ("m15", lambda ls: sk.Matern(length_scale=ls, nu=1.5)),
+                     ("m25", lambda ls: sk.Matern(length_scale=ls, nu=2.5))):
+        for i, th in enumerate(thetas):
+            k = sk.ConstantKernel(np.exp(th[0])) * mk(np.exp(th[1:1 + d])) + sk.WhiteKernel(np.exp(th[-1]))
+            gp = GPR(kernel=k, alpha=0.1, optimizer=None, copy_X_train=False).fit(X, z)
+            lml, grad = gp.log_marginal_likelihood(th, eval_gradient=True)
+            mean, cov = gp.predict(Xs, return_cov=True)
+            out[f"{name}_{i}_alpha_"] = gp.alpha_
+            out[f"{name}_{i}_lml"] = lml
+            out[f"{name}_{i}_grad"] = grad
+            out[f"{name}_{i}_mean"] = mean
+            out[f"{name}_{i}_var"] = cov.diagonal().copy()
+            if i == 0:
+                out[f"{name}_{i}_L"] = gp.L_
+    np.savez_compressed(os.path.join(OUT, "g2_gpr.npz"), **out)
+
+
+VARIANTS = {
+    # name: (N, d, M, npc, kernel_type, ctor kwargs)
+    "pca_rbf":    (128, 8, 4, 4, "RBF", {}),
+    "pca_trunc":  (128, 8, 6, 3, "RBF", {}),
+    "nopca_rbf":  (96, 5, 3, 3, "RBF", dict(perform_no_PCA=True)),
+    "logexp_rbf": (96, 5, 4, 2, "RBF", dict(logTrafo=True, exp_and_cov_diagonal=True)),
+    "pca_matern": (96, 6, 4, 3, "Matern", {}),
+}
+
+
+def _make_inputs(name, N, d, M, seed):
+    rng = np.random.default_rng(seed)
+    lo = rng.uniform(-1.0, 0.5, d)
+    hi = lo + rng.uniform(0.5, 3.0, d)
+    X = synth.lhs(N, d, seed=seed + 1, lo=lo, hi=hi)
+    U = (X - lo) / (hi - lo)
+    Y = synth.observables(U, M, seed=seed + 2)
+    Yerr = np.full_like(Y, 0.01)
+    return lo, hi, X, Y, Yerr
+
+
+def g3_g4_emulators(Emulator):
+    trained = {}
+    for vi, (name, (N, d, M, npc, ktype, kw)) in enumerate(VARIANTS.items()):
+        lo, hi, X, Y, Yerr = _make_inputs(name, N, d, M, 300 + 10 * vi)
+        tp = os.path.join(_work, f"{name}_train.pkl")
+        pf = os.path.join(_work, f"{name}_par.txt")
+        synth.write_training_pickle(tp, X, Y, Yerr)
+        synth.write_parameter_file(pf, lo, hi)
+        emu = Emulator(training_set_path=tp, parameter_file=pf, npc=npc, **kw)
+        emu.trainEmulator([True] * emu.nev, kernel_type=ktype)
+        rng = np.random.default_rng(900 + vi)
+        Xs = lo + (hi - lo) * rng.random((32, d))
+        extra = rng.uniform(0.0, 0.05, 32)
+        per_gp = [gp.predict(Xs, return_cov=True) for gp in emu.gps]
+        gp_mean = np.stack([m for m, _ in per_gp], axis=1)
+        gp_var = np.stack([c.diagonal() for _, c in per_gp], axis=1)
+        mean, cov = emu.predict(Xs, return_cov=True, extra_std=extra)
+        mean0, cov0 = emu.predict(Xs, return_cov=True, extra_std=np.zeros(32))
+        mean_only = emu.predict(Xs, return_cov=False)
+        out = dict(
+            lo=lo, hi=hi, X=X, Y=Y, Yerr=Yerr, npc=npc, kernel_type=ktype,
+            model_data=emu.model_data,
+            thetas=np.array([gp.kernel_.theta for gp in emu.gps]),
+            theta_bounds=emu.gps[0].kernel_.bounds,
+            lml=np.array([gp.log_marginal_likelihood_value_ for gp in emu.gps]),
+            alpha_=np.array([gp.alpha_ for gp in emu.gps]),
+            Ldiag=np.array([gp.L_.diagonal() for gp in emu.gps]),
+            Lrow_last=np.array([gp.L_[-1] for gp in emu.gps]),
+            scaler_mean=emu.scaler.mean_, scaler_scale=emu.scaler.scale_, scaler_var=emu.scaler.var_,
+            Xs=Xs, extra_std=extra, gp_mean=gp_mean, gp_var=gp_var,
+            mean=mean, cov=cov, mean0=mean0, cov0=cov0, mean_only=mean_only,
+        )
+        if not kw.get("perform_no_PCA"):
+            out.update(pca_components=emu.pca.components_,
+                       pca_explained_variance=emu.pca.explained_variance_,
+                       pca_mean=emu.pca.mean_,
+                       trans_matrix=emu._trans_matrix, var_trans=emu._var_trans,
+                       cov_trunc=emu._cov_trunc)
+        np.savez_compressed(os.path.join(OUT, f"g3_emulator_{name}.npz"), **out)
+        trained[name] = (emu, lo, hi)
+    return trained
+
+
+def g5_chain(mcmc, Emulator):
+    """Two emulators that share one parameter space (E=2: block-diagonal covariance,
+    src/mcmc.py:153-166)."""
+    N, d = 128, 8
+    rng = np.random.default_rng(500)
+    lo = rng.uniform(-1.0, 0.5, d)
+    hi = lo + rng.uniform(0.5, 3.0, d)
+    X = synth.lhs(N, d, seed=501, lo=lo, hi=hi)
+    U = (X - lo) / (hi - lo)
+    specs = [("A", 4, 4, 502), ("B", 6, 3, 503)]
+    emus, out = [], dict(lo=lo, hi=hi, X=X)
+    pf = os.path.join(_work, "chain_par.txt")
+    synth.write_parameter_file(pf, lo, hi)
+    for tag, M, npc, seed in specs:
+        Y = synth.observables(U, M, seed=seed)
+        tp = os.path.join(_work, f"chain_{tag}.pkl")
+        synth.write_training_pickle(tp, X, Y, np.full_like(Y, 0.01))
+        emu = Emulator(training_set_path=tp, parameter_file=pf, npc=npc)
+        emu.trainEmulatorAutoMask()
+        emus.append(emu)
+        out[f"Y_{tag}"] = Y
+        out[f"npc_{tag}"] = npc
+        out[f"thetas_{tag}"] = np.array([gp.kernel_.theta for gp in emu.gps])
+    xstar = lo + (hi - lo) * synth.truth_point(d, seed=504)
+    yexp = np.concatenate([e.predict(xstar[None, :], return_cov=False)[0] for e in emus])
+    yerr = 0.05 * np.abs(yexp)
+    ep = os.path.join(_work, "chain_exp.pkl")
+    synth.write_experiment_pickle(ep, yexp, yerr)
+    chain = mcmc.Chain(mcmc_path=os.path.join(_work, "mcmc", "chain.pkl"),
+                       expdata_path=ep, model_parafile=pf)
+    chain.emuList = emus
+    W = 64
+    Xw = lo + (hi - lo) * rng.random((W, d))
+    Xw[3, 2] = hi[2] + 0.1            # outside
+    Xw[10, 0] = lo[0] - 1e-3          # outside
+    Xw[17, 5] = lo[5]                 # exactly on the lower bound -> outside (strict)
+    Xw[23, 7] = hi[7]                 # exactly on the upper bound -> outside (strict)
+    Xw[40] = lo + (hi - lo) * 1e-9    # barely inside
+    Xout = hi + 0.5 + rng.random((5, d))
+    inside = np.all((Xw > lo) & (Xw < hi), axis=1)
+    pm, pc = chain._predict(Xw[inside], extra_std=0.0)
+    out.update(
+        xstar=xstar, yexp=yexp, yerr=yerr, Xw=Xw, Xout=Xout, inside=inside,
+        expdata=chain.expdata, expdata_cov=chain.expdata_cov,
+        log_prior=chain.log_prior(Xw),
+        log_likelihood=chain.log_likelihood(Xw),
+        log_likelihood_finite=chain.log_likelihood(Xw, finite=True),
+        log_posterior=chain.log_posterior(Xw),
+        log_posterior_out=chain.log_posterior(Xout),
+        log_likelihood_out_finite=chain.log_likelihood(Xout, finite=True),
+        log_posterior_1d=chain.log_posterior(Xw[0]),
+        predict_mean=pm, predict_cov=pc,
+    )
+    np.savez_compressed(os.path.join(OUT, "g5_chain.npz"), **out)
+
+
+def g6_mvn(mcmc):
+    rng = np.random.default_rng(600)
+    out = {}
+    for M in (4, 16, 64):
+        ys, covs, lls = [], [], []
+        for _ in range(6):
+            B = rng.standard_normal((M, M))
+            cov = B @ B.T / M + np.diag(rng.uniform(0.01, 0.5, M))
+            y = rng.standard_normal(M)
+            ys.append(y); covs.append(cov)
+            lls.append(mcmc.mvn_loglike(y, cov))
+        out[f"y_{M}"] = np.array(ys); out[f"cov_{M}"] = np.array(covs); out[f"ll_{M}"] = np.array(lls)
+    np.savez_compressed(os.path.join(OUT, "g6_mvn.npz"), **out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    Emulator, mcmc = _import_reference()
+    g1_kernels()
+    g2_gpr()
+    g3_g4_emulators(Emulator)
+    g5_chain(mcmc, Emulator)
+    g6_mvn(mcmc)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
