@@ -1,0 +1,99 @@
+"""
+ctypes binding of include/gpbayes.h (the C-ABI drop-in boundary).
+
+There is no CPU fallback: if the HIP library is missing or no gfx950 device is
+visible, creating an engine raises.  torch is imported first so that this
+process holds exactly one HIP runtime (libamdhip64.so.7) shared by torch tensors
+and the kernels.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgpbayes.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+c_i64 = C.c_int64
+c_u64 = C.c_uint64
+VP = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/gpbayes.h one to one
+PROTOTYPES = {
+    "gpb_version": (C.c_int, []),
+    "gpb_device_count": (C.c_int, []),
+    "gpb_ctx_create": (C.c_int, [C.c_int, VP, C.POINTER(VP)]),
+    "gpb_ctx_destroy": (C.c_int, [VP]),
+    "gpb_ctx_set_stream": (C.c_int, [VP, VP]),
+    "gpb_sync": (C.c_int, [VP]),
+    "gpb_last_error": (C.c_char_p, [VP]),
+    "gpb_stream": (VP, [VP]),
+    "gpb_gp_set": (C.c_int, [VP, c_i64, c_i64, c_i64, VP, VP, C.c_int, C.c_double]),
+    "gpb_gp_set_theta": (C.c_int, [VP, VP]),
+    "gpb_gp_factor": (C.c_int, [VP, VP]),
+    "gpb_gp_get": (C.c_int, [VP, C.c_int, VP]),
+    "gpb_gp_lml": (C.c_int, [VP, VP, VP, VP, VP]),
+    "gpb_gp_predict": (C.c_int, [VP, VP, c_i64, C.c_int, VP, VP]),
+    "gpb_emu_set_transform": (C.c_int, [VP, C.c_int, c_i64, VP, VP, VP, VP]),
+    "gpb_emu_predict": (C.c_int, [VP, VP, c_i64, C.c_int, VP, VP, VP]),
+    "gpb_like_set": (C.c_int, [VP, VP, VP]),
+    "gpb_loglike": (C.c_int, [VP, VP, c_i64, C.c_int, VP, C.c_int, VP]),
+    "gpb_mvn_loglike": (C.c_int, [VP, VP, VP, c_i64, c_i64, C.c_int, VP, VP]),
+    "gpb_box_finish": (C.c_int, [VP, VP, c_i64, VP, VP, C.c_double, C.c_double, VP]),
+    "gpb_stretch_propose": (C.c_int, [VP, VP, c_i64, c_i64, C.c_int, c_u64, c_u64, C.c_double, VP, VP]),
+    "gpb_stretch_accept": (C.c_int, [VP, VP, VP, c_i64, c_i64, C.c_int, c_u64, c_u64, VP, VP, VP, VP]),
+    "gpb_dist_uid": (C.c_int, [VP]),
+    "gpb_dist_init": (C.c_int, [VP, C.c_int, C.c_int, VP]),
+    "gpb_dist_allgather": (C.c_int, [VP, VP, VP, c_i64]),
+    "gpb_dist_finalize": (C.c_int, [VP]),
+    "gpb_test_gemm": (C.c_int, [VP, c_i64, c_i64, c_i64, VP, VP, VP, C.c_int]),
+    "gpb_probe_fp64": (C.c_int, [VP, C.c_int, VP]),
+}
+
+_lib = None
+
+
+class GPBError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgpbayes.so (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GPBError(
+            f"{LIB_PATH} not found: build it with `python -m gpbayestools_hic_amd.build` "
+            "(there is no CPU fallback)")
+    try:
+        import torch  # noqa: F401  (one shared HIP runtime per process)
+    except Exception:  # pragma: no cover
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(a):
+    """void* of a C-contiguous float64/int32 numpy array, a torch tensor, an int, or None."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data_as(VP)
+    if isinstance(a, int):
+        return VP(a)
+    if hasattr(a, "data_ptr"):
+        return VP(a.data_ptr())
+    raise TypeError(type(a))
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)

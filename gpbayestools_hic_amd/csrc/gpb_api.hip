@@ -1,0 +1,527 @@
+// gpb_api.hip — C-ABI entry points (include/gpbayes.h): state management, host<->HBM staging,
+// and kernel sequencing on the context's HIP stream.  No compute happens on the host.
+#include "gpb_internal.h"
+#include <dlfcn.h>
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+using namespace gpb;
+
+namespace {
+
+template <typename T>
+int dev_alloc(gpb_ctx* ctx, T** p, int64_t count) {
+    if (*p) { GPB_HIP(hipFree(*p)); *p = nullptr; }
+    GPB_HIP(hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * (size_t)(count > 0 ? count : 1)));
+    return 0;
+}
+template <typename T>
+void dev_free(T** p) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+}
+
+int pick_dpad(int64_t d) {
+    const int opts[] = {8, 16, 24, 32, 48, 64};
+    for (int o : opts) if (d <= o) return o;
+    return -1;
+}
+
+int ensure_out(gpb_ctx* ctx, int64_t count) {
+    if (count <= ctx->out_cap) return 0;
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    dev_free(&ctx->out_stage);
+    GPB_HIP(hipMalloc(&ctx->out_stage, sizeof(double) * (size_t)count));
+    ctx->out_cap = count;
+    return 0;
+}
+
+// [P][Wld] -> [W][P]
+__global__ void k_transpose_pw(const double* __restrict__ src, double* __restrict__ dst, int64_t W, int64_t Wld,
+                               int P) {
+    const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    for (int p = 0; p < P; ++p) dst[w * P + p] = src[(int64_t)p * Wld + w];
+}
+
+// stage caller inputs: returns device pointers for Xs (and extra_std)
+int stage_inputs(gpb_ctx* ctx, const double* Xs, int64_t W, int on_device, const double* estd,
+                 const double** Xs_dev, const double** estd_dev) {
+    int rc = ensure_wcap(ctx, W);
+    if (rc) return rc;
+    if (on_device) {
+        *Xs_dev = Xs;
+        if (estd_dev) *estd_dev = estd;
+    } else {
+        GPB_HIP(hipMemcpyAsync(ctx->Xs, Xs, sizeof(double) * W * ctx->d, hipMemcpyHostToDevice, ctx->stream));
+        *Xs_dev = ctx->Xs;
+        if (estd_dev) {
+            if (estd) {
+                GPB_HIP(hipMemcpyAsync(ctx->estd, estd, sizeof(double) * W, hipMemcpyHostToDevice, ctx->stream));
+                *estd_dev = ctx->estd;
+            } else {
+                *estd_dev = nullptr;
+            }
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int gpb_version(void) { return GPB_VERSION; }
+
+extern "C" int gpb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int gpb_ctx_create(int device, void* stream, gpb_ctx** out) {
+    if (!out) return GPB_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return GPB_E_NODEV;   // no CPU fallback, by design
+    if (device < 0 || device >= n) return GPB_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return GPB_E_HIP;
+    gpb_ctx* ctx = new gpb_ctx();
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return GPB_E_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    if (hipMalloc(&ctx->notpd, sizeof(int)) != hipSuccess ||
+        hipMemsetAsync(ctx->notpd, 0, sizeof(int), ctx->stream) != hipSuccess) {
+        delete ctx;
+        return GPB_E_ALLOC;
+    }
+    *out = ctx;
+    return 0;
+}
+
+extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
+    if (!ctx) return GPB_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    gpb_dist_finalize(ctx);
+    free(ctx->h_theta);
+    dev_free(&ctx->X); dev_free(&ctx->Xsc); dev_free(&ctx->ls); dev_free(&ctx->amp); dev_free(&ctx->noise);
+    dev_free(&ctx->Z); dev_free(&ctx->K); dev_free(&ctx->Linv); dev_free(&ctx->T); dev_free(&ctx->yv);
+    dev_free(&ctx->alpha); dev_free(&ctx->apart); dev_free(&ctx->info); dev_free(&ctx->lmlbuf);
+    dev_free(&ctx->gpart); dev_free(&ctx->Xs); dev_free(&ctx->estd); dev_free(&ctx->KsT); dev_free(&ctx->mpart);
+    dev_free(&ctx->spart); dev_free(&ctx->mean_pc); dev_free(&ctx->var_pc); dev_free(&ctx->out_stage);
+    dev_free(&ctx->A); dev_free(&ctx->mu); dev_free(&ctx->scale); dev_free(&ctx->C0); dev_free(&ctx->yexp);
+    dev_free(&ctx->Cexp); dev_free(&ctx->mvn_ws); dev_free(&ctx->notpd);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+extern "C" int gpb_ctx_set_stream(gpb_ctx* ctx, void* stream) {
+    if (!ctx) return GPB_E_ARG;
+    GPB_HIP(hipSetDevice(ctx->device));
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+    ctx->stream = reinterpret_cast<hipStream_t>(stream);      // NULL = the legacy default stream
+    return 0;
+}
+
+extern "C" int gpb_sync(gpb_ctx* ctx) {
+    if (!ctx) return GPB_E_ARG;
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" const char* gpb_last_error(gpb_ctx* ctx) { return ctx ? ctx->err.c_str() : "gpb: null context"; }
+extern "C" void* gpb_stream(gpb_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// ---------------------------------------------------------------------------- GP state
+extern "C" int gpb_gp_set(gpb_ctx* ctx, int64_t N, int64_t d, int64_t P, const double* X_host,
+                          const double* Z_host, int kernel_id, double alpha) {
+    if (!ctx) return GPB_E_ARG;
+    if (N < 1 || d < 1 || P < 1 || !X_host || !Z_host) GPB_FAIL(GPB_E_ARG, "gpb_gp_set: bad sizes or null input");
+    if (kernel_id < 0 || kernel_id > 2) GPB_FAIL(GPB_E_ARG, "gpb_gp_set: unknown kernel_id");
+    const int dpad = pick_dpad(d);
+    if (dpad < 0) GPB_FAIL(GPB_E_ARG, "gpb_gp_set: d > 64 not supported");
+    GPB_HIP(hipSetDevice(ctx->device));
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->N = N; ctx->d = d; ctx->P = P; ctx->dpad = dpad; ctx->kind = kernel_id; ctx->alpha_reg = alpha;
+    ctx->Np = round_up(N, NB);
+    ctx->have_theta = ctx->factored = false;
+    const int64_t Np = ctx->Np;
+    // workspaces sized by (Np, P) are stale now
+    dev_free(&ctx->KsT); dev_free(&ctx->mpart); dev_free(&ctx->spart); dev_free(&ctx->mean_pc);
+    dev_free(&ctx->var_pc); dev_free(&ctx->Xs); dev_free(&ctx->estd);
+    ctx->Wcap = 0;
+    int rc;
+    if ((rc = dev_alloc(ctx, &ctx->X, Np * dpad))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->Xsc, P * Np * dpad))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->ls, P * dpad))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->amp, P))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->noise, P))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->Z, P * Np))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->K, P * Np * Np))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->Linv, P * Np * Np))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->T, P * Np * Np))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->yv, P * Np))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->alpha, P * Np))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->info, P))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->lmlbuf, P * 4 + P * (d + 2)))) return rc;
+    free(ctx->h_theta);
+    ctx->h_theta = (double*)calloc((size_t)(P * (d + 2)), sizeof(double));
+    std::vector<double> xp((size_t)(Np * dpad), 0.0), zp((size_t)(P * Np), 0.0);
+    for (int64_t i = 0; i < N; ++i)
+        for (int64_t k = 0; k < d; ++k) xp[i * dpad + k] = X_host[i * d + k];
+    for (int64_t p = 0; p < P; ++p)
+        for (int64_t i = 0; i < N; ++i) zp[p * Np + i] = Z_host[p * N + i];
+    GPB_HIP(hipMemcpy(ctx->X, xp.data(), sizeof(double) * xp.size(), hipMemcpyHostToDevice));
+    GPB_HIP(hipMemcpy(ctx->Z, zp.data(), sizeof(double) * zp.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int gpb_gp_set_theta(gpb_ctx* ctx, const double* theta_host) {
+    if (!ctx) return GPB_E_ARG;
+    if (ctx->N == 0) GPB_FAIL(GPB_E_STATE, "gpb_gp_set_theta before gpb_gp_set");
+    if (!theta_host) GPB_FAIL(GPB_E_ARG, "gpb_gp_set_theta: null theta");
+    const int64_t P = ctx->P, d = ctx->d, dpad = ctx->dpad;
+    for (int64_t i = 0; i < P * (d + 2); ++i)
+        if (!isfinite(theta_host[i])) GPB_FAIL(GPB_E_ARG, "gpb_gp_set_theta: non-finite theta");
+    memcpy(ctx->h_theta, theta_host, sizeof(double) * P * (d + 2));
+    std::vector<double> ls((size_t)(P * dpad), 1.0), amp((size_t)P), noise((size_t)P);
+    for (int64_t p = 0; p < P; ++p) {
+        const double* th = theta_host + p * (d + 2);
+        amp[p] = exp(th[0]);
+        for (int64_t k = 0; k < d; ++k) ls[p * dpad + k] = exp(th[1 + k]);
+        noise[p] = exp(th[d + 1]);
+    }
+    GPB_HIP(hipSetDevice(ctx->device));
+    GPB_HIP(hipStreamSynchronize(ctx->stream));     // host vectors are about to go out of scope
+    GPB_HIP(hipMemcpy(ctx->ls, ls.data(), sizeof(double) * ls.size(), hipMemcpyHostToDevice));
+    GPB_HIP(hipMemcpy(ctx->amp, amp.data(), sizeof(double) * P, hipMemcpyHostToDevice));
+    GPB_HIP(hipMemcpy(ctx->noise, noise.data(), sizeof(double) * P, hipMemcpyHostToDevice));
+    int rc = launch_scale_design(ctx);
+    if (rc) return rc;
+    ctx->have_theta = true;
+    ctx->factored = false;
+    return 0;
+}
+
+static int factor_impl(gpb_ctx* ctx, int* info_host, bool need_inverse) {
+    if (!ctx->have_theta) GPB_FAIL(GPB_E_STATE, "gpb_gp_factor before gpb_gp_set_theta");
+    GPB_HIP(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = launch_kmat(ctx))) return rc;
+    if ((rc = launch_potrf(ctx))) return rc;
+    if (need_inverse) {
+        if ((rc = launch_trtri(ctx))) return rc;
+        if ((rc = launch_alpha(ctx))) return rc;
+    }
+    std::vector<int> info((size_t)ctx->P, 0);
+    GPB_HIP(hipMemcpyAsync(info.data(), ctx->info, sizeof(int) * ctx->P, hipMemcpyDeviceToHost, ctx->stream));
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    int first = 0;
+    for (int64_t p = 0; p < ctx->P; ++p) {
+        if (info_host) info_host[p] = info[p];
+        if (info[p] != 0 && first == 0) first = info[p];
+    }
+    return first;
+}
+
+extern "C" int gpb_gp_factor(gpb_ctx* ctx, int* info_host) {
+    if (!ctx) return GPB_E_ARG;
+    int rc = factor_impl(ctx, info_host, true);
+    if (rc < 0) return rc;
+    ctx->factored = true;        // per-GP failures are reported through info / the return code
+    if (rc > 0) ctx->err = "gpb_gp_factor: kernel matrix not positive definite (see info)";
+    return rc;
+}
+
+extern "C" int gpb_gp_get(gpb_ctx* ctx, int what, double* out_host) {
+    if (!ctx || !out_host) return GPB_E_ARG;
+    if (ctx->N == 0) GPB_FAIL(GPB_E_STATE, "gpb_gp_get before gpb_gp_set");
+    const int64_t N = ctx->N, Np = ctx->Np, P = ctx->P;
+    GPB_HIP(hipSetDevice(ctx->device));
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    if (what == GPB_GET_ALPHA) {
+        for (int64_t p = 0; p < P; ++p)
+            GPB_HIP(hipMemcpy(out_host + p * N, ctx->alpha + p * Np, sizeof(double) * N, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    const double* src = (what == GPB_GET_K || what == GPB_GET_L) ? ctx->K : (what == GPB_GET_LINV ? ctx->Linv : nullptr);
+    if (!src) GPB_FAIL(GPB_E_ARG, "gpb_gp_get: unknown selector");
+    for (int64_t p = 0; p < P; ++p) {
+        GPB_HIP(hipMemcpy2D(out_host + p * N * N, sizeof(double) * N, src + p * Np * Np, sizeof(double) * Np,
+                            sizeof(double) * N, (size_t)N, hipMemcpyDeviceToHost));
+    }
+    if (what == GPB_GET_L) {        // upper blocks hold scratch from the trailing updates: zero them
+        for (int64_t p = 0; p < P; ++p)
+            for (int64_t i = 0; i < N; ++i)
+                for (int64_t j = i + 1; j < N; ++j) out_host[p * N * N + i * N + j] = 0.0;
+    }
+    return 0;
+}
+
+extern "C" int gpb_gp_lml(gpb_ctx* ctx, const double* theta_host, double* lml_host, double* grad_host,
+                          int* info_host) {
+    if (!ctx || !theta_host || !lml_host) return GPB_E_ARG;
+    int rc = gpb_gp_set_theta(ctx, theta_host);
+    if (rc) return rc;
+    std::vector<int> info((size_t)ctx->P, 0);
+    rc = factor_impl(ctx, info.data(), true);
+    if (rc < 0) return rc;
+    const int64_t P = ctx->P, d = ctx->d;
+    if ((rc = launch_lml_value(ctx))) return rc;
+    double* gdev = ctx->lmlbuf + P * 4;
+    if (grad_host) {
+        if ((rc = launch_lml_grad(ctx, gdev))) return rc;
+    }
+    std::vector<double> buf((size_t)(P * 4 + P * (d + 2)));
+    GPB_HIP(hipMemcpyAsync(buf.data(), ctx->lmlbuf, sizeof(double) * buf.size(), hipMemcpyDeviceToHost, ctx->stream));
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    for (int64_t p = 0; p < P; ++p) {
+        const bool bad = info[p] != 0;
+        lml_host[p] = bad ? -INFINITY : buf[p * 4];                  // sk:_gpr.py:588-589
+        if (grad_host)
+            for (int64_t k = 0; k < d + 2; ++k) grad_host[p * (d + 2) + k] = bad ? 0.0 : buf[P * 4 + p * (d + 2) + k];
+        if (info_host) info_host[p] = info[p];
+    }
+    ctx->factored = true;
+    return 0;
+}
+
+extern "C" int gpb_gp_predict(gpb_ctx* ctx, const double* Xs, int64_t W, int on_device, double* mean,
+                              double* var) {
+    if (!ctx || !Xs || !mean || W < 0) return GPB_E_ARG;
+    if (W == 0) return 0;
+    GPB_HIP(hipSetDevice(ctx->device));
+    const double* Xs_dev;
+    int rc = stage_inputs(ctx, Xs, W, on_device, nullptr, &Xs_dev, nullptr);
+    if (rc) return rc;
+    if ((rc = launch_predict(ctx, Xs_dev, W, var != nullptr))) return rc;
+    const int64_t P = ctx->P;
+    dim3 grid((unsigned)((W + 255) / 256));
+    if (on_device) {
+        hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->mean_pc, mean, W, ctx->Wcap, (int)P);
+        if (var) hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->var_pc, var, W, ctx->Wcap, (int)P);
+        GPB_HIP(hipGetLastError());
+        return 0;
+    }
+    if ((rc = ensure_out(ctx, 2 * W * P))) return rc;
+    hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->mean_pc, ctx->out_stage, W, ctx->Wcap, (int)P);
+    GPB_HIP(hipMemcpyAsync(mean, ctx->out_stage, sizeof(double) * W * P, hipMemcpyDeviceToHost, ctx->stream));
+    if (var) {
+        hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->var_pc, ctx->out_stage + W * P, W, ctx->Wcap, (int)P);
+        GPB_HIP(hipMemcpyAsync(var, ctx->out_stage + W * P, sizeof(double) * W * P, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- emulator transform
+extern "C" int gpb_emu_set_transform(gpb_ctx* ctx, int mode, int64_t M, const double* A_host, const double* mu_host,
+                                     const double* cov_trunc_host, const double* scale_host) {
+    if (!ctx) return GPB_E_ARG;
+    if (ctx->N == 0) GPB_FAIL(GPB_E_STATE, "gpb_emu_set_transform before gpb_gp_set");
+    if (mode < 0 || mode > 3 || M < 1 || !mu_host) GPB_FAIL(GPB_E_ARG, "gpb_emu_set_transform: bad arguments");
+    const bool no_pca = (mode == GPB_MODE_NO_PCA || mode == GPB_MODE_NO_PCA_EXPDIAG);
+    if (!no_pca && !A_host) GPB_FAIL(GPB_E_ARG, "gpb_emu_set_transform: PCA mode needs A");
+    if (no_pca && (M != ctx->P || !scale_host)) GPB_FAIL(GPB_E_ARG, "gpb_emu_set_transform: no-PCA mode needs M == P and scale");
+    GPB_HIP(hipSetDevice(ctx->device));
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t P = ctx->P;
+    int rc;
+    if ((rc = dev_alloc(ctx, &ctx->A, P * M))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->mu, M))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->scale, M))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->C0, M * M))) return rc;
+    std::vector<double> zeros((size_t)(M * M > P * M ? M * M : P * M), 0.0), ones((size_t)M, 1.0);
+    GPB_HIP(hipMemcpy(ctx->A, A_host ? A_host : zeros.data(), sizeof(double) * P * M, hipMemcpyHostToDevice));
+    GPB_HIP(hipMemcpy(ctx->mu, mu_host, sizeof(double) * M, hipMemcpyHostToDevice));
+    GPB_HIP(hipMemcpy(ctx->scale, scale_host ? scale_host : ones.data(), sizeof(double) * M, hipMemcpyHostToDevice));
+    GPB_HIP(hipMemcpy(ctx->C0, cov_trunc_host ? cov_trunc_host : zeros.data(), sizeof(double) * M * M, hipMemcpyHostToDevice));
+    ctx->mode = mode; ctx->M = M; ctx->have_transform = true; ctx->have_like = false;
+    return 0;
+}
+
+extern "C" int gpb_emu_predict(gpb_ctx* ctx, const double* Xs, int64_t W, int on_device, const double* extra_std,
+                               double* mean, double* cov) {
+    if (!ctx || !Xs || !mean || W < 0) return GPB_E_ARG;
+    if (!ctx->have_transform) GPB_FAIL(GPB_E_STATE, "gpb_emu_predict before gpb_emu_set_transform");
+    if (W == 0) return 0;
+    GPB_HIP(hipSetDevice(ctx->device));
+    const double *Xs_dev, *estd_dev;
+    int rc = stage_inputs(ctx, Xs, W, on_device, extra_std, &Xs_dev, &estd_dev);
+    if (rc) return rc;
+    if ((rc = launch_predict(ctx, Xs_dev, W, cov != nullptr))) return rc;
+    const int64_t M = ctx->M;
+    if (on_device) return launch_obs(ctx, W, estd_dev, mean, cov);
+    const int64_t need = W * M + (cov ? W * M * M : 0);
+    if ((rc = ensure_out(ctx, need))) return rc;
+    double* dm = ctx->out_stage;
+    double* dc = cov ? ctx->out_stage + W * M : nullptr;
+    if ((rc = launch_obs(ctx, W, estd_dev, dm, dc))) return rc;
+    GPB_HIP(hipMemcpyAsync(mean, dm, sizeof(double) * W * M, hipMemcpyDeviceToHost, ctx->stream));
+    if (cov) GPB_HIP(hipMemcpyAsync(cov, dc, sizeof(double) * W * M * M, hipMemcpyDeviceToHost, ctx->stream));
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- likelihood block
+extern "C" int gpb_like_set(gpb_ctx* ctx, const double* yexp_host, const double* cov_exp_host) {
+    if (!ctx) return GPB_E_ARG;
+    if (!ctx->have_transform) GPB_FAIL(GPB_E_STATE, "gpb_like_set before gpb_emu_set_transform");
+    if (!yexp_host || !cov_exp_host) GPB_FAIL(GPB_E_ARG, "gpb_like_set: null input");
+    GPB_HIP(hipSetDevice(ctx->device));
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t M = ctx->M;
+    int rc;
+    if ((rc = dev_alloc(ctx, &ctx->yexp, M))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->Cexp, M * M))) return rc;
+    GPB_HIP(hipMemcpy(ctx->yexp, yexp_host, sizeof(double) * M, hipMemcpyHostToDevice));
+    GPB_HIP(hipMemcpy(ctx->Cexp, cov_exp_host, sizeof(double) * M * M, hipMemcpyHostToDevice));
+    ctx->have_like = true;
+    return 0;
+}
+
+extern "C" int gpb_loglike(gpb_ctx* ctx, const double* Xs, int64_t W, int on_device, double* ll, int accumulate,
+                           int* n_notpd_host) {
+    if (!ctx || !Xs || !ll || W < 0) return GPB_E_ARG;
+    if (!ctx->have_like) GPB_FAIL(GPB_E_STATE, "gpb_loglike before gpb_like_set");
+    if (W == 0) { if (n_notpd_host) *n_notpd_host = 0; return 0; }
+    GPB_HIP(hipSetDevice(ctx->device));
+    const double* Xs_dev;
+    int rc = stage_inputs(ctx, Xs, W, on_device, nullptr, &Xs_dev, nullptr);
+    if (rc) return rc;
+    if (n_notpd_host) GPB_HIP(hipMemsetAsync(ctx->notpd, 0, sizeof(int), ctx->stream));
+    if ((rc = launch_predict(ctx, Xs_dev, W, true))) return rc;
+    if (on_device) {
+        if ((rc = launch_loglike(ctx, W, ll, accumulate != 0))) return rc;
+    } else {
+        if ((rc = ensure_out(ctx, W))) return rc;
+        if (accumulate) GPB_HIP(hipMemcpyAsync(ctx->out_stage, ll, sizeof(double) * W, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = launch_loglike(ctx, W, ctx->out_stage, accumulate != 0))) return rc;
+        GPB_HIP(hipMemcpyAsync(ll, ctx->out_stage, sizeof(double) * W, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (n_notpd_host) {
+        GPB_HIP(hipMemcpyAsync(n_notpd_host, ctx->notpd, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        GPB_HIP(hipStreamSynchronize(ctx->stream));
+    } else if (!on_device) {
+        GPB_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+extern "C" int gpb_mvn_loglike(gpb_ctx* ctx, const double* dY, const double* cov, int64_t W, int64_t M,
+                               int on_device, double* ll, int* n_notpd_host) {
+    if (!ctx || !dY || !cov || !ll || W < 0 || M < 1) return GPB_E_ARG;
+    if (W == 0) { if (n_notpd_host) *n_notpd_host = 0; return 0; }
+    GPB_HIP(hipSetDevice(ctx->device));
+    GPB_HIP(hipMemsetAsync(ctx->notpd, 0, sizeof(int), ctx->stream));
+    int rc;
+    if (on_device) {
+        if ((rc = launch_mvn(ctx, dY, cov, W, M, ll))) return rc;
+    } else {
+        const int64_t need = W * M + W * M * M + W;
+        if ((rc = ensure_out(ctx, need))) return rc;
+        double* dy = ctx->out_stage; double* dc = dy + W * M; double* dl = dc + W * M * M;
+        GPB_HIP(hipMemcpyAsync(dy, dY, sizeof(double) * W * M, hipMemcpyHostToDevice, ctx->stream));
+        GPB_HIP(hipMemcpyAsync(dc, cov, sizeof(double) * W * M * M, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = launch_mvn(ctx, dy, dc, W, M, dl))) return rc;
+        GPB_HIP(hipMemcpyAsync(ll, dl, sizeof(double) * W, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (n_notpd_host) GPB_HIP(hipMemcpyAsync(n_notpd_host, ctx->notpd, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (n_notpd_host || !on_device) GPB_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- RCCL (lazy dlopen)
+namespace {
+struct NcclId { char internal[128]; };
+typedef int (*fn_getuid)(NcclId*);
+typedef int (*fn_init)(void**, int, NcclId, int);
+typedef int (*fn_allgather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*fn_destroy)(void*);
+struct Rccl {
+    void* h = nullptr;
+    fn_getuid getuid = nullptr; fn_init init = nullptr; fn_allgather allgather = nullptr; fn_destroy destroy = nullptr;
+    bool load() {
+        if (h) return true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        if (!h) return false;
+        getuid = (fn_getuid)dlsym(h, "ncclGetUniqueId");
+        init = (fn_init)dlsym(h, "ncclCommInitRank");
+        allgather = (fn_allgather)dlsym(h, "ncclAllGather");
+        destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
+        return getuid && init && allgather && destroy;
+    }
+} g_rccl;
+constexpr int NCCL_DOUBLE = 8;   // ncclFloat64
+}  // namespace
+
+extern "C" int gpb_dist_uid(void* uid128_host) {
+    if (!uid128_host) return GPB_E_ARG;
+    if (!g_rccl.load()) return GPB_E_RCCL;
+    NcclId id;
+    if (g_rccl.getuid(&id) != 0) return GPB_E_RCCL;
+    memcpy(uid128_host, &id, sizeof(id));
+    return 0;
+}
+
+extern "C" int gpb_dist_init(gpb_ctx* ctx, int rank, int nranks, const void* uid128_host) {
+    if (!ctx || !uid128_host || nranks < 1 || rank < 0 || rank >= nranks) return GPB_E_ARG;
+    if (!g_rccl.load()) GPB_FAIL(GPB_E_RCCL, "gpb_dist_init: cannot load librccl");
+    GPB_HIP(hipSetDevice(ctx->device));
+    NcclId id;
+    memcpy(&id, uid128_host, sizeof(id));
+    void* comm = nullptr;
+    if (g_rccl.init(&comm, nranks, id, rank) != 0) GPB_FAIL(GPB_E_RCCL, "gpb_dist_init: ncclCommInitRank failed");
+    ctx->comm = comm; ctx->rank = rank; ctx->nranks = nranks;
+    return 0;
+}
+
+extern "C" int gpb_dist_allgather(gpb_ctx* ctx, const double* send_dev, double* recv_dev, int64_t count) {
+    if (!ctx || !send_dev || !recv_dev || count < 0) return GPB_E_ARG;
+    if (!ctx->comm) GPB_FAIL(GPB_E_STATE, "gpb_dist_allgather before gpb_dist_init");
+    if (g_rccl.allgather(send_dev, recv_dev, (size_t)count, NCCL_DOUBLE, ctx->comm, ctx->stream) != 0)
+        GPB_FAIL(GPB_E_RCCL, "ncclAllGather failed");
+    return 0;
+}
+
+extern "C" int gpb_dist_finalize(gpb_ctx* ctx) {
+    if (!ctx) return GPB_E_ARG;
+    if (ctx->comm && g_rccl.destroy) { g_rccl.destroy(ctx->comm); ctx->comm = nullptr; }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- test hooks
+extern "C" int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K, const double* A_host,
+                             const double* B_host, double* C_host, int b_trans) {
+    if (!ctx || !A_host || !B_host || !C_host) return GPB_E_ARG;
+    if (M < 2 || N < 2 || K < 16 || (K % 16) || (M % 2) || (N % 2)) GPB_FAIL(GPB_E_ARG, "gpb_test_gemm: K%16, M%2, N%2");
+    GPB_HIP(hipSetDevice(ctx->device));
+    double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+    GPB_HIP(hipMalloc(&dA, sizeof(double) * M * K));
+    GPB_HIP(hipMalloc(&dB, sizeof(double) * K * N));
+    GPB_HIP(hipMalloc(&dC, sizeof(double) * M * N));
+    GPB_HIP(hipMemcpy(dA, A_host, sizeof(double) * M * K, hipMemcpyHostToDevice));
+    GPB_HIP(hipMemcpy(dB, B_host, sizeof(double) * K * N, hipMemcpyHostToDevice));
+    int rc = launch_test_gemm(ctx, M, N, K, dA, dB, dC, b_trans);
+    if (rc == 0) {
+        GPB_HIP(hipStreamSynchronize(ctx->stream));
+        GPB_HIP(hipMemcpy(C_host, dC, sizeof(double) * M * N, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
+    return rc;
+}
+
+extern "C" int gpb_probe_fp64(gpb_ctx* ctx, int mode, double* tflops_out) {
+    if (!ctx || !tflops_out || mode < 0 || mode > 2) return GPB_E_ARG;
+    GPB_HIP(hipSetDevice(ctx->device));
+    return launch_probe(ctx, mode, tflops_out);
+}

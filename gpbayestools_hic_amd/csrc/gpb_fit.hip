@@ -1,0 +1,533 @@
+// gpb_fit.hip — fit-side kernels: K(X,X) assembly, blocked right-looking fp64 Cholesky,
+// triangular inverse by recursive block doubling, alpha = K^-1 z, log-marginal likelihood
+// and its gradient.  Replaces the body of sklearn GPR.fit / log_marginal_likelihood
+// (sk:_gpr.py:346-364, 537-652) that the reference calls from src/emulator.py:309-315.
+//
+// All matrices are padded to Np = multiple of 64 with an identity block, so that no kernel
+// has ragged edges in N:  K_pad = [[K,0],[0,I]]  =>  L_pad = [[L,0],[0,I]], same for L^-1.
+#include "gpb_internal.h"
+#include "gemm_tile.h"
+#include <math.h>
+#include <vector>
+
+namespace gpb {
+
+// ------------------------------------------------------------------ shape functions
+template <int KIND>
+__device__ __forceinline__ double shape_fn(double r2) {
+    if (KIND == GPB_KERNEL_RBF) {
+        return exp(-0.5 * r2);                                   // sk:kernels.py:1557
+    } else if (KIND == GPB_KERNEL_MATERN15) {
+        const double t = sqrt(r2) * 1.7320508075688772;          // sk:kernels.py:1721-1723
+        return (1.0 + t) * exp(-t);
+    } else {
+        const double t = sqrt(r2) * 2.23606797749979;            // sk:kernels.py:1724-1726
+        return (1.0 + t + t * t / 3.0) * exp(-t);
+    }
+}
+
+// ------------------------------------------------------------------ design scaling
+// Xsc[p][n][k] = X[n][k] / l_p[k]   (sklearn divides: sk:kernels.py:1556,1564)
+__global__ void k_scale_design(const double* __restrict__ X, const double* __restrict__ ls,
+                               double* __restrict__ Xsc, int64_t Np, int dpad) {
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int p = blockIdx.y;
+    if (idx >= Np * dpad) return;
+    const int k = idx % dpad;
+    Xsc[(int64_t)p * Np * dpad + idx] = X[idx] / ls[p * dpad + k];
+}
+
+int launch_scale_design(gpb_ctx* ctx) {
+    const int64_t tot = ctx->Np * ctx->dpad;
+    dim3 grid((unsigned)((tot + 255) / 256), (unsigned)ctx->P);
+    hipLaunchKernelGGL(k_scale_design, grid, dim3(256), 0, ctx->stream, ctx->X, ctx->ls, ctx->Xsc,
+                       ctx->Np, (int)ctx->dpad);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ K(X,X)
+// One 64x64 tile per workgroup; scaled design rows staged in LDS; HBM-write bound
+// (8*Np^2 bytes per GP).  Diagonal: c*1 + sigma_n^2 + alpha (sk:kernels.py:1559-1560,
+// 1401-1412; sk:_gpr.py:347).  Padding rows/cols: identity.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_kmat(const double* __restrict__ Xsc, const double* __restrict__ amp,
+                                              const double* __restrict__ noise, double alpha_reg,
+                                              double* __restrict__ K, int64_t N, int64_t Np, int dpad) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int p = blockIdx.z;
+    const int64_t i0 = (int64_t)blockIdx.y * 64, j0 = (int64_t)blockIdx.x * 64;
+    const int ldx = dpad + 1;
+    double* Xi = sm;
+    double* Xj = sm + 64 * ldx;
+    const double* Xp = Xsc + (int64_t)p * Np * dpad;
+    for (int e = threadIdx.x; e < 64 * dpad; e += 256) {
+        const int r = e / dpad, k = e % dpad;
+        Xi[r * ldx + k] = Xp[(i0 + r) * dpad + k];
+        Xj[r * ldx + k] = Xp[(j0 + r) * dpad + k];
+    }
+    __syncthreads();
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    double r2[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
+    for (int k = 0; k < dpad; ++k) {
+        double xi[4], xj[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) xi[a] = Xi[(ty + 16 * a) * ldx + k];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) xj[b] = Xj[(tx + 16 * b) * ldx + k];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const double df = xi[a] - xj[b];
+                r2[a][b] = fma(df, df, r2[a][b]);
+            }
+    }
+    const double c = amp[p], dg = amp[p] + noise[p] + alpha_reg;
+    double* Kp = K + (int64_t)p * Np * Np;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int64_t i = i0 + ty + 16 * a, j = j0 + tx + 16 * b;
+            double v;
+            if (i >= N || j >= N) v = (i == j) ? 1.0 : 0.0;
+            else if (i == j) v = dg;
+            else v = c * shape_fn<KIND>(r2[a][b]);
+            Kp[i * Np + j] = v;
+        }
+}
+
+int launch_kmat(gpb_ctx* ctx) {
+    dim3 grid((unsigned)(ctx->Np / 64), (unsigned)(ctx->Np / 64), (unsigned)ctx->P);
+    const size_t sh = 2 * 64 * (ctx->dpad + 1) * sizeof(double);
+#define GPB_KMAT(KIND)                                                                          \
+    hipLaunchKernelGGL(k_kmat<KIND>, grid, dim3(256), sh, ctx->stream, ctx->Xsc, ctx->amp,       \
+                       ctx->noise, ctx->alpha_reg, ctx->K, ctx->N, ctx->Np, (int)ctx->dpad)
+    if (ctx->kind == GPB_KERNEL_RBF) GPB_KMAT(GPB_KERNEL_RBF);
+    else if (ctx->kind == GPB_KERNEL_MATERN15) GPB_KMAT(GPB_KERNEL_MATERN15);
+    else GPB_KMAT(GPB_KERNEL_MATERN25);
+#undef GPB_KMAT
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ Cholesky: diagonal block
+// Factor the 64x64 diagonal block kb in LDS (right-looking, unblocked), invert the factor,
+// write L_kk back (upper zeroed) and L_kk^-1 into the diagonal block of Linv.
+// info[p] = 1-based global index of the first non-positive pivot (LAPACK dpotrf convention).
+__global__ __launch_bounds__(256) void k_potf2_inv(double* __restrict__ K, double* __restrict__ Linv,
+                                                   int64_t Np, int64_t kb, int* __restrict__ info) {
+    __shared__ double a[64][65];
+    __shared__ double x[64][65];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int64_t c0 = kb * 64;
+    double* Kp = K + (int64_t)p * Np * Np + c0 * Np + c0;
+    double* Lp = Linv + (int64_t)p * Np * Np + c0 * Np + c0;
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        a[r][c] = Kp[(int64_t)r * Np + c];
+        x[r][c] = 0.0;
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    for (int j = 0; j < 64; ++j) {
+        const double ajj = a[j][j];
+        if (tid == 0 && !(ajj > 0.0)) {
+            if (info[p] == 0) info[p] = (int)(c0 + j + 1);
+        }
+        const double dd = sqrt(ajj);
+        __syncthreads();
+        if (tid < 64) {
+            if (tid > j) a[tid][j] = a[tid][j] / dd;
+            else if (tid == j) a[j][j] = dd;
+        }
+        __syncthreads();
+        for (int i = j + 1 + ty; i < 64; i += 16) {
+            const double lij = a[i][j];
+            for (int k = j + 1 + tx; k <= i; k += 16) a[i][k] = fma(-lij, a[k][j], a[i][k]);
+        }
+        __syncthreads();
+    }
+    // inverse of the lower-triangular factor: 4 threads per column, forward substitution
+    const int c = tid >> 2, sub = tid & 3;
+    if (sub == 0) x[c][c] = 1.0 / a[c][c];
+    __syncthreads();
+    for (int i = 1; i < 64; ++i) {
+        double s = 0.0;
+        if (i > c) {
+            for (int k = c + sub; k < i; k += 4) s = fma(a[i][k], x[k][c], s);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (i > c && sub == 0) x[i][c] = -s / a[i][i];
+        __syncthreads();
+    }
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int r = e >> 6, cc = e & 63;
+        Kp[(int64_t)r * Np + cc] = (cc <= r) ? a[r][cc] : 0.0;
+        Lp[(int64_t)r * Np + cc] = (cc <= r) ? x[r][cc] : 0.0;
+    }
+}
+
+// Panel: L_ik = A_ik * L_kk^-T for the 64-row blocks below the diagonal block.
+__global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ K, const double* __restrict__ Linv,
+                                                    int64_t Np, int64_t kb) {
+    __shared__ double a[64][65];
+    __shared__ double x[64][65];
+    const int p = blockIdx.y, tid = threadIdx.x;
+    const int64_t c0 = kb * 64, r0 = (kb + 1 + blockIdx.x) * 64;
+    double* Ap = K + (int64_t)p * Np * Np + r0 * Np + c0;
+    const double* Xp = Linv + (int64_t)p * Np * Np + c0 * Np + c0;
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        a[r][c] = Ap[(int64_t)r * Np + c];
+        x[r][c] = Xp[(int64_t)r * Np + c];
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    double o[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) o[u][v] = 0.0;
+    // out[i][j] = sum_k a[i][k] * x[j][k]
+    for (int k = 0; k < 64; ++k) {
+        double ai[4], xj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ai[u] = a[ty + 16 * u][k];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) xj[v] = x[tx + 16 * v][k];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) o[u][v] = fma(ai[u], xj[v], o[u][v]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Ap[(int64_t)(ty + 16 * u) * Np + tx + 16 * v] = o[u][v];
+}
+
+// Trailing update (SYRK): A[r0+.., r0+..] -= Lp Lp^T on the lower 128x128 tiles, K = 64 (MFMA).
+__global__ __launch_bounds__(256, 2) void k_syrk(double* __restrict__ K, int64_t Np, int64_t kb) {
+    __shared__ TileLds lds;
+    const int p = blockIdx.y;
+    // linear lower-triangle tile index -> (ti, tj), tj <= ti
+    const int t = blockIdx.x;
+    int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int64_t c0 = kb * 64, r0 = c0 + 64;
+    const int64_t nt = Np - r0;
+    const int64_t mb = (int64_t)ti * 128, nb = (int64_t)tj * 128;
+    const int m_ext = (int)imin64(128, nt - mb), n_ext = (int)imin64(128, nt - nb);
+    double* Kp = K + (int64_t)p * Np * Np;
+    const double* Pn = Kp + r0 * Np + c0;   // panel: rows r0.., cols c0..c0+63
+    d4 acc[4][4];
+    acc_zero(acc);
+    gemm_tile_loop<false, true>(Pn, Np, Pn, Np, mb, nb, m_ext, n_ext, 0, 64, lds, acc);
+    tile_store(Kp + r0 * Np + r0, Np, mb, nb, m_ext, n_ext, -1.0, true, acc);
+}
+
+int launch_potrf(gpb_ctx* ctx) {
+    const int64_t nb = ctx->Np / 64;
+    GPB_HIP(hipMemsetAsync(ctx->info, 0, sizeof(int) * ctx->P, ctx->stream));
+    GPB_HIP(hipMemsetAsync(ctx->Linv, 0, sizeof(double) * ctx->P * ctx->Np * ctx->Np, ctx->stream));
+    for (int64_t kb = 0; kb < nb; ++kb) {
+        hipLaunchKernelGGL(k_potf2_inv, dim3((unsigned)ctx->P), dim3(256), 0, ctx->stream, ctx->K, ctx->Linv,
+                           ctx->Np, kb, ctx->info);
+        const int64_t rem = nb - kb - 1;
+        if (rem > 0) {
+            hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)rem, (unsigned)ctx->P), dim3(256), 0, ctx->stream,
+                               ctx->K, ctx->Linv, ctx->Np, kb);
+            const int64_t nt128 = (rem * 64 + 127) / 128;
+            const int64_t ntiles = nt128 * (nt128 + 1) / 2;
+            hipLaunchKernelGGL(k_syrk, dim3((unsigned)ntiles, (unsigned)ctx->P), dim3(256), 0, ctx->stream,
+                               ctx->K, ctx->Np, kb);
+        }
+    }
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ L^-1 by block doubling
+// inv([[A,0],[C,B]]) = [[A^-1,0],[-B^-1 C A^-1, B^-1]].  Level hs: the hs-sized diagonal blocks
+// of Linv are complete; phase 1: T = C A^-1, phase 2: X21 = -B^-1 T.  Both are NN MFMA GEMMs
+// whose K range is clipped by the triangular operand.
+template <int PHASE>
+__global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict__ L, double* __restrict__ Linv,
+                                                        double* __restrict__ T, int64_t Np, int64_t hs,
+                                                        int ngroups) {
+    __shared__ TileLds lds;
+    const int p = blockIdx.z / ngroups, g = blockIdx.z % ngroups;
+    const int64_t c0 = (int64_t)g * 2 * hs, r0 = c0 + hs;
+    const int64_t n2 = imin64(hs, Np - r0);
+    const int64_t mb = (int64_t)blockIdx.y * 128, nb = (int64_t)blockIdx.x * 128;
+    if (n2 <= 0 || mb >= n2 || nb >= hs) return;
+    const int m_ext = (int)imin64(128, n2 - mb), n_ext = (int)imin64(128, hs - nb);
+    const int64_t off = (int64_t)p * Np * Np;
+    d4 acc[4][4];
+    acc_zero(acc);
+    if (PHASE == 1) {
+        // T[r0+m][c0+n] = sum_{k>=n} L[r0+m][c0+k] * Linv[c0+k][c0+n]
+        gemm_tile_loop<false, false>(L + off + r0 * Np + c0, Np, Linv + off + c0 * Np + c0, Np, mb, nb, m_ext,
+                                     n_ext, nb, hs, lds, acc);
+        tile_store(T + off + r0 * Np + c0, Np, mb, nb, m_ext, n_ext, 1.0, false, acc);
+    } else {
+        // Linv[r0+m][c0+n] = -sum_{k<=m} Linv[r0+m][r0+k] * T[r0+k][c0+n]
+        const int64_t k_end = imin64(mb + 128, n2);
+        gemm_tile_loop<false, false>(Linv + off + r0 * Np + r0, Np, T + off + r0 * Np + c0, Np, mb, nb, m_ext,
+                                     n_ext, 0, k_end, lds, acc);
+        tile_store(Linv + off + r0 * Np + c0, Np, mb, nb, m_ext, n_ext, -1.0, false, acc);
+    }
+}
+
+int launch_trtri(gpb_ctx* ctx) {
+    const int64_t Np = ctx->Np;
+    for (int64_t hs = 64; hs < Np; hs *= 2) {
+        const int ngroups = (int)((Np + 2 * hs - 1) / (2 * hs));
+        const unsigned tl = (unsigned)((hs + 127) / 128);
+        dim3 grid(tl, tl, (unsigned)(ngroups * ctx->P));
+        hipLaunchKernelGGL(k_trtri_level<1>, grid, dim3(256), 0, ctx->stream, ctx->K, ctx->Linv, ctx->T, Np, hs,
+                           ngroups);
+        hipLaunchKernelGGL(k_trtri_level<2>, grid, dim3(256), 0, ctx->stream, ctx->K, ctx->Linv, ctx->T, Np, hs,
+                           ngroups);
+    }
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ alpha = L^-T (L^-1 z)
+// y_i = sum_{k<=i} Linv[i][k] z_k : one wave per row, fixed-order shuffle reduction.
+__global__ __launch_bounds__(256) void k_lower_matvec(const double* __restrict__ Linv, const double* __restrict__ z,
+                                                      double* __restrict__ y, int64_t Np) {
+    const int p = blockIdx.y, lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const double* row = Linv + (int64_t)p * Np * Np + i * Np;
+    const double* zp = z + (int64_t)p * Np;
+    double s = 0.0;
+    for (int64_t k = lane; k <= i; k += 64) s = fma(row[k], zp[k], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) y[(int64_t)p * Np + i] = s;
+}
+// alpha_j = sum_{i>=j} Linv[i][j] y_i : 64 columns per workgroup, rows strided over 4 waves.
+__global__ __launch_bounds__(256) void k_lower_matvec_t(const double* __restrict__ Linv, const double* __restrict__ y,
+                                                        double* __restrict__ out, int64_t Np) {
+    __shared__ double red[4][64];
+    const int p = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t j0 = (int64_t)blockIdx.x * 64, j = j0 + lane;
+    const double* Lp = Linv + (int64_t)p * Np * Np;
+    const double* yp = y + (int64_t)p * Np;
+    double s = 0.0;
+    for (int64_t i = j0 + wave; i < Np; i += 4) s = fma(Lp[i * Np + j], yp[i], s);
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0) out[(int64_t)p * Np + j] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
+int launch_alpha(gpb_ctx* ctx) {
+    hipLaunchKernelGGL(k_lower_matvec, dim3((unsigned)(ctx->Np / 4), (unsigned)ctx->P), dim3(256), 0, ctx->stream,
+                       ctx->Linv, ctx->Z, ctx->yv, ctx->Np);
+    hipLaunchKernelGGL(k_lower_matvec_t, dim3((unsigned)(ctx->Np / 64), (unsigned)ctx->P), dim3(256), 0,
+                       ctx->stream, ctx->Linv, ctx->yv, ctx->alpha, ctx->Np);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ LML value
+// lml = -1/2 z.alpha - sum log L_ii - N/2 log 2pi   (sk:_gpr.py:609-611)
+__global__ __launch_bounds__(256) void k_lml_value(const double* __restrict__ L, const double* __restrict__ z,
+                                                   const double* __restrict__ alpha, double* __restrict__ out,
+                                                   int64_t N, int64_t Np) {
+    __shared__ double r1[256], r2[256];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const double* Lp = L + (int64_t)p * Np * Np;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t i = tid; i < Np; i += 256) {
+        s1 = fma(z[(int64_t)p * Np + i], alpha[(int64_t)p * Np + i], s1);
+        s2 += log(Lp[i * Np + i]);
+    }
+    r1[tid] = s1; r2[tid] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { r1[tid] += r1[tid + o]; r2[tid] += r2[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[p * 4 + 0] = -0.5 * r1[0] - r2[0] - 0.5 * (double)N * 1.8378770664093453;  // log(2 pi)
+        out[p * 4 + 1] = r1[0];
+        out[p * 4 + 2] = r2[0];
+    }
+}
+
+int launch_lml_value(gpb_ctx* ctx) {
+    hipLaunchKernelGGL(k_lml_value, dim3((unsigned)ctx->P), dim3(256), 0, ctx->stream, ctx->K, ctx->Z, ctx->alpha,
+                       ctx->lmlbuf, ctx->N, ctx->Np);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ LML gradient
+// K^-1 = L^-T L^-1 on the lower 128x128 tiles (TN MFMA GEMM, k >= m_base), into T.
+__global__ __launch_bounds__(256, 2) void k_kinv(const double* __restrict__ Linv, double* __restrict__ T,
+                                                 int64_t Np) {
+    __shared__ TileLds lds;
+    const int p = blockIdx.y, t = blockIdx.x;
+    int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int64_t mb = (int64_t)ti * 128, nb = (int64_t)tj * 128;
+    const int m_ext = (int)imin64(128, Np - mb), n_ext = (int)imin64(128, Np - nb);
+    const double* Lp = Linv + (int64_t)p * Np * Np;
+    d4 acc[4][4];
+    acc_zero(acc);
+    gemm_tile_loop<true, false>(Lp, Np, Lp, Np, mb, nb, m_ext, n_ext, mb, Np, lds, acc);
+    tile_store(T + (int64_t)p * Np * Np, Np, mb, nb, m_ext, n_ext, 1.0, false, acc);
+}
+
+// grad_t = 1/2 sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta_t  (sk:_gpr.py:625-647), never
+// materialising dK: each 64x64 lower tile recomputes the kernel and its d+2 derivatives
+// (sk:kernels.py:1574-1580, 1762-1766, 1276-1289, 1401-1410) and reduces them on the fly.
+template <int KIND, int DPAD>
+__global__ __launch_bounds__(256) void k_lml_grad(const double* __restrict__ Xsc, const double* __restrict__ amp,
+                                                  const double* __restrict__ noise,
+                                                  const double* __restrict__ alpha, const double* __restrict__ Kinv,
+                                                  double* __restrict__ gpart, int64_t N, int64_t Np, int d,
+                                                  int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int p = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+    int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int64_t i0 = (int64_t)ti * 64, j0 = (int64_t)tj * 64;
+    constexpr int ldx = DPAD + 1;
+    double* Xi = sm;
+    double* Xj = sm + 64 * ldx;
+    double* red = sm + 128 * ldx;            // [4 waves][DPAD+2]
+    const double* Xp = Xsc + (int64_t)p * Np * DPAD;
+    for (int e = tid; e < 64 * DPAD; e += 256) {
+        const int r = e / DPAD, k = e % DPAD;
+        Xi[r * ldx + k] = Xp[(i0 + r) * DPAD + k];
+        Xj[r * ldx + k] = Xp[(j0 + r) * DPAD + k];
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    const double c = amp[p];
+    const double* ap = alpha + (int64_t)p * Np;
+    const double* Kv = Kinv + (int64_t)p * Np * Np;
+    double g[DPAD + 2];
+#pragma unroll
+    for (int k = 0; k < DPAD + 2; ++k) g[k] = 0.0;
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
+            const int li = ty + 16 * a, lj = tx + 16 * b;
+            const int64_t i = i0 + li, j = j0 + lj;
+            if (i >= N || j >= N || j > i) continue;
+            const double w = (ap[i] * ap[j] - Kv[i * Np + j]) * ((i == j) ? 0.5 : 1.0);
+            double D[DPAD];
+            double r2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < DPAD; ++k) {
+                const double df = Xi[li * ldx + k] - Xj[lj * ldx + k];
+                D[k] = df * df;
+                r2 += D[k];
+            }
+            double ks, gl;   // ks: unit-amplitude kernel; gl: factor multiplying c*D_k in dK/dlog l_k
+            if (i == j) { ks = 1.0; gl = 0.0; }
+            else if (KIND == GPB_KERNEL_RBF) { ks = exp(-0.5 * r2); gl = ks; }
+            else if (KIND == GPB_KERNEL_MATERN15) {
+                const double tt = sqrt(3.0 * r2), e = exp(-tt);
+                ks = (1.0 + sqrt(r2) * 1.7320508075688772) * exp(-sqrt(r2) * 1.7320508075688772);
+                gl = 3.0 * e;
+            } else {
+                const double tt = sqrt(5.0 * r2), e = exp(-tt);
+                const double t2 = sqrt(r2) * 2.23606797749979;
+                ks = (1.0 + t2 + t2 * t2 / 3.0) * exp(-t2);
+                gl = (5.0 / 3.0) * (tt + 1.0) * e;
+            }
+            g[0] = fma(w, c * ks, g[0]);
+            const double wl = w * c * gl;
+#pragma unroll
+            for (int k = 0; k < DPAD; ++k) g[1 + k] = fma(wl, D[k], g[1 + k]);
+            if (i == j) g[DPAD + 1] = fma(w, noise[p], g[DPAD + 1]);
+        }
+    // fixed-order reduction: lanes (shuffle tree) -> waves (LDS) -> tile partial
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < DPAD + 2; ++k) {
+        double v = g[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave * (DPAD + 2) + k] = v;
+    }
+    __syncthreads();
+    if (tid < DPAD + 2) {
+        const double v = ((red[tid] + red[(DPAD + 2) + tid]) + red[2 * (DPAD + 2) + tid]) + red[3 * (DPAD + 2) + tid];
+        // output slots: [0]=log c, [1..d]=log l, [d+1]=log noise
+        int slot = -1;
+        if (tid == 0) slot = 0;
+        else if (tid <= d) slot = tid;
+        else if (tid == DPAD + 1) slot = d + 1;
+        if (slot >= 0) gpart[((int64_t)p * ntiles + t) * (d + 2) + slot] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_grad_final(const double* __restrict__ gpart, double* __restrict__ grad,
+                                                   int ntiles, int d) {
+    const int p = blockIdx.x, k = threadIdx.x;
+    if (k >= d + 2) return;
+    double s = 0.0;
+    for (int t = 0; t < ntiles; ++t) s += gpart[((int64_t)p * ntiles + t) * (d + 2) + k];
+    grad[p * (d + 2) + k] = s;   // 1/2 and the symmetric factor 2 are folded into w
+}
+
+template <int KIND>
+static int launch_grad_kind(gpb_ctx* ctx, int ntiles, double* gfinal) {
+    dim3 grid((unsigned)ntiles, (unsigned)ctx->P);
+#define GPB_GRAD(DP)                                                                              \
+    hipLaunchKernelGGL((k_lml_grad<KIND, DP>), grid, dim3(256), (128 * (DP + 1) + 4 * (DP + 2)) * sizeof(double), \
+                       ctx->stream, ctx->Xsc, ctx->amp, ctx->noise, ctx->alpha, ctx->T, ctx->gpart, ctx->N,        \
+                       ctx->Np, (int)ctx->d, ntiles)
+    switch (ctx->dpad) {
+        case 8: GPB_GRAD(8); break;
+        case 16: GPB_GRAD(16); break;
+        case 24: GPB_GRAD(24); break;
+        case 32: GPB_GRAD(32); break;
+        case 48: GPB_GRAD(48); break;
+        default: GPB_GRAD(64); break;
+    }
+#undef GPB_GRAD
+    hipLaunchKernelGGL(k_grad_final, dim3((unsigned)ctx->P), dim3(64), 0, ctx->stream, ctx->gpart, gfinal, ntiles,
+                       (int)ctx->d);
+    return 0;
+}
+
+int launch_lml_grad(gpb_ctx* ctx, double* grad_dev) {
+    const int64_t nt128 = (ctx->Np + 127) / 128;
+    hipLaunchKernelGGL(k_kinv, dim3((unsigned)(nt128 * (nt128 + 1) / 2), (unsigned)ctx->P), dim3(256), 0,
+                       ctx->stream, ctx->Linv, ctx->T, ctx->Np);
+    const int64_t nt64 = ctx->Np / 64;
+    const int ntiles = (int)(nt64 * (nt64 + 1) / 2);
+    const int64_t need = (int64_t)ctx->P * ntiles * (ctx->d + 2);
+    if (need > ctx->gpart_cap) {
+        if (ctx->gpart) GPB_HIP(hipFree(ctx->gpart));
+        GPB_HIP(hipMalloc(&ctx->gpart, need * sizeof(double)));
+        ctx->gpart_cap = need;
+    }
+    if (ctx->kind == GPB_KERNEL_RBF) launch_grad_kind<GPB_KERNEL_RBF>(ctx, ntiles, grad_dev);
+    else if (ctx->kind == GPB_KERNEL_MATERN15) launch_grad_kind<GPB_KERNEL_MATERN15>(ctx, ntiles, grad_dev);
+    else launch_grad_kind<GPB_KERNEL_MATERN25>(ctx, ntiles, grad_dev);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gpb

@@ -1,0 +1,115 @@
+// gpb_internal.h — context layout and launch prototypes shared by the .hip files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/gpbayes.h"
+
+namespace gpb {
+
+constexpr int NB = 64;          // Cholesky diagonal block / padding granule of N
+constexpr int WPAD = 128;       // walker-batch padding granule (GEMM tile width)
+constexpr int KX_CHUNK = 256;   // design points per kcross workgroup (mean partial granule)
+constexpr int MAX_D = 64;
+
+inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+__host__ __device__ inline int64_t imin64(int64_t a, int64_t b) { return a < b ? a : b; }
+
+}  // namespace gpb
+
+struct gpb_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // ---- GP state -------------------------------------------------------------
+    int64_t N = 0, Np = 0, d = 0, dpad = 0, P = 0;
+    int kind = 0;
+    double alpha_reg = 0.0;
+    bool have_theta = false, factored = false;
+    double* h_theta = nullptr;     // host [P][d+2]
+    double* X = nullptr;           // [Np][dpad]   raw design (pad rows/cols zero)
+    double* Xsc = nullptr;         // [P][Np][dpad] design / length_scale_p
+    double* ls = nullptr;          // [P][dpad]    length scales (1 in pad columns)
+    double* amp = nullptr;         // [P] c
+    double* noise = nullptr;       // [P] sigma_n^2
+    double* Z = nullptr;           // [P][Np]
+    double* K = nullptr;           // [P][Np][Np]  K, overwritten by L (lower) in gp_factor
+    double* Linv = nullptr;        // [P][Np][Np]
+    double* T = nullptr;           // [P][Np][Np]  workspace (trtri / K^-1)
+    double* yv = nullptr;          // [P][Np]      L^-1 z
+    double* alpha = nullptr;       // [P][Np]      K^-1 z
+    double* apart = nullptr;       // [Np/256][P][Np] alpha partials
+    int* info = nullptr;           // [P]
+    double* lmlbuf = nullptr;      // [P][4]
+    double* gpart = nullptr;       // gradient partials
+    int64_t gpart_cap = 0;
+
+    // ---- predict workspace ------------------------------------------------------
+    int64_t Wcap = 0;              // padded capacity (multiple of WPAD)
+    double* Xs = nullptr;          // [Wcap][d] staged inputs (when caller passes host memory)
+    double* estd = nullptr;        // [Wcap]
+    double* KsT = nullptr;         // [P][Np][Wcap]
+    double* mpart = nullptr;       // [Np/KX_CHUNK][P][Wcap]
+    double* spart = nullptr;       // [Np/128 (ceil)][P][Wcap]
+    double* mean_pc = nullptr;     // [P][Wcap]
+    double* var_pc = nullptr;      // [P][Wcap]
+    double* out_stage = nullptr;   // staging for host outputs
+    int64_t out_cap = 0;
+
+    // ---- emulator transform / likelihood ----------------------------------------
+    int mode = 0;
+    int64_t M = 0;
+    bool have_transform = false, have_like = false;
+    double* A = nullptr;           // [P][M]
+    double* mu = nullptr;          // [M]
+    double* scale = nullptr;       // [M]
+    double* C0 = nullptr;          // [M][M] cov_trunc (zeros if absent)
+    double* yexp = nullptr;        // [M]
+    double* Cexp = nullptr;        // [M][M]
+    double* mvn_ws = nullptr;      // global fallback for M > 128: [Wcap][M][M]
+    int64_t mvn_ws_cap = 0;
+    int* notpd = nullptr;          // device counter
+
+    // ---- RCCL ---------------------------------------------------------------------
+    void* comm = nullptr;
+    int rank = 0, nranks = 1;
+};
+
+#define GPB_HIP(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);               \
+            return GPB_E_HIP;                                                           \
+        }                                                                               \
+    } while (0)
+
+#define GPB_FAIL(code, msg)                                                             \
+    do {                                                                                \
+        ctx->err = (msg);                                                               \
+        return (code);                                                                  \
+    } while (0)
+
+namespace gpb {
+// fit side (gpb_fit.hip)
+int launch_scale_design(gpb_ctx* ctx);
+int launch_kmat(gpb_ctx* ctx);
+int launch_potrf(gpb_ctx* ctx);
+int launch_trtri(gpb_ctx* ctx);
+int launch_alpha(gpb_ctx* ctx);
+int launch_lml_value(gpb_ctx* ctx);
+int launch_lml_grad(gpb_ctx* ctx, double* grad_host);
+// predict side (gpb_predict.hip)
+int ensure_wcap(gpb_ctx* ctx, int64_t W);
+int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var);
+// likelihood (gpb_like.hip)
+int launch_obs(gpb_ctx* ctx, int64_t W, const double* estd_dev, double* mean_dev, double* cov_dev);
+int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate);
+int launch_mvn(gpb_ctx* ctx, const double* dY_dev, const double* cov_dev, int64_t W, int64_t M, double* ll_dev);
+// test hooks
+int launch_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K, const double* A, const double* B,
+                     double* C, int b_trans);
+int launch_probe(gpb_ctx* ctx, int mode, double* tflops);
+}  // namespace gpb

@@ -1,0 +1,361 @@
+// gpb_like.hip — PC -> observable transform, batched multivariate-normal log-likelihood,
+// prior box, and the emcee-equivalent stretch move.
+//   k_obs       Emulator.predict after the per-GP calls            src/emulator.py:555-605
+//   k_loglike   Chain._predict block + mvn_loglike, fused          src/mcmc.py:23-65,153-166,288-293
+//   k_box       strict prior box + constant                        src/mcmc.py:194-198,275-276,296-297
+//   k_propose / k_accept   emcee StretchMove (a=2) as driven by     src/mcmc.py:68-92,372-412
+#include "gpb_internal.h"
+#include <math.h>
+
+namespace gpb {
+
+// ------------------------------------------------------------------ observable transform (materialised)
+// one workgroup per walker; writes mean[w][M] and (optionally) cov[w][M][M]
+__global__ __launch_bounds__(256) void k_obs(const double* __restrict__ mean_pc, const double* __restrict__ var_pc,
+                                             const double* __restrict__ estd, int64_t Wld, int P, int M, int mode,
+                                             const double* __restrict__ A, const double* __restrict__ mu,
+                                             const double* __restrict__ scale, const double* __restrict__ C0,
+                                             double* __restrict__ mean_out, double* __restrict__ cov_out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* zm = sm;            // [P]
+    double* zv = sm + P;        // [P]
+    double* mo = sm + 2 * P;    // [M]
+    const int64_t w = blockIdx.x;
+    const int tid = threadIdx.x;
+    const bool no_pca = (mode == GPB_MODE_NO_PCA || mode == GPB_MODE_NO_PCA_EXPDIAG);
+    const bool expdiag = (mode == GPB_MODE_EXPDIAG || mode == GPB_MODE_NO_PCA_EXPDIAG);
+    const double e = estd ? estd[w] : 0.0;
+    for (int p = tid; p < P; p += 256) {
+        zm[p] = mean_pc[(int64_t)p * Wld + w];
+        zv[p] = var_pc ? (var_pc[(int64_t)p * Wld + w] + e * e) : 0.0;     // src/emulator.py:578-579
+    }
+    __syncthreads();
+    for (int m = tid; m < M; m += 256) {
+        double v;
+        if (!no_pca) {
+            v = 0.0;
+            for (int p = 0; p < P; ++p) v = fma(zm[p], A[p * M + m], v);   // :559-561, 373-374
+            v += mu[m];
+        } else {
+            v = zm[m] * scale[m] + mu[m];                                    // :563-565
+        }
+        if (expdiag) v = exp(v);                                             // :567-568
+        mo[m] = v;
+        mean_out[w * M + m] = v;
+    }
+    if (!cov_out) return;
+    __syncthreads();
+    double* co = cov_out + w * (int64_t)M * M;
+    for (int e2 = tid; e2 < M * M; e2 += 256) {
+        const int i = e2 / M, j = e2 % M;
+        double v;
+        if (!no_pca) {
+            if (expdiag && i != j) v = 0.0;
+            else {
+                v = 0.0;
+                for (int p = 0; p < P; ++p) v = fma(zv[p] * A[p * M + i], A[p * M + j], v);   // :584-586
+                v += C0[i * M + j];                                                            // :587
+            }
+        } else {
+            v = (i == j) ? zv[i] : 0.0;                                                        // :590-592
+        }
+        if (expdiag && i == j) {
+            const double f = sqrt(v) * mo[i];                                                  // :599-600
+            v = f * f;
+        }
+        co[e2] = v;
+    }
+}
+
+int launch_obs(gpb_ctx* ctx, int64_t W, const double* estd_dev, double* mean_dev, double* cov_dev) {
+    const size_t sh = (2 * ctx->P + ctx->M) * sizeof(double);
+    hipLaunchKernelGGL(k_obs, dim3((unsigned)W), dim3(256), sh, ctx->stream, ctx->mean_pc,
+                       cov_dev ? ctx->var_pc : nullptr, estd_dev, ctx->Wcap, (int)ctx->P, (int)ctx->M, ctx->mode,
+                       ctx->A, ctx->mu, ctx->scale, ctx->C0, mean_dev, cov_dev);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+// Right-looking Cholesky of the augmented (M+1) x M lower matrix held at c (LDS or global slab),
+// then ll[w] = -1/2 |v|^2 - sum log L_jj with v = last row.  Non-PD -> NaN and a counted status.
+__device__ __forceinline__ void chol_aug_finish(double* c, int ld, int M, double* dg, double* __restrict__ ll,
+                                                int64_t w, int accumulate, int* __restrict__ notpd) {
+    const int tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15;
+    bool bad = false;
+    for (int j = 0; j < M; ++j) {
+        const double ajj = c[j * ld + j];
+        if (!(ajj > 0.0)) bad = true;
+        const double dd = sqrt(ajj);
+        __syncthreads();
+        for (int i = j + 1 + tid; i <= M; i += 256) c[i * ld + j] = c[i * ld + j] / dd;
+        if (tid == 0) dg[j] = dd;
+        __syncthreads();
+        for (int i = j + 1 + ty; i <= M; i += 16) {
+            const double lij = c[i * ld + j];
+            const int kmax = (i < M) ? i : (M - 1);
+            for (int k = j + 1 + tx; k <= kmax; k += 16) c[i * ld + k] = fma(-lij, c[k * ld + j], c[i * ld + k]);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double q = 0.0, ld_sum = 0.0;
+        for (int j = 0; j < M; ++j) {
+            const double v = c[M * ld + j];
+            q = fma(v, v, q);
+            ld_sum += log(dg[j]);
+        }
+        double r = -0.5 * q - ld_sum;
+        if (bad) {
+            r = nan("");
+            atomicAdd(notpd, 1);
+        }
+        ll[w] = accumulate ? (ll[w] + r) : r;
+    }
+}
+
+// Generic batched mvn_loglike(y, cov) (src/mcmc.py:23-65) on caller-provided dY[W,M], cov[W,M,M].
+__global__ __launch_bounds__(256) void k_mvn(const double* __restrict__ dY, const double* __restrict__ cov, int M,
+                                             double* __restrict__ gws, double* __restrict__ ll,
+                                             int* __restrict__ notpd) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int64_t w = blockIdx.x;
+    const int tid = threadIdx.x, ld = M + 1;
+    double* dg = sm;
+    double* c = gws ? (gws + w * (int64_t)(M + 1) * ld) : (sm + M);
+    const double* cw = cov + w * (int64_t)M * M;
+    for (int e2 = tid; e2 < M * M; e2 += 256) {
+        const int i = e2 / M, j = e2 % M;
+        if (j <= i) c[i * ld + j] = cw[e2];
+    }
+    for (int m = tid; m < M; m += 256) c[M * ld + m] = dY[w * M + m];
+    __syncthreads();
+    chol_aug_finish(c, ld, M, dg, ll, w, 0, notpd);
+}
+
+// ------------------------------------------------------------------ fused block log-likelihood
+// One workgroup per walker.  Builds dY = mean - y_exp and C = cov_model + cov_exp directly in LDS
+// (or in a global scratch slab when M > 128), then factorises the augmented matrix
+//        [ C   . ]            [ L    0 ]
+//        [ dY^T . ]   ->      [ v^T  . ]     with  L v = dY,
+// so that  -1/2 dY^T C^-1 dY - sum log L_ii = -1/2 |v|^2 - sum log L_ii   (src/mcmc.py:42-65).
+__global__ __launch_bounds__(256) void k_loglike(const double* __restrict__ mean_pc,
+                                                 const double* __restrict__ var_pc, int64_t Wld, int P, int M,
+                                                 int mode, const double* __restrict__ A,
+                                                 const double* __restrict__ mu, const double* __restrict__ scale,
+                                                 const double* __restrict__ C0, const double* __restrict__ yexp,
+                                                 const double* __restrict__ Cexp, double* __restrict__ gws,
+                                                 double* __restrict__ ll, int accumulate, int* __restrict__ notpd) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int64_t w = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int ld = M + 1;
+    double* zm = sm;                 // [P]
+    double* zv = sm + P;             // [P]
+    double* mo = sm + 2 * P;         // [M]
+    double* dg = sm + 2 * P + M;     // [M] pivots
+    double* c = gws ? (gws + w * (int64_t)(M + 1) * ld) : (sm + 2 * P + 2 * M);   // [(M+1)][ld]
+    const bool no_pca = (mode == GPB_MODE_NO_PCA || mode == GPB_MODE_NO_PCA_EXPDIAG);
+    const bool expdiag = (mode == GPB_MODE_EXPDIAG || mode == GPB_MODE_NO_PCA_EXPDIAG);
+    for (int p = tid; p < P; p += 256) {
+        zm[p] = mean_pc[(int64_t)p * Wld + w];
+        zv[p] = var_pc[(int64_t)p * Wld + w];       // extra_std == 0 on this path (src/mcmc.py:205,281)
+    }
+    __syncthreads();
+    for (int m = tid; m < M; m += 256) {
+        double v;
+        if (!no_pca) {
+            v = 0.0;
+            for (int p = 0; p < P; ++p) v = fma(zm[p], A[p * M + m], v);
+            v += mu[m];
+        } else {
+            v = zm[m] * scale[m] + mu[m];
+        }
+        if (expdiag) v = exp(v);
+        mo[m] = v;
+        c[M * ld + m] = v - yexp[m];                // dY (src/mcmc.py:288)
+    }
+    __syncthreads();
+    for (int e2 = tid; e2 < M * M; e2 += 256) {
+        const int i = e2 / M, j = e2 % M;
+        if (j > i) continue;
+        double v;
+        if (!no_pca) {
+            if (expdiag && i != j) v = 0.0;
+            else {
+                v = 0.0;
+                for (int p = 0; p < P; ++p) v = fma(zv[p] * A[p * M + i], A[p * M + j], v);
+                v += C0[i * M + j];
+            }
+        } else {
+            v = (i == j) ? zv[i] : 0.0;
+        }
+        if (expdiag && i == j) {
+            const double f = sqrt(v) * mo[i];
+            v = f * f;
+        }
+        c[i * ld + j] = v + Cexp[i * M + j];        // src/mcmc.py:290
+    }
+    __syncthreads();
+    chol_aug_finish(c, ld, M, dg, ll, w, accumulate, notpd);
+}
+
+int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate) {
+    const int64_t M = ctx->M, P = ctx->P;
+    const size_t small = (2 * P + 2 * M) * sizeof(double);
+    const size_t mat = (size_t)(M + 1) * (M + 1) * sizeof(double);
+    double* gws = nullptr;
+    size_t sh = small + mat;
+    if (sh > 150 * 1024) {                       // M > ~135: slab in HBM/L2 instead of LDS
+        const int64_t need = W * (M + 1) * (M + 1);
+        if (need > ctx->mvn_ws_cap) {
+            GPB_HIP(hipStreamSynchronize(ctx->stream));
+            if (ctx->mvn_ws) GPB_HIP(hipFree(ctx->mvn_ws));
+            GPB_HIP(hipMalloc(&ctx->mvn_ws, need * sizeof(double)));
+            ctx->mvn_ws_cap = need;
+        }
+        gws = ctx->mvn_ws;
+        sh = small;
+    }
+    if (sh > 64 * 1024) {
+        GPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loglike),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    }
+    hipLaunchKernelGGL(k_loglike, dim3((unsigned)W), dim3(256), sh, ctx->stream, ctx->mean_pc, ctx->var_pc,
+                       ctx->Wcap, (int)P, (int)M, ctx->mode, ctx->A, ctx->mu, ctx->scale, ctx->C0, ctx->yexp,
+                       ctx->Cexp, gws, ll_dev, accumulate ? 1 : 0, ctx->notpd);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_mvn(gpb_ctx* ctx, const double* dY_dev, const double* cov_dev, int64_t W, int64_t M, double* ll_dev) {
+    const size_t mat = (size_t)(M + 1) * (M + 1) * sizeof(double);
+    size_t sh = M * sizeof(double) + mat;
+    double* gws = nullptr;
+    if (sh > 150 * 1024) {
+        const int64_t need = W * (M + 1) * (M + 1);
+        if (need > ctx->mvn_ws_cap) {
+            GPB_HIP(hipStreamSynchronize(ctx->stream));
+            if (ctx->mvn_ws) GPB_HIP(hipFree(ctx->mvn_ws));
+            GPB_HIP(hipMalloc(&ctx->mvn_ws, need * sizeof(double)));
+            ctx->mvn_ws_cap = need;
+        }
+        gws = ctx->mvn_ws;
+        sh = M * sizeof(double);
+    }
+    if (sh > 64 * 1024) {
+        GPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mvn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)sh));
+    }
+    hipLaunchKernelGGL(k_mvn, dim3((unsigned)W), dim3(256), sh, ctx->stream, dY_dev, cov_dev, (int)M, gws, ll_dev,
+                       ctx->notpd);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ prior box
+__global__ void k_box(const double* __restrict__ X, int64_t W, int d, const double* __restrict__ lo,
+                      const double* __restrict__ hi, double outside, double inside_const,
+                      double* __restrict__ ll) {
+    const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    bool in = true;
+    for (int k = 0; k < d; ++k) {
+        const double x = X[w * d + k];
+        in = in && (x > lo[k]) && (x < hi[k]);      // strict (src/mcmc.py:275)
+    }
+    ll[w] = in ? (ll[w] + inside_const) : outside;
+}
+
+// ------------------------------------------------------------------ Philox4x32-10
+struct U4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ U4 philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    U4 c = {c0, c1, c2, c3};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;
+        U4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        n.w = (uint32_t)p0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {   // 53-bit uniform in [0,1)
+    const uint64_t b = (((uint64_t)hi << 32) | lo) >> 11;
+    return (double)b * (1.0 / 9007199254740992.0);
+}
+
+// halves: walker k of half h is index 2k+h (emcee inds = arange(nwalkers) % 2 without shuffling)
+__global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, int half, uint64_t seed,
+                          uint32_t step, double a, double* __restrict__ q, double* __restrict__ factor) {
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k >= nhalf) return;
+    const U4 r = philox(seed, (uint32_t)k, step, (uint32_t)half, 0u);
+    const double u = u01(r.x, r.y);
+    const double zs = (a - 1.0) * u + 1.0;
+    const double zz = zs * zs / a;                                   // emcee StretchMove.get_proposal
+    const int64_t j = (int64_t)(((uint64_t)r.z * (uint64_t)nhalf) >> 32);
+    const double* s = pos + (2 * k + half) * d;
+    const double* c = pos + (2 * j + (1 - half)) * d;
+    for (int t = 0; t < d; ++t) q[k * d + t] = c[t] - (c[t] - s[t]) * zz;
+    factor[k] = (d - 1.0) * log(zz);
+}
+__global__ void k_accept(double* __restrict__ pos, double* __restrict__ lp, int64_t nhalf, int d, int half,
+                         uint64_t seed, uint32_t step, const double* __restrict__ q,
+                         const double* __restrict__ factor, const double* __restrict__ lpq,
+                         long long* __restrict__ naccept) {
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k >= nhalf) return;
+    const U4 r = philox(seed, (uint32_t)k, step, (uint32_t)half, 1u);
+    const double u = u01(r.x, r.y);
+    const int64_t idx = 2 * k + half;
+    const double diff = factor[k] + lpq[k] - lp[idx];
+    if (diff > log(u)) {                                             // emcee RedBlueMove.propose
+        for (int t = 0; t < d; ++t) pos[idx * d + t] = q[k * d + t];
+        lp[idx] = lpq[k];
+        if (naccept) naccept[idx] += 1;
+    }
+}
+
+}  // namespace gpb
+
+using namespace gpb;
+
+extern "C" int gpb_box_finish(gpb_ctx* ctx, const double* X_dev, int64_t W, const double* lo_dev,
+                              const double* hi_dev, double outside_value, double inside_const,
+                              double* ll_inout_dev) {
+    if (!ctx || W < 0) return GPB_E_ARG;
+    if (W == 0) return 0;
+    hipLaunchKernelGGL(k_box, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, ctx->stream, X_dev, W, (int)ctx->d,
+                       lo_dev, hi_dev, outside_value, inside_const, ll_inout_dev);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gpb_stretch_propose(gpb_ctx* ctx, const double* pos_dev, int64_t nwalkers, int64_t d, int half,
+                                   uint64_t seed, uint64_t step, double a, double* q_dev, double* factor_dev) {
+    if (!ctx || nwalkers < 2 || (nwalkers & 1) || d < 1 || (half != 0 && half != 1)) return GPB_E_ARG;
+    const int64_t nh = nwalkers / 2;
+    hipLaunchKernelGGL(k_propose, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev, nh, (int)d,
+                       half, seed, (uint32_t)step, a, q_dev, factor_dev);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gpb_stretch_accept(gpb_ctx* ctx, double* pos_dev, double* lp_dev, int64_t nwalkers, int64_t d,
+                                  int half, uint64_t seed, uint64_t step, const double* q_dev,
+                                  const double* factor_dev, const double* lpq_dev, int64_t* naccept_dev) {
+    if (!ctx || nwalkers < 2 || (nwalkers & 1) || d < 1 || (half != 0 && half != 1)) return GPB_E_ARG;
+    const int64_t nh = nwalkers / 2;
+    hipLaunchKernelGGL(k_accept, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev, lp_dev, nh,
+                       (int)d, half, seed, (uint32_t)step, q_dev, factor_dev, lpq_dev,
+                       reinterpret_cast<long long*>(naccept_dev));
+    GPB_HIP(hipGetLastError());
+    return 0;
+}

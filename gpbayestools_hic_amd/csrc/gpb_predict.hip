@@ -1,0 +1,333 @@
+// gpb_predict.hip — the MCMC hot loop's GP part:  for every GP p and walker w
+//     mean[p][w] = K*(x_w, X) alpha_p                     (sk:_gpr.py:443-444)
+//     var[p][w]  = c_p + sigma_n,p^2 - || L_p^-1 K*(x_w, X)^T ||^2   (sk:_gpr.py:454-460, diag only:
+//                                                                   src/emulator.py:573-575)
+// Three kernels per batch:
+//   k_kcross    K*^T[p][n][w] assembled once (coalesced along w), mean partials per 256-point chunk
+//   k_predict   V = L^-1 K*^T on the fp64 matrix cores, lower-triangular K-clipping, fused
+//               per-walker sum of squares — V is never written to HBM
+//   k_finalize  fixed-order sums of the partials
+// The reference instead forms a W x W covariance per GP (sk:_gpr.py:460) and keeps its diagonal.
+// Reduction orders are fixed by (N, tile sizes) only — never by W or by the rank's shard — so a
+// walker's result is bit-identical however the ensemble is split across GPUs.
+#include "gpb_internal.h"
+#include "gemm_tile.h"
+#include <math.h>
+
+namespace gpb {
+
+template <int KIND>
+__device__ __forceinline__ double shape_fn_p(double r2) {
+    if (KIND == GPB_KERNEL_RBF) {
+        return exp(-0.5 * r2);
+    } else if (KIND == GPB_KERNEL_MATERN15) {
+        const double t = sqrt(r2) * 1.7320508075688772;
+        return (1.0 + t) * exp(-t);
+    } else {
+        const double t = sqrt(r2) * 2.23606797749979;
+        return (1.0 + t + t * t / 3.0) * exp(-t);
+    }
+}
+
+// grid (Wpad/64, ceil(Np/256), P), 256 threads: lane = walker, the 4 waves stride the chunk's
+// design points; the design row is wave-uniform (scalar loads), the walker row lives in VGPRs.
+template <int KIND, int DPAD>
+__global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, int64_t W, int d,
+                                                const double* __restrict__ Xsc, const double* __restrict__ ls,
+                                                const double* __restrict__ amp, const double* __restrict__ alpha,
+                                                double* __restrict__ KsT, double* __restrict__ mpart,
+                                                int64_t N, int64_t Np, int64_t Wld, int P) {
+    __shared__ double red[4][64];
+    const int p = blockIdx.z, chunk = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t w = (int64_t)blockIdx.x * 64 + lane;
+    double xs[DPAD];
+#pragma unroll
+    for (int k = 0; k < DPAD; ++k) {
+        xs[k] = (k < d && w < W) ? Xs[w * d + k] / ls[p * DPAD + k] : 0.0;
+    }
+    const double c = amp[p];
+    const double* Xp = Xsc + (int64_t)p * Np * DPAD;
+    const double* ap = alpha + (int64_t)p * Np;
+    double* Kp = KsT + (int64_t)p * Np * Wld;
+    double msum = 0.0;
+    const int64_t nbeg = (int64_t)chunk * KX_CHUNK;
+    for (int t = 0; t < KX_CHUNK / 4; ++t) {
+        const int64_t n = nbeg + wave + 4 * t;          // wave-uniform
+        if (n >= Np) break;
+        double kv = 0.0;
+        if (n < N) {
+            const double* xr = Xp + n * DPAD;
+            double r2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < DPAD; ++k) {
+                const double df = xs[k] - xr[k];
+                r2 = fma(df, df, r2);
+            }
+            kv = c * shape_fn_p<KIND>(r2);
+            msum = fma(ap[n], kv, msum);
+        }
+        Kp[n * Wld + w] = kv;
+    }
+    red[wave][lane] = msum;
+    __syncthreads();
+    if (wave == 0)
+        mpart[((int64_t)chunk * P + p) * Wld + w] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
+// 1-D grid of P * nI * nW 128x128 tiles, heaviest row blocks first; consecutive blocks differ in
+// the walker tile so that the 8 XCDs (round-robin dispatch) each keep their own K*^T columns in L2.
+__global__ __launch_bounds__(256, 2) void k_predict(const double* __restrict__ Linv, const double* __restrict__ KsT,
+                                                    double* __restrict__ spart, int64_t Np, int64_t Wld, int P,
+                                                    int nI, int nW) {
+    __shared__ TileLds lds;
+    const int b = blockIdx.x;
+    const int p = b / (nI * nW);
+    const int rem = b - p * nI * nW;
+    const int ib = nI - 1 - rem / nW;
+    const int wt = rem % nW;
+    const int64_t mb = (int64_t)ib * 128, nb = (int64_t)wt * 128;
+    const int m_ext = (int)imin64(128, Np - mb);
+    const int64_t k_end = imin64(mb + 128, Np);
+    d4 acc[4][4];
+    acc_zero(acc);
+    gemm_tile_loop<false, false>(Linv + (int64_t)p * Np * Np, Np, KsT + (int64_t)p * Np * Wld, Wld, mb, nb, m_ext,
+                                 128, 0, k_end, lds, acc);
+    // fused epilogue: column sums of squares over this tile's rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v = fma(acc[i][j][r], acc[i][j][r], v);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        s[j] = v;
+    }
+    __syncthreads();                       // all waves are done reading the operand tiles
+    double* red = &lds.As[0][0];           // [2 row-halves][128 columns]
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[(wave >> 1) * 128 + (wave & 1) * 64 + 16 * j + lane] = s[j];
+    }
+    __syncthreads();
+    if (tid < 128) spart[((int64_t)ib * P + p) * Wld + nb + tid] = red[tid] + red[128 + tid];
+}
+
+__global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ mpart, const double* __restrict__ spart,
+                                                  const double* __restrict__ amp, const double* __restrict__ noise,
+                                                  double* __restrict__ mean_pc, double* __restrict__ var_pc,
+                                                  int64_t Wld, int64_t Wuse, int P, int nchunk, int nI, int need_var) {
+    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int p = blockIdx.y;
+    if (w >= Wuse) return;
+    double m = 0.0;
+    for (int c = 0; c < nchunk; ++c) m += mpart[((int64_t)c * P + p) * Wld + w];
+    mean_pc[(int64_t)p * Wld + w] = m;
+    if (need_var) {
+        double s = 0.0;
+        for (int i = 0; i < nI; ++i) s += spart[((int64_t)i * P + p) * Wld + w];
+        var_pc[(int64_t)p * Wld + w] = (amp[p] + noise[p]) - s;
+    }
+}
+
+int ensure_wcap(gpb_ctx* ctx, int64_t W) {
+    const int64_t need = round_up(W < 1 ? 1 : W, WPAD);
+    if (need <= ctx->Wcap) return 0;
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    double** bufs[] = {&ctx->Xs, &ctx->estd, &ctx->KsT, &ctx->mpart, &ctx->spart, &ctx->mean_pc, &ctx->var_pc};
+    for (auto b : bufs) {
+        if (*b) { GPB_HIP(hipFree(*b)); *b = nullptr; }
+    }
+    ctx->Wcap = 0;
+    const int64_t P = ctx->P, Np = ctx->Np;
+    const int64_t nchunk = (Np + KX_CHUNK - 1) / KX_CHUNK, nI = (Np + 127) / 128;
+    GPB_HIP(hipMalloc(&ctx->Xs, sizeof(double) * need * ctx->d));
+    GPB_HIP(hipMalloc(&ctx->estd, sizeof(double) * need));
+    GPB_HIP(hipMalloc(&ctx->KsT, sizeof(double) * P * Np * need));
+    GPB_HIP(hipMalloc(&ctx->mpart, sizeof(double) * nchunk * P * need));
+    GPB_HIP(hipMalloc(&ctx->spart, sizeof(double) * nI * P * need));
+    GPB_HIP(hipMalloc(&ctx->mean_pc, sizeof(double) * P * need));
+    GPB_HIP(hipMalloc(&ctx->var_pc, sizeof(double) * P * need));
+    ctx->Wcap = need;
+    return 0;
+}
+
+template <int KIND>
+static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int64_t Wuse) {
+    const int nchunk = (int)((ctx->Np + KX_CHUNK - 1) / KX_CHUNK);
+    dim3 grid((unsigned)(Wuse / 64), (unsigned)nchunk, (unsigned)ctx->P);
+#define GPB_KX(DP)                                                                                         \
+    hipLaunchKernelGGL((k_kcross<KIND, DP>), grid, dim3(256), 0, ctx->stream, Xs_dev, W, (int)ctx->d, ctx->Xsc, \
+                       ctx->ls, ctx->amp, ctx->alpha, ctx->KsT, ctx->mpart, ctx->N, ctx->Np, ctx->Wcap,     \
+                       (int)ctx->P)
+    switch (ctx->dpad) {
+        case 8: GPB_KX(8); break;
+        case 16: GPB_KX(16); break;
+        case 24: GPB_KX(24); break;
+        case 32: GPB_KX(32); break;
+        case 48: GPB_KX(48); break;
+        default: GPB_KX(64); break;
+    }
+#undef GPB_KX
+    return 0;
+}
+
+// Xs_dev: [W][d] on the device.  Results land in ctx->mean_pc / var_pc ([P][Wcap]).
+int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var) {
+    if (!ctx->factored) GPB_FAIL(GPB_E_STATE, "gpb: predict before gpb_gp_factor");
+    if (W > ctx->Wcap) GPB_FAIL(GPB_E_STATE, "gpb: internal: W exceeds workspace");
+    const int64_t Wuse = round_up(W, WPAD);
+    if (ctx->kind == GPB_KERNEL_RBF) launch_kcross_kind<GPB_KERNEL_RBF>(ctx, Xs_dev, W, Wuse);
+    else if (ctx->kind == GPB_KERNEL_MATERN15) launch_kcross_kind<GPB_KERNEL_MATERN15>(ctx, Xs_dev, W, Wuse);
+    else launch_kcross_kind<GPB_KERNEL_MATERN25>(ctx, Xs_dev, W, Wuse);
+    const int nI = (int)((ctx->Np + 127) / 128), nW = (int)(Wuse / 128);
+    const int nchunk = (int)((ctx->Np + KX_CHUNK - 1) / KX_CHUNK);
+    if (need_var) {
+        hipLaunchKernelGGL(k_predict, dim3((unsigned)((int64_t)ctx->P * nI * nW)), dim3(256), 0, ctx->stream,
+                           ctx->Linv, ctx->KsT, ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW);
+    }
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((Wuse + 255) / 256), (unsigned)ctx->P), dim3(256), 0, ctx->stream,
+                       ctx->mpart, ctx->spart, ctx->amp, ctx->noise, ctx->mean_pc, ctx->var_pc, ctx->Wcap, Wuse,
+                       (int)ctx->P, nchunk, nI, need_var ? 1 : 0);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ test hooks
+__global__ __launch_bounds__(256, 2) void k_test_gemm_nn(const double* A, const double* B, double* C, int64_t M,
+                                                         int64_t N, int64_t K) {
+    __shared__ TileLds lds;
+    const int64_t mb = (int64_t)blockIdx.y * 128, nb = (int64_t)blockIdx.x * 128;
+    d4 acc[4][4];
+    acc_zero(acc);
+    gemm_tile_loop<false, false>(A, K, B, N, mb, nb, (int)imin64(128, M - mb), (int)imin64(128, N - nb), 0, K, lds,
+                                 acc);
+    tile_store(C, N, mb, nb, (int)imin64(128, M - mb), (int)imin64(128, N - nb), 1.0, false, acc);
+}
+__global__ __launch_bounds__(256, 2) void k_test_gemm_nt(const double* A, const double* B, double* C, int64_t M,
+                                                         int64_t N, int64_t K) {
+    __shared__ TileLds lds;
+    const int64_t mb = (int64_t)blockIdx.y * 128, nb = (int64_t)blockIdx.x * 128;
+    d4 acc[4][4];
+    acc_zero(acc);
+    gemm_tile_loop<false, true>(A, K, B, K, mb, nb, (int)imin64(128, M - mb), (int)imin64(128, N - nb), 0, K, lds,
+                                acc);
+    tile_store(C, N, mb, nb, (int)imin64(128, M - mb), (int)imin64(128, N - nb), 1.0, false, acc);
+}
+__global__ __launch_bounds__(256, 2) void k_test_gemm_tn(const double* A, const double* B, double* C, int64_t M,
+                                                         int64_t N, int64_t K) {
+    __shared__ TileLds lds;
+    const int64_t mb = (int64_t)blockIdx.y * 128, nb = (int64_t)blockIdx.x * 128;
+    d4 acc[4][4];
+    acc_zero(acc);
+    gemm_tile_loop<true, false>(A, M, B, N, mb, nb, (int)imin64(128, M - mb), (int)imin64(128, N - nb), 0, K, lds,
+                                acc);
+    tile_store(C, N, mb, nb, (int)imin64(128, M - mb), (int)imin64(128, N - nb), 1.0, false, acc);
+}
+
+// b_trans: 0 = C = A[M,K] B[K,N]; 1 = C = A[M,K] B[N,K]^T; 2 = C = A[K,M]^T B[K,N]
+int launch_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K, const double* A, const double* B, double* C,
+                     int b_trans) {
+    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
+    if (b_trans == 0) hipLaunchKernelGGL(k_test_gemm_nn, grid, dim3(256), 0, ctx->stream, A, B, C, M, N, K);
+    else if (b_trans == 1) hipLaunchKernelGGL(k_test_gemm_nt, grid, dim3(256), 0, ctx->stream, A, B, C, M, N, K);
+    else hipLaunchKernelGGL(k_test_gemm_tn, grid, dim3(256), 0, ctx->stream, A, B, C, M, N, K);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+// issue-rate probes: one wave per SIMD (256 threads/WG, 1 WG/CU x 256 CUs x 4 rounds)
+__global__ __launch_bounds__(256) void k_probe_mfma(double* out, int iters) {
+    d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+    const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, a3, 0, 0, 0);
+    }
+    const d4 s = a0 + a1 + a2 + a3;
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678) out[0] = s[0];
+}
+__global__ __launch_bounds__(256) void k_probe_fma(double* out, int iters) {
+    double a[8];
+    const double x = 1.0 + threadIdx.x * 1e-12, y = 1e-9 * threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = k;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = fma(a[k], x, y);
+    }
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += a[k];
+    if (s == 12345.678) out[0] = s;
+}
+// waves 0-3 (one per SIMD) issue MFMA, waves 4-7 issue v_fma_f64: do the pipes overlap for fp64?
+__global__ __launch_bounds__(512) void k_probe_both(double* out, int iters) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave < 4) {
+        d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+        const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+        for (int i = 0; i < iters; ++i) {
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, a3, 0, 0, 0);
+        }
+        const d4 s = a0 + a1 + a2 + a3;
+        if (s[0] + s[1] + s[2] + s[3] == 12345.678) out[0] = s[0];
+    } else {
+        double a[8];
+        const double x = 1.0 + threadIdx.x * 1e-12, y = 1e-9 * threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = k;
+        for (int i = 0; i < iters * 16; ++i) {   // 16*8 wave-FMAs = 128*64*2 flop vs 4 MFMA = 4*2048 flop... same order
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = fma(a[k], x, y);
+        }
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += a[k];
+        if (s == 12345.678) out[1] = s;
+    }
+}
+
+int launch_probe(gpb_ctx* ctx, int mode, double* tflops) {
+    double* d_out = nullptr;
+    GPB_HIP(hipMalloc(&d_out, 64));
+    hipEvent_t e0, e1;
+    GPB_HIP(hipEventCreate(&e0));
+    GPB_HIP(hipEventCreate(&e1));
+    const int iters = 4000, blocks = 1024;
+    double flops = 0.0;
+    for (int rep = 0; rep < 2; ++rep) {
+        GPB_HIP(hipEventRecord(e0, ctx->stream));
+        if (mode == 0) {
+            hipLaunchKernelGGL(k_probe_mfma, dim3(blocks), dim3(256), 0, ctx->stream, d_out, iters);
+            flops = (double)blocks * 4 * iters * 4 * 2048.0;
+        } else if (mode == 1) {
+            hipLaunchKernelGGL(k_probe_fma, dim3(blocks), dim3(256), 0, ctx->stream, d_out, iters * 16);
+            flops = (double)blocks * 256 * (double)iters * 16 * 8 * 2.0;
+        } else {
+            hipLaunchKernelGGL(k_probe_both, dim3(blocks), dim3(512), 0, ctx->stream, d_out, iters);
+            flops = (double)blocks * 4 * iters * 4 * 2048.0 + (double)blocks * 256 * (double)iters * 16 * 8 * 2.0;
+        }
+        GPB_HIP(hipEventRecord(e1, ctx->stream));
+        GPB_HIP(hipEventSynchronize(e1));
+    }
+    float ms = 0.f;
+    GPB_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(d_out);
+    return 0;
+}
+
+}  // namespace gpb

@@ -1,0 +1,71 @@
+"""
+Walker sharding across the GPUs of one node: one process per GPU, every rank holds
+the full GP state (replicated, a few hundred MB) and the full walker array; rank r evaluates
+rows [r*chunk, (r+1)*chunk) of each log-probability batch and ONE all-gather of `chunk` float64
+per rank puts the complete log-probability vector on every rank.  There is no other exchange:
+proposals and accept draws are regenerated identically everywhere (sampler.py).
+
+The collective goes through torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo"
+on CPU for tests), enqueued on the same stream as the kernels — no host synchronisation.  The
+payload is 2-16 KB, so the step is latency-bound, not link-bound.
+"""
+import os
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
+    Returns (rank, world, local_rank).  Single-process when WORLD_SIZE is absent or 1."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class WalkerSharding:
+    def __init__(self, rank=None, world=None, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self._buf = {}
+
+    def rows(self, W):
+        """(r0, r1, chunk): this rank's row range of a W-row batch; chunk = ceil(W / world)."""
+        chunk = -(-W // self.world)
+        r0 = min(self.rank * chunk, W)
+        return r0, min(r0 + chunk, W), chunk
+
+    def logprob(self, fn, X, out):
+        """out[:] = fn over all rows of X, computed in shards.  fn(X_rows, out_rows) -> out_rows
+        must fill its output for exactly the rows it is given (torch tensors, any device)."""
+        import torch
+        W = X.shape[0]
+        r0, r1, chunk = self.rows(W)
+        key = (chunk, X.device, out.dtype)
+        if key not in self._buf:
+            self._buf[key] = (torch.zeros(chunk, dtype=out.dtype, device=X.device),
+                              torch.empty(chunk * self.world, dtype=out.dtype, device=X.device))
+        local, gathered = self._buf[key]
+        if r1 > r0:
+            fn(X[r0:r1], local[:r1 - r0])
+        if self.world == 1:
+            out.copy_(local[:W])
+            return out
+        self.dist.all_gather_into_tensor(gathered, local, group=self.group)
+        out.copy_(gathered[:W])
+        return out

@@ -1,0 +1,366 @@
+"""
+Drop-in replacement for the reference's `src/emulator.py` `Emulator` (B1 protocol):
+same constructor, `trainEmulatorAutoMask()`, `trainEmulator(eventMask, kernel_type)`,
+`predict(X, return_cov, extra_std)` and attribute names, but every GP operation — kernel
+matrices, Cholesky, alpha, log-marginal likelihood and gradient, predictive mean/variance,
+the PC->observable covariance — runs in the HIP engine (GPEngine / include/gpbayes.h).
+Host Python keeps file parsing, the N x M scaler/PCA SVD and the L-BFGS-B driver
+(scipy.optimize, as sklearn uses: sk:_gpr.py:654-670).
+
+Objects pickle/dill cleanly: device handles are dropped in __getstate__ and the factorisation
+is rebuilt on the device from (X, Z, theta) at first use after loading (src/mcmc.py:145-150).
+"""
+import logging
+import pickle
+import threading
+
+import numpy as np
+import scipy.optimize
+
+from .engine import (GPEngine, MODE_EXPDIAG, MODE_NO_PCA, MODE_NO_PCA_EXPDIAG, MODE_PCA,
+                     NotPositiveDefinite)
+from .preprocess import (Standardizer, WhitenedPCA, observable_transform,
+                         parse_model_parameter_file)
+
+log = logging.getLogger(__name__)
+
+_KERNELS = {"RBF": ("RBF", (1e-1, 1e2)), "Matern": ("Matern15", (1e-3, 1e5)),
+            "Matern25": ("Matern25", (1e-3, 1e5))}
+
+
+class FittedGP:
+    """Read-only view of one fitted GP with the sklearn attribute names the reference reads
+    (SURVEY §8b B3): kernel_theta (= kernel_.theta), log_marginal_likelihood_value_, alpha_, L_,
+    X_train_, predict()."""
+
+    def __init__(self, emu, index):
+        self._emu, self._i = emu, index
+
+    @property
+    def kernel_theta(self):
+        return self._emu.thetas_[self._i]
+
+    @property
+    def log_marginal_likelihood_value_(self):
+        return float(self._emu.lml_[self._i])
+
+    @property
+    def X_train_(self):
+        return self._emu._X_train
+
+    @property
+    def alpha_(self):
+        return self._emu._engine_ready().get("alpha")[self._i]
+
+    @property
+    def L_(self):
+        return self._emu._engine_ready().get("L")[self._i]
+
+    def predict(self, X, return_cov=False, return_std=False):
+        m, v = self._emu._engine_ready().predict(np.atleast_2d(X), return_var=True)
+        m, v = m[:, self._i], v[:, self._i]
+        if return_std:
+            return m, np.sqrt(np.clip(v, 0.0, None))       # sk:_gpr.py:479-485
+        if return_cov:
+            raise NotImplementedError("full W x W covariance is never formed on the device; "
+                                      "use return_std or Emulator.predict")
+        return m
+
+    def __repr__(self):
+        th = self.kernel_theta
+        return "{:.3g}**2 * k(length_scale={}) + White(noise_level={:.3g})".format(
+            np.sqrt(np.exp(th[0])), np.array2string(np.exp(th[1:-1]), precision=3), np.exp(th[-1]))
+
+
+class Emulator:
+    def __init__(self, training_set_path=".", parameter_file="ABCD.txt",
+                 npc=10, nrestarts=0, logTrafo=False, parameterTrafoPCA=False,
+                 max_rel_uncertainty_data=0.1, exp_and_cov_diagonal=False,
+                 perform_no_PCA=False, device=0):
+        self.logTrafo_ = logTrafo
+        self.parameterTrafoPCA_ = parameterTrafoPCA
+        self.max_rel_uncertainty_data_ = max_rel_uncertainty_data
+        self._load_training_data_pickle(training_set_path)
+        self.exp_and_cov_diagonal_ = exp_and_cov_diagonal
+        if self.exp_and_cov_diagonal_ and not self.logTrafo_:
+            raise ValueError("exp_and_cov_diagonal can only be set to True if logTrafo is True.")
+        self.perform_no_PCA_ = perform_no_PCA
+        self.pardict = parse_model_parameter_file(parameter_file)
+        self.design_min = np.array([v[1] for v in self.pardict.values()])
+        self.design_max = np.array([v[2] for v in self.pardict.values()])
+        self.npc = npc
+        self.nrestarts = nrestarts
+        self.nev, self.nobs = self.model_data.shape
+        self.scaler = Standardizer()
+        self.pca = WhitenedPCA()
+        self.device = device
+        self.alpha = 0.1                      # GPR(alpha=0.1), src/emulator.py:310
+        self._engine = None
+        self._trained = False
+        if self.parameterTrafoPCA_:
+            from .param_pca import ParameterPCA
+            self._ppca = ParameterPCA(self.design_points, self.design_min, self.design_max)
+            self.PCA_new_design_points = self._ppca.new_design_points
+            self.design_min, self.design_max = self._ppca.design_min, self._ppca.design_max
+
+    # ------------------------------------------------------------------ data loading
+    def _load_training_data_pickle(self, dataFile):
+        """{event_id -> {"parameter": f64[ndim], "obs": f64[2,nobs]}}; points whose largest
+        relative statistical error exceeds max_rel_uncertainty_data are dropped; optional log
+        transform (src/emulator.py:378-415)."""
+        with open(dataFile, "rb") as fp:
+            data = pickle.load(fp)
+        X, Y, E = [], [], []
+        dropped = 0
+        for key in sorted(data.keys(), key=lambda s: int(s)):
+            val, err = data[key]["obs"][0], data[key]["obs"][1]
+            if np.abs(err / (val + 1e-16)).max() > self.max_rel_uncertainty_data_:
+                dropped += 1
+                continue
+            X.append(data[key]["parameter"])
+            if self.logTrafo_:
+                Y.append(np.log(np.abs(val) + 1e-30))
+                E.append(np.abs(err / (val + 1e-30)))
+            else:
+                Y.append(val)
+                E.append(err)
+        self.design_points = np.array(X)
+        self.design_points_org_ = np.copy(self.design_points)
+        self.model_data = np.array(Y)
+        self.model_data_err = np.nan_to_num(np.abs(np.array(E)))
+        log.info("training set: %d points kept, %d discarded", len(Y), dropped)
+
+    def getAvgTrainingDataRelError(self):
+        return np.mean(np.nan_to_num(self.model_data_err / self.model_data), axis=0)
+
+    def outputPCAvsParam(self):
+        Z = self.pca.fit_transform(self.scaler.fit_transform(self.model_data))[:, :self.npc]
+        return self.design_points, Z.T
+
+    # ------------------------------------------------------------------ training
+    def trainEmulatorAutoMask(self):
+        self.trainEmulator([True] * self.nev)
+
+    def _theta0_bounds(self, kernel_type):
+        """Initial theta and log-bounds of `1.*RBF(ptp, ptp x (1e-1,1e2)) + White(.05,(1e-2,1e2))`
+        (src/emulator.py:286-306); the constant kernel's bounds are sklearn's default (1e-5,1e5)."""
+        ptp = self.design_max - self.design_min
+        lo, hi = _KERNELS[kernel_type][1]
+        d = ptp.shape[0]
+        theta0 = np.concatenate([[0.0], np.log(ptp), [np.log(0.05)]])
+        bounds = np.empty((d + 2, 2))
+        bounds[0] = np.log([1e-5, 1e5])
+        bounds[1:1 + d, 0] = np.log(ptp * lo)
+        bounds[1:1 + d, 1] = np.log(ptp * hi)
+        bounds[d + 1] = np.log([1e-2, 1e2])
+        return theta0, bounds
+
+    def trainEmulator(self, eventMask, kernel_type="RBF", thetas=None):
+        """Fit one GP per principal component (src/emulator.py:257-363).  `thetas` (optional,
+        [npc, d+2]) skips the hyper-parameter search and factorises at the given values."""
+        if kernel_type not in _KERNELS:
+            raise ValueError("Unknown kernel type: {}".format(kernel_type))
+        mask = np.asarray(eventMask, dtype=bool)
+        S = self.scaler.fit_transform(self.model_data[mask])
+        if self.perform_no_PCA_:
+            Z = S
+        else:
+            Z = self.pca.fit_transform(S)[:, :self.npc]
+            log.info("%d PCs explain %.5f of variance", self.npc,
+                     self.pca.explained_variance_ratio_[:self.npc].sum())
+        X = (self.PCA_new_design_points if self.parameterTrafoPCA_ else self.design_points)[mask]
+        self._X_train = np.ascontiguousarray(X, dtype=np.float64)
+        self._Z_train = np.ascontiguousarray(Z.T, dtype=np.float64)       # [P, N]
+        self.kernel_type_ = kernel_type
+        self._ngp = self._Z_train.shape[0]
+        eng = self._new_engine()
+        if thetas is not None:
+            self.thetas_ = np.array(thetas, dtype=np.float64).reshape(self._ngp, -1)
+            self.lml_ = eng.lml(self.thetas_, eval_gradient=False)
+        else:
+            self.thetas_, self.lml_ = self._optimise(eng, kernel_type)
+        eng.set_theta(self.thetas_)
+        eng.factor()
+        self._build_transform()
+        self._push_transform(eng)
+        self._trained = True
+        self.gps = [FittedGP(self, i) for i in range(self._ngp)]
+        # R^2 of each GP on its training targets (src/emulator.py:316-318)
+        m = eng.predict(self._X_train, return_var=False)
+        zt = self._Z_train.T
+        self.gp_scores_ = 1.0 - ((zt - m) ** 2).sum(0) / ((zt - zt.mean(0)) ** 2).sum(0)
+        log.info("GP scores: %s", self.gp_scores_)
+
+    def _optimise(self, eng, kernel_type):
+        """argmax LML per GP with scipy L-BFGS-B (sk:_gpr.py:296-337,654-670).  The P searches
+        are independent; they run in lock-step threads so that every objective call is ONE
+        batched device evaluation of all P log-marginal likelihoods and gradients."""
+        P = self._ngp
+        theta0, bounds = self._theta0_bounds(kernel_type)
+        starts = [np.tile(theta0, (P, 1))]
+        rng = np.random.default_rng()
+        for _ in range(int(self.nrestarts)):
+            starts.append(rng.uniform(bounds[:, 0], bounds[:, 1], size=(P, theta0.size)))
+        best_theta = np.tile(theta0, (P, 1))
+        best_val = np.full(P, np.inf)
+        for start in starts:
+            th, val = _batched_lbfgsb(eng, start, bounds)
+            better = val < best_val
+            best_theta[better], best_val[better] = th[better], val[better]
+        return best_theta, -best_val
+
+    def _build_transform(self):
+        if self.perform_no_PCA_:
+            self._A = self._cov_trunc = self._trans_matrix = None
+            return
+        self._trans_matrix, self._A, self._cov_trunc = observable_transform(
+            self.pca.components_, self.pca.explained_variance_, self.scaler.scale_, self.scaler.var_,
+            self.npc)
+        self._var_trans = np.einsum("ki,kj->kij", self._A, self._A).reshape(self.npc, self.nobs ** 2)
+
+    @property
+    def _mode(self):
+        if self.perform_no_PCA_:
+            return MODE_NO_PCA_EXPDIAG if self.exp_and_cov_diagonal_ else MODE_NO_PCA
+        return MODE_EXPDIAG if self.exp_and_cov_diagonal_ else MODE_PCA
+
+    def _push_transform(self, eng):
+        if self.perform_no_PCA_:
+            eng.set_transform(self._mode, self.scaler.mean_, scale=self.scaler.scale_)
+        else:
+            eng.set_transform(self._mode, self.scaler.mean_, A=self._A, cov_trunc=self._cov_trunc)
+
+    # ------------------------------------------------------------------ engine lifetime
+    def _new_engine(self):
+        if self._engine is not None:
+            self._engine.close()
+        eng = GPEngine(self.device)
+        eng.set_data(self._X_train, self._Z_train, _KERNELS[self.kernel_type_][0], self.alpha)
+        self._engine = eng
+        self._like_key = None
+        return eng
+
+    def _engine_ready(self):
+        """(Re)create the device state after unpickling / in a forked worker."""
+        if self._engine is None:
+            if not self._trained:
+                raise RuntimeError("Emulator is not trained")
+            eng = self._new_engine()
+            eng.set_theta(self.thetas_)
+            eng.factor()
+            self._push_transform(eng)
+        return self._engine
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_engine"] = None
+        st["_like_key"] = None
+        st.pop("gps", None)
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        if self._trained:
+            self.gps = [FittedGP(self, i) for i in range(self._ngp)]
+
+    # ------------------------------------------------------------------ prediction
+    def _map_parameters(self, X):
+        return self._ppca.transform(X) if self.parameterTrafoPCA_ else X
+
+    def predict(self, X, return_cov=True, extra_std=0):
+        """mean[W,nobs] (and cov[W,nobs,nobs]) at X[W,ndim] (src/emulator.py:465-605).
+        extra_std: scalar or length-W array added in quadrature to every GP's predictive std."""
+        X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        Xg = np.ascontiguousarray(self._map_parameters(X))
+        eng = self._engine_ready()
+        if not return_cov:
+            return eng.emu_predict(Xg, return_cov=False)
+        es = np.broadcast_to(np.asarray(extra_std, dtype=np.float64).reshape(-1), (Xg.shape[0],))
+        return eng.emu_predict(Xg, return_cov=True, extra_std=np.ascontiguousarray(es))
+
+    def sample_y(self, X, n_samples=1, random_state=None):
+        raise NotImplementedError("sample_y needs the W x W predictive covariance, which this engine "
+                                  "never forms (SURVEY §8f item 4)")
+
+    # ------------------------------------------------------------------ hold-out validation helpers
+    def _holdout(self, nTestPoints, on_training):
+        mask = np.ones(self.nev, dtype=bool)
+        mask[self.nev - nTestPoints:] = False
+        self.trainEmulator(mask)
+        vmask = mask if on_training else ~mask
+        pred, cov = self.predict(self.design_points_org_[vmask], return_cov=True)
+        perr = np.sqrt(np.diagonal(cov, axis1=1, axis2=2))
+        if self.logTrafo_ and not self.exp_and_cov_diagonal_:
+            pred, perr = np.exp(pred), perr * np.exp(pred)
+        if self.logTrafo_:
+            truth = np.exp(self.model_data[vmask])
+            terr = self.model_data_err[vmask] * truth
+        else:
+            truth, terr = self.model_data[vmask], self.model_data_err[vmask]
+        r = lambda a: np.array(a).reshape(-1, self.nobs)
+        return r(pred), r(perr), r(truth), r(terr)
+
+    def testEmulatorErrors(self, nTestPoints=1):
+        """Train on the first nev-nTestPoints points, predict the rest (src/emulator.py:636-679)."""
+        return self._holdout(nTestPoints, on_training=False)
+
+    def testEmulatorErrorsWithTrainingPoints(self, nTestPoints=1):
+        """Same split, but predict the training points themselves (src/emulator.py:682-726)."""
+        return self._holdout(nTestPoints, on_training=True)
+
+
+def _batched_lbfgsb(eng, start, bounds):
+    """Run P independent scipy L-BFGS-B minimisations of -LML_p(theta_p) in lock-step threads;
+    each round of objective calls is served by one batched gpb_gp_lml evaluation."""
+    P = start.shape[0]
+    cur = start.copy()
+    results = [None] * P
+    cond = threading.Condition()
+    state = {"waiting": 0, "active": P, "round": 0, "val": None, "grad": None, "err": None}
+
+    def evaluate_round():
+        try:
+            v, g = eng.lml(cur, eval_gradient=True)
+            state["val"], state["grad"] = v, g
+        except Exception as e:  # propagate to every waiting thread
+            state["err"] = e
+        state["waiting"] = 0
+        state["round"] += 1
+        cond.notify_all()
+
+    def objective(p, th):
+        with cond:
+            cur[p] = th
+            state["waiting"] += 1
+            my_round = state["round"]
+            if state["waiting"] == state["active"]:
+                evaluate_round()
+            else:
+                while state["round"] == my_round:
+                    cond.wait()
+            if state["err"] is not None:
+                raise state["err"]
+            return -state["val"][p], -state["grad"][p]
+
+    def worker(p):
+        try:
+            res = scipy.optimize.minimize(lambda th: objective(p, th), start[p], method="L-BFGS-B",
+                                          jac=True, bounds=bounds)
+            results[p] = (res.x, res.fun)
+        except Exception as e:
+            results[p] = e
+        finally:
+            with cond:
+                state["active"] -= 1
+                if state["active"] > 0 and state["waiting"] == state["active"]:
+                    evaluate_round()
+
+    threads = [threading.Thread(target=worker, args=(p,), daemon=True) for p in range(P)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for r in results:
+        if isinstance(r, Exception):
+            raise r
+    return np.array([r[0] for r in results]), np.array([r[1] for r in results])

@@ -1,0 +1,216 @@
+"""
+GPEngine — thin Python handle on one gpb_ctx (include/gpbayes.h): the P independent GPs of one
+emulator resident in HBM, plus its observable transform and likelihood block.
+Host code only moves arguments; every number is produced by the HIP kernels.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+
+KERNEL_IDS = {"RBF": 0, "Matern": 1, "Matern15": 1, "Matern25": 2}
+MODE_PCA, MODE_NO_PCA, MODE_EXPDIAG, MODE_NO_PCA_EXPDIAG = 0, 1, 2, 3
+
+
+class NotPositiveDefinite(np.linalg.LinAlgError):
+    pass
+
+
+def _is_torch(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+class GPEngine:
+    def __init__(self, device=0, stream="torch"):
+        """stream: "torch" = enqueue on torch's current stream of `device` (one ordered queue
+        shared with torch copies and collectives), None = private stream, or a hipStream_t."""
+        self.lib = nat.load()
+        if self.lib.gpb_device_count() <= 0:
+            raise nat.GPBError("no HIP device visible: the gfx950 kernels cannot run (no CPU fallback)")
+        h = nat.VP()
+        rc = self.lib.gpb_ctx_create(int(device), None, C.byref(h))
+        if rc != 0:
+            raise nat.GPBError(f"gpb_ctx_create failed ({rc})")
+        self.h = h
+        if stream == "torch":
+            import torch
+            with torch.cuda.device(int(device)):
+                s = torch.cuda.current_stream(int(device)).cuda_stream
+            self._ck(self.lib.gpb_ctx_set_stream(h, nat.VP(s)))
+        elif stream is not None:
+            self._ck(self.lib.gpb_ctx_set_stream(h, nat.VP(int(stream))))
+        self.device = int(device)
+        self.N = self.d = self.P = self.M = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def _ck(self, rc):
+        if rc < 0:
+            raise nat.GPBError(f"{self.lib.gpb_last_error(self.h).decode()} (code {rc})")
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gpb_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._ck(self.lib.gpb_sync(self.h))
+
+    # ------------------------------------------------------------------ GP state
+    def set_data(self, X, Z, kernel="RBF", alpha=0.1):
+        """X[N,d] design, Z[P,N] targets (one row per GP)."""
+        X, Z = nat.f64(X), nat.f64(Z)
+        self.N, self.d = X.shape
+        self.P = Z.shape[0]
+        assert Z.shape[1] == self.N
+        kid = KERNEL_IDS[kernel] if isinstance(kernel, str) else int(kernel)
+        self._ck(self.lib.gpb_gp_set(self.h, self.N, self.d, self.P, nat.ptr(X), nat.ptr(Z), kid, float(alpha)))
+
+    def set_theta(self, theta):
+        theta = nat.f64(theta).reshape(self.P, self.d + 2)
+        self._ck(self.lib.gpb_gp_set_theta(self.h, nat.ptr(theta)))
+        self.theta = theta.copy()
+
+    def factor(self, raise_on_fail=True):
+        info = np.zeros(self.P, dtype=np.int32)
+        rc = self._ck(self.lib.gpb_gp_factor(self.h, nat.ptr(info)))
+        if rc > 0 and raise_on_fail:
+            raise NotPositiveDefinite(
+                f"kernel matrix of GP {int(np.flatnonzero(info)[0])} is not positive definite "
+                f"(leading minor {rc}); try increasing alpha")
+        return info
+
+    def get(self, what):
+        sel = {"K": 0, "L": 1, "Linv": 2, "alpha": 3}[what]
+        shape = (self.P, self.N) if what == "alpha" else (self.P, self.N, self.N)
+        out = np.empty(shape)
+        self._ck(self.lib.gpb_gp_get(self.h, sel, nat.ptr(out)))
+        return out
+
+    def lml(self, theta, eval_gradient=True):
+        theta = nat.f64(theta).reshape(self.P, self.d + 2)
+        val = np.empty(self.P)
+        grad = np.empty((self.P, self.d + 2)) if eval_gradient else None
+        info = np.zeros(self.P, dtype=np.int32)
+        self._ck(self.lib.gpb_gp_lml(self.h, nat.ptr(theta), nat.ptr(val), nat.ptr(grad), nat.ptr(info)))
+        self.theta = theta.copy()
+        return (val, grad) if eval_gradient else val
+
+    def predict(self, Xs, return_var=True):
+        """per-GP mean[W,P] (and var[W,P]); numpy in -> numpy out, torch(cuda) in -> torch out."""
+        if _is_torch(Xs):
+            import torch
+            W = Xs.shape[0]
+            mean = torch.empty((W, self.P), dtype=torch.float64, device=Xs.device)
+            var = torch.empty((W, self.P), dtype=torch.float64, device=Xs.device) if return_var else None
+            self._ck(self.lib.gpb_gp_predict(self.h, nat.ptr(Xs.contiguous()), W, 1, nat.ptr(mean), nat.ptr(var)))
+            return (mean, var) if return_var else mean
+        Xs = nat.f64(Xs).reshape(-1, self.d)
+        W = Xs.shape[0]
+        mean = np.empty((W, self.P))
+        var = np.empty((W, self.P)) if return_var else None
+        self._ck(self.lib.gpb_gp_predict(self.h, nat.ptr(Xs), W, 0, nat.ptr(mean), nat.ptr(var)))
+        return (mean, var) if return_var else mean
+
+    # ------------------------------------------------------------------ emulator transform
+    def set_transform(self, mode, mu, A=None, cov_trunc=None, scale=None):
+        mu = nat.f64(mu)
+        self.M = mu.shape[0]
+        A = None if A is None else nat.f64(A)
+        cov_trunc = None if cov_trunc is None else nat.f64(cov_trunc)
+        scale = None if scale is None else nat.f64(scale)
+        self._ck(self.lib.gpb_emu_set_transform(self.h, int(mode), self.M, nat.ptr(A), nat.ptr(mu),
+                                                nat.ptr(cov_trunc), nat.ptr(scale)))
+
+    def emu_predict(self, Xs, return_cov=True, extra_std=None):
+        if _is_torch(Xs):
+            import torch
+            W = Xs.shape[0]
+            mean = torch.empty((W, self.M), dtype=torch.float64, device=Xs.device)
+            cov = torch.empty((W, self.M, self.M), dtype=torch.float64, device=Xs.device) if return_cov else None
+            self._ck(self.lib.gpb_emu_predict(self.h, nat.ptr(Xs.contiguous()), W, 1, nat.ptr(extra_std),
+                                              nat.ptr(mean), nat.ptr(cov)))
+            return (mean, cov) if return_cov else mean
+        Xs = nat.f64(Xs).reshape(-1, self.d)
+        W = Xs.shape[0]
+        es = None if extra_std is None else nat.f64(np.broadcast_to(np.asarray(extra_std, float).reshape(-1), (W,)))
+        mean = np.empty((W, self.M))
+        cov = np.empty((W, self.M, self.M)) if return_cov else None
+        self._ck(self.lib.gpb_emu_predict(self.h, nat.ptr(Xs), W, 0, nat.ptr(es), nat.ptr(mean), nat.ptr(cov)))
+        return (mean, cov) if return_cov else mean
+
+    # ------------------------------------------------------------------ likelihood block
+    def set_likelihood(self, yexp, cov_exp):
+        yexp, cov_exp = nat.f64(yexp).reshape(-1), nat.f64(cov_exp)
+        assert yexp.shape[0] == self.M and cov_exp.shape == (self.M, self.M)
+        self._ck(self.lib.gpb_like_set(self.h, nat.ptr(yexp), nat.ptr(cov_exp)))
+
+    def loglike(self, Xs, out=None, accumulate=False, check=True):
+        """Block log-likelihood for every row of Xs.  torch(cuda) in/out stays on the device
+        and is asynchronous when check=False."""
+        npd = C.c_int(0)
+        if _is_torch(Xs):
+            import torch
+            W = Xs.shape[0]
+            if out is None:
+                out = torch.empty(W, dtype=torch.float64, device=Xs.device)
+                accumulate = False
+            self._ck(self.lib.gpb_loglike(self.h, nat.ptr(Xs.contiguous()), W, 1, nat.ptr(out),
+                                          1 if accumulate else 0, C.byref(npd) if check else None))
+        else:
+            Xs = nat.f64(Xs).reshape(-1, self.d)
+            W = Xs.shape[0]
+            if out is None:
+                out = np.empty(W)
+                accumulate = False
+            self._ck(self.lib.gpb_loglike(self.h, nat.ptr(Xs), W, 0, nat.ptr(out), 1 if accumulate else 0,
+                                          C.byref(npd) if check else None))
+        self.last_not_pd = npd.value
+        return out
+
+    def mvn_loglike(self, dY, cov):
+        """Batched mvn_loglike on explicit dY[W,M], cov[W,M,M] (numpy or torch cuda)."""
+        npd = C.c_int(0)
+        if _is_torch(dY):
+            import torch
+            W, M = dY.shape
+            out = torch.empty(W, dtype=torch.float64, device=dY.device)
+            self._ck(self.lib.gpb_mvn_loglike(self.h, nat.ptr(dY.contiguous()), nat.ptr(cov.contiguous()), W, M, 1,
+                                              nat.ptr(out), C.byref(npd)))
+        else:
+            dY, cov = nat.f64(dY), nat.f64(cov)
+            W, M = dY.shape
+            out = np.empty(W)
+            self._ck(self.lib.gpb_mvn_loglike(self.h, nat.ptr(dY), nat.ptr(cov), W, M, 0, nat.ptr(out),
+                                              C.byref(npd)))
+        self.last_not_pd = npd.value
+        return out
+
+    def box_finish(self, X_dev, lo_dev, hi_dev, outside, const, ll_dev):
+        self._ck(self.lib.gpb_box_finish(self.h, nat.ptr(X_dev), X_dev.shape[0], nat.ptr(lo_dev), nat.ptr(hi_dev),
+                                         float(outside), float(const), nat.ptr(ll_dev)))
+
+    # ------------------------------------------------------------------ diagnostics
+    def test_gemm(self, A, B, mode=0):
+        A, B = nat.f64(A), nat.f64(B)
+        if mode == 0:
+            M, K = A.shape; N = B.shape[1]
+        elif mode == 1:
+            M, K = A.shape; N = B.shape[0]
+        else:
+            K, M = A.shape; N = B.shape[1]
+        Cm = np.empty((M, N))
+        self._ck(self.lib.gpb_test_gemm(self.h, M, N, K, nat.ptr(A), nat.ptr(B), nat.ptr(Cm), mode))
+        return Cm
+
+    def probe_fp64(self, mode):
+        out = C.c_double(0.0)
+        self._ck(self.lib.gpb_probe_fp64(self.h, int(mode), C.byref(out)))
+        return out.value

@@ -1,0 +1,266 @@
+"""
+Drop-in replacement for the reference's `src/mcmc.py` log-posterior path and emcee driver
+(B2 protocol): `mvn_loglike`, `Chain` with `log_prior / log_likelihood /
+log_posterior / _predict / run_mcmc / run_pocoMC / compute_log_likelihood_for_chain`.
+
+Every emulator prediction, covariance assembly, Cholesky and quadratic form runs in the HIP
+engine.  When all emulators in `emuList` are this package's `Emulator`, a log-probability call
+is E fused `gpb_loglike` block evaluations plus one box kernel; rows never leave HBM between
+them.  Foreign emulators (anything with the reference's predict protocol) go through
+`_predict` on the host and the generic batched device MVN (`gpb_mvn_loglike`).
+"""
+import logging
+import math
+import pickle
+from pathlib import Path
+
+import numpy as np
+
+from .emulator import Emulator
+from .engine import GPEngine
+from .preprocess import parse_model_parameter_file
+
+log = logging.getLogger(__name__)
+
+# the reference adds 2*log(extra_std + 1e-16) - extra_std/scale with extra_std == 0*X[:, -1]
+# (src/mcmc.py:205,220-221 and :281,296-297): a constant inside the box
+EXTRA_STD_CONST = 2.0 * math.log(1e-16)
+
+_util_engine = None
+
+
+def _utility_engine(device=0):
+    global _util_engine
+    if _util_engine is None:
+        _util_engine = GPEngine(device)
+    return _util_engine
+
+
+def mvn_loglike(y, cov):
+    """Unnormalised multivariate-normal log-likelihood -1/2 y^T C^-1 y - 1/2 log det C
+    (src/mcmc.py:23-65), evaluated by the device Cholesky kernel.  A covariance that is not
+    positive definite raises numpy.linalg.LinAlgError (the reference's branch for this case is
+    unreachable, src/mcmc.py:44-54)."""
+    eng = _utility_engine()
+    out = eng.mvn_loglike(np.asarray(y, float)[None, :], np.asarray(cov, float)[None, :, :])
+    if eng.last_not_pd:
+        raise np.linalg.LinAlgError("mvn_loglike: covariance is not positive definite")
+    return float(out[0])
+
+
+class Chain:
+    def __init__(self, mcmc_path="./mcmc/chain.pkl", expdata_path="./exp_data.dat",
+                 model_parafile="./model.dat", device=0):
+        self.mcmc_path = Path(mcmc_path)
+        self.mcmc_path.parent.mkdir(exist_ok=True)
+        self.pardict = parse_model_parameter_file(model_parafile)
+        self.ndim = len(self.pardict)
+        self.label = [v[0] for v in self.pardict.values()]
+        self.min = np.array([v[1] for v in self.pardict.values()])
+        self.max = np.array([v[2] for v in self.pardict.values()])
+        self.prior_volume_ = np.prod(self.max - self.min)
+        self.expdata, self.expdata_cov = self._read_in_exp_data_pickle(expdata_path)
+        self.nobs = self.expdata.shape[1]
+        self.emuList = []
+        self.chain = False
+        self.device = device
+        self._like_sig = None
+
+    # ------------------------------------------------------------------ inputs
+    def _read_in_exp_data_pickle(self, filepath):
+        """One experimental event: values and errors; covariance = diag(err^2)
+        (src/mcmc.py:302-324)."""
+        with open(filepath, "rb") as fp:
+            data = pickle.load(fp)
+        vals = np.array([data[k]["obs"][0] for k in data.keys()])
+        errs = np.nan_to_num(np.abs(np.array([data[k]["obs"][1] for k in data.keys()])))
+        cov = np.diag(errs.flatten() ** 2)
+        return vals, cov
+
+    def loadEmulator(self, emulatorPathList):
+        import dill
+        for path in emulatorPathList:
+            with open(path, "rb") as f:
+                self.emuList.append(dill.load(f))
+        log.info("Number of Emulators: %d", len(self.emuList))
+
+    def random_pos(self, n=1):
+        return np.random.uniform(self.min, self.max, (n, self.ndim))
+
+    @staticmethod
+    def map(f, args):
+        """Lets the object stand in as an emcee `pool` so that the sampler hands the whole
+        half-ensemble to the log-probability function in one call (src/mcmc.py:335-342)."""
+        return f(args)
+
+    # ------------------------------------------------------------------ model prediction
+    def _predict(self, X, extra_std=0.0):
+        """Concatenated means and block-diagonal covariance over the emulators
+        (src/mcmc.py:153-166)."""
+        n = X.shape[0]
+        mean = np.zeros((n, self.nobs))
+        cov = np.zeros((n, self.nobs, self.nobs))
+        es = extra_std * X[:, -1]
+        i0 = 0
+        for emu in self.emuList:
+            m, c = emu.predict(X, return_cov=True, extra_std=es)
+            k = m.shape[1]
+            mean[:, i0:i0 + k] = m
+            cov[:, i0:i0 + k, i0:i0 + k] = c
+            i0 += k
+        return mean, cov
+
+    # ------------------------------------------------------------------ log-probabilities
+    def log_prior(self, X):
+        """log(1/volume) inside the open box, -inf outside (src/mcmc.py:169-185)."""
+        X = np.array(X, ndmin=2, dtype=np.float64)
+        lp = np.log(np.ones(X.shape[0]) / self.prior_volume_)
+        lp[~np.all((X > self.min) & (X < self.max), axis=1)] = -np.inf
+        return lp
+
+    def _native(self):
+        return len(self.emuList) > 0 and all(isinstance(e, Emulator) for e in self.emuList)
+
+    def _prepare_blocks(self):
+        """Hand every emulator its slice of the experimental data.  The fused path needs the
+        experimental covariance to be block-diagonal over the emulators (it is diagonal in the
+        reference, src/mcmc.py:320-322)."""
+        sig = (id(self.expdata), id(self.expdata_cov), tuple(id(e) for e in self.emuList),
+               tuple(id(e._engine) for e in self.emuList))
+        if sig == self._like_sig:
+            return
+        i0 = 0
+        mask = np.zeros_like(self.expdata_cov, dtype=bool)
+        for emu in self.emuList:
+            k = emu.nobs
+            eng = emu._engine_ready()
+            eng.set_likelihood(self.expdata[0, i0:i0 + k], self.expdata_cov[i0:i0 + k, i0:i0 + k])
+            mask[i0:i0 + k, i0:i0 + k] = True
+            i0 += k
+        if i0 != self.nobs:
+            raise ValueError("emulators provide %d observables, experiment has %d" % (i0, self.nobs))
+        if np.any(self.expdata_cov[~mask] != 0.0):
+            raise ValueError("experimental covariance couples different emulators; "
+                             "the fused likelihood needs it block-diagonal")
+        self._like_sig = (sig[0], sig[1], sig[2], tuple(id(e._engine) for e in self.emuList))
+
+    def log_prob_device(self, X_dev, out=None, outside=-np.inf, lo_dev=None, hi_dev=None):
+        """Device-resident log-posterior: X_dev torch.float64 cuda [W,ndim] -> lp [W] (no host
+        sync).  Used by the resident sampler; `log_posterior`/`log_likelihood` wrap it."""
+        import torch
+        self._prepare_blocks()
+        if out is None:
+            out = torch.empty(X_dev.shape[0], dtype=torch.float64, device=X_dev.device)
+        if lo_dev is None:
+            lo_dev = torch.as_tensor(self.min, dtype=torch.float64, device=X_dev.device)
+            hi_dev = torch.as_tensor(self.max, dtype=torch.float64, device=X_dev.device)
+        eng0 = None
+        for i, emu in enumerate(self.emuList):
+            eng = emu._engine_ready()
+            eng.loglike(X_dev, out=out, accumulate=(i > 0), check=False)
+            eng0 = eng0 or eng      # all engines enqueue on torch's current stream: ordered
+        eng0.box_finish(X_dev, lo_dev, hi_dev, outside, EXTRA_STD_CONST, out)
+        return out
+
+    def _log_prob(self, X, outside):
+        X = np.array(X, ndmin=2, dtype=np.float64)
+        if self._native():
+            import torch
+            dev = torch.device("cuda", self.device)
+            Xd = torch.as_tensor(np.ascontiguousarray(X), device=dev)
+            return self.log_prob_device(Xd, outside=outside).cpu().numpy()
+        # generic path: foreign emulators predict on the host, the MVN runs on the device
+        lp = np.zeros(X.shape[0])
+        inside = np.all((X > self.min) & (X < self.max), axis=1)
+        lp[~inside] = outside
+        if np.count_nonzero(inside) > 0:
+            Xi = X[inside]
+            mY, mC = self._predict(Xi, 0.0 * Xi[:, -1])
+            eng = _utility_engine(self.device)
+            lp[inside] += eng.mvn_loglike(mY - self.expdata, mC + self.expdata_cov)
+            lp[inside] += EXTRA_STD_CONST
+        return lp
+
+    def log_likelihood(self, X, extra_std_prior_scale=0.001, finite=False):
+        """src/mcmc.py:188-222 (pocoMC calls it with finite=True)."""
+        return self._log_prob(X, -1e300 if finite else -np.inf)
+
+    def log_posterior(self, X, extra_std_prior_scale=.05):
+        """src/mcmc.py:261-299 (the function emcee samples)."""
+        return self._log_prob(X, -np.inf)
+
+    def log_likelihood_point_by_point(self, X, extra_std_prior_scale=0.001):
+        """Same values as the reference's per-row loop (src/mcmc.py:225-258), in one batch."""
+        return self._log_prob(np.asarray(X), -np.inf)
+
+    def compute_log_likelihood_for_chain(self, output_path="./mcmc/log_likelihood.pkl"):
+        """src/mcmc.py:729-749."""
+        if self.chain is False:
+            with open(self.mcmc_path, "rb") as f:
+                self.chain = pickle.load(f)["chain"]
+        ll = self.log_likelihood_point_by_point(self.chain.reshape(-1, self.ndim))
+        ll = ll.reshape(self.chain.shape[0], self.chain.shape[1])
+        with open(output_path, "wb") as f:
+            pickle.dump({"log_likelihood": ll}, f)
+
+    # ------------------------------------------------------------------ samplers
+    def run_mcmc(self, nsteps=500, nburnsteps=None, nwalkers=None, status=None, nthin=10,
+                 skip_initial_state_check=False, seed=None):
+        """Affine-invariant ensemble sampling with the reference's schedule (src/mcmc.py:345-426):
+        resume from an existing chain pickle, else two-stage burn-in with re-seeding at the
+        `nwalkers` best unique log-probabilities, then production; thinned chain appended to
+        `{'chain': [nwalkers, nsteps/nthin, ndim]}`.  The stretch move runs on the device
+        (sampler.StretchSampler) instead of emcee."""
+        from .sampler import StretchSampler
+        chain_data = {}
+        try:
+            with open(self.mcmc_path, "rb") as f:
+                chain_data = pickle.load(f)
+        except FileNotFoundError:
+            pass
+        burn = "chain" not in chain_data
+        if nburnsteps is None or nwalkers is None:
+            log.error("must specify nburnsteps and nwalkers to start chain")
+            return
+        sampler = StretchSampler(self, nwalkers, seed=seed)
+        if burn:
+            nburn0 = nburnsteps // 2
+            sampler.run(self.random_pos(nwalkers), nburn0, status=status)
+            flat_lp = sampler.lnprobability.reshape(-1)
+            flat_x = sampler.chain.reshape(-1, self.ndim)
+            X0 = flat_x[np.unique(flat_lp, return_index=True)[1][-nwalkers:]]
+            sampler.reset()
+            X0 = sampler.run(X0, nburnsteps - nburn0, status=status)
+            sampler.reset()
+        else:
+            X0 = chain_data["chain"][:, -1, :]
+        sampler.run(X0, nsteps, status=status)
+        thinned = sampler.chain[:, ::nthin, :]
+        if "chain" in chain_data:
+            chain_data["chain"] = np.concatenate((chain_data["chain"], thinned), axis=1)
+        else:
+            chain_data["chain"] = thinned
+        self.chain = chain_data["chain"]
+        self.acceptance_fraction = sampler.acceptance_fraction
+        with open(self.mcmc_path, "wb") as f:
+            pickle.dump(chain_data, f)
+
+    def run_pocoMC(self, n_effective=1000, n_active=250, n_prior=2000, sample="tpcn", n_max_steps=200,
+                   random_state=42, n_total=5000, n_evidence=5000, pool=None, prior=None):
+        """pocoMC driver with the reference's call shape and output schema (src/mcmc.py:752-819);
+        the likelihood callback is this class's device-backed log_likelihood(finite=True)."""
+        import pocomc
+        from scipy.stats import uniform
+        if prior is None:
+            prior = pocomc.Prior([uniform(self.min[i], self.max[i] - self.min[i]) for i in range(self.ndim)])
+        elif self.ndim != prior.dim:
+            raise ValueError("prior.dim does not match the model parameter space")
+        sampler = pocomc.Sampler(prior=prior, likelihood=self.log_likelihood, likelihood_kwargs={"finite": True},
+                                 n_effective=n_effective, n_active=n_active, n_prior=n_prior, sample=sample,
+                                 n_max_steps=n_max_steps, random_state=random_state, vectorize=True, pool=pool)
+        sampler.run(n_total=n_total, n_evidence=n_evidence)
+        samples, weights, logl, logp = sampler.posterior()
+        logz, logz_err = sampler.evidence()
+        with open(self.mcmc_path, "wb") as f:
+            pickle.dump({"chain": samples, "weights": weights, "logl": logl, "logp": logp, "logz": logz,
+                         "logz_err": logz_err}, f)

@@ -1,0 +1,142 @@
+"""
+Device-resident affine-invariant ensemble sampler: the emcee stretch move (a = 2) that the
+reference drives through `LoggingEnsembleSampler` (src/mcmc.py:68-92, 372-412), with walker
+positions, log-probabilities, proposals and the chain kept in HBM.
+
+Per step and per half-ensemble ("red"/"blue"): gpb_stretch_propose -> log-probability of the
+proposals (Chain.log_prob_device, optionally walker-sharded over ranks with one all-gather) ->
+gpb_stretch_accept.  Nothing synchronises with the host inside the loop; Python only enqueues.
+Random numbers come from a counter-based Philox generator keyed by (seed, step, half, walker),
+so every rank of a sharded run generates identical proposals and accept decisions without
+exchanging positions.
+
+emcee itself is not installed in the build environment, so its MT19937 stream order cannot be
+reproduced; equivalence with emcee is statistical (tests/test_gpu_sampler.py), while
+log-probabilities at identical inputs are pinned by the golden vectors.
+"""
+import logging
+
+import numpy as np
+
+from . import _native as nat
+
+log = logging.getLogger(__name__)
+
+
+class StretchSampler:
+    def __init__(self, chain, nwalkers, seed=None, a=2.0, logprob_device=None, sharding=None,
+                 device=None):
+        """chain: object with .min/.max/.ndim and log_prob_device(X_dev, out) (mcmc.Chain).
+        logprob_device: optional override f(X_dev, out_dev) -> out_dev.
+        sharding: optional dist.WalkerSharding (one process per GPU)."""
+        import torch
+        if nwalkers % 2:
+            raise ValueError("nwalkers must be even")
+        self.torch = torch
+        self.chain_obj = chain
+        self.ndim = int(chain.ndim)
+        self.nwalkers = int(nwalkers)
+        if self.nwalkers < 2 * self.ndim:
+            log.warning("fewer walkers than 2*ndim")
+        self.a = float(a)
+        self.seed = int(np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0]) if seed is None \
+            else int(seed)
+        self.device = torch.device("cuda", chain.device if device is None else device)
+        self.sharding = sharding
+        self._logprob = logprob_device or chain.log_prob_device
+        self._eng = None
+        self._step_counter = 0
+        nh = self.nwalkers // 2
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self.pos = torch.empty((self.nwalkers, self.ndim), **f64)
+        self.lp = torch.empty(self.nwalkers, **f64)
+        self.q = torch.empty((nh, self.ndim), **f64)
+        self.factor = torch.empty(nh, **f64)
+        self.lpq = torch.empty(nh, **f64)
+        self.naccept = torch.zeros(self.nwalkers, dtype=torch.int64, device=self.device)
+        self.reset()
+
+    # ------------------------------------------------------------------ helpers
+    def _engine(self):
+        if self._eng is None:
+            emus = getattr(self.chain_obj, "emuList", None)
+            if emus:
+                self._eng = emus[0]._engine_ready()
+            else:
+                from .engine import GPEngine
+                self._eng = GPEngine(self.device.index or 0)
+        return self._eng
+
+    def _eval(self, X_dev, out_dev):
+        if self.sharding is not None:
+            return self.sharding.logprob(self._logprob, X_dev, out_dev)
+        return self._logprob(X_dev, out_dev)
+
+    def reset(self):
+        self._chain_dev = None
+        self._lp_dev = None
+        self.iterations = 0
+        self.naccept.zero_()
+
+    # ------------------------------------------------------------------ main loop
+    def run(self, X0, nsteps, status=None, store=True):
+        """Advance `nsteps` stretch-move steps from X0[nwalkers, ndim]; returns the final positions
+        (numpy).  Mirrors LoggingEnsembleSampler.run_mcmc (src/mcmc.py:69-92)."""
+        torch = self.torch
+        eng = self._engine()
+        lib, h = eng.lib, eng.h
+        nw, d = self.nwalkers, self.ndim
+        self.pos.copy_(torch.as_tensor(np.ascontiguousarray(X0, dtype=np.float64)))
+        self._eval(self.pos, self.lp)
+        if store:
+            cd = torch.empty((nsteps, nw, d), dtype=torch.float64, device=self.device)
+            ld = torch.empty((nsteps, nw), dtype=torch.float64, device=self.device)
+        if status is None:
+            status = max(nsteps // 10, 1)
+        for n in range(1, nsteps + 1):
+            step = self._step_counter
+            self._step_counter += 1
+            for half in (0, 1):
+                eng._ck(lib.gpb_stretch_propose(h, nat.ptr(self.pos), nw, d, half, self.seed, step, self.a,
+                                                nat.ptr(self.q), nat.ptr(self.factor)))
+                self._eval(self.q, self.lpq)
+                eng._ck(lib.gpb_stretch_accept(h, nat.ptr(self.pos), nat.ptr(self.lp), nw, d, half, self.seed,
+                                               step, nat.ptr(self.q), nat.ptr(self.factor), nat.ptr(self.lpq),
+                                               nat.ptr(self.naccept)))
+            if store:
+                cd[n - 1].copy_(self.pos)
+                ld[n - 1].copy_(self.lp)
+            self.iterations += 1
+            if n % status == 0 or n == nsteps:
+                af = self.acceptance_fraction
+                log.info("step %d: acceptance fraction: mean %.4f, std %.4f, min %.4f, max %.4f",
+                         n, af.mean(), af.std(), af.min(), af.max())
+        if store:
+            self._chain_dev = cd if self._chain_dev is None else torch.cat([self._chain_dev, cd], 0)
+            self._lp_dev = ld if self._lp_dev is None else torch.cat([self._lp_dev, ld], 0)
+        if torch.isnan(self.lp).any().item():
+            raise ValueError("Probability function returned NaN")       # emcee's contract
+        return self.pos.cpu().numpy()
+
+    # ------------------------------------------------------------------ emcee-style accessors
+    @property
+    def acceptance_fraction(self):
+        return self.naccept.cpu().numpy() / max(self.iterations, 1)
+
+    @property
+    def chain(self):
+        """[nwalkers, nsteps, ndim] like emcee's `sampler.chain`."""
+        return self._chain_dev.permute(1, 0, 2).contiguous().cpu().numpy()
+
+    @property
+    def lnprobability(self):
+        """[nwalkers, nsteps]."""
+        return self._lp_dev.permute(1, 0).contiguous().cpu().numpy()
+
+    @property
+    def flatchain(self):
+        return self._chain_dev.reshape(-1, self.ndim).cpu().numpy()
+
+    @property
+    def flatlnprobability(self):
+        return self._lp_dev.reshape(-1).cpu().numpy()

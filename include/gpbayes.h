@@ -1,0 +1,176 @@
+/*
+ * gpbayes.h — C ABI of the MI355X-native GP-emulator + log-posterior engine.
+ *
+ * The reference (Hendrik1704/GPBayesTools-HIC) is pure Python and has no FFI of its
+ * own; the hot path sits behind three duck-typed Python seams.  This
+ * header is the C boundary a maintainer binds with ctypes; each
+ * entry point names the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all matrices row-major float64; sizes int64_t.
+ *   - pointers flagged "host" are caller-owned host memory; pointers flagged "dev"
+ *     are caller-owned device (HBM) memory on the context's device.  Functions with
+ *     an `on_device` argument accept either.
+ *   - every function returns int: 0 = ok, >0 = LAPACK-style info (1-based index of the
+ *     first non-positive pivot), <0 = GPB_E_* error; gpb_last_error() gives the text.
+ *   - work is enqueued on the context's HIP stream; functions that return host data
+ *     synchronise that stream themselves, device-output functions do not
+ *     (call gpb_sync or use stream order).
+ *   - one context per (process, device, emulator); not thread-safe per context.
+ *   - there is NO CPU fallback: if no gfx950 device is present gpb_ctx_create fails.
+ */
+#ifndef GPBAYES_H
+#define GPBAYES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPB_VERSION 100
+
+/* kernel_id  — sklearn kernels the reference instantiates (src/emulator.py:286-306) */
+#define GPB_KERNEL_RBF      0   /* 1.*RBF(l) + White          sk:kernels.py:1525-1575 */
+#define GPB_KERNEL_MATERN15 1   /* 1.*Matern(l, nu=1.5)+White sk:kernels.py:1721-1723 */
+#define GPB_KERNEL_MATERN25 2   /* nu=2.5 (BASELINE cfg 5)    sk:kernels.py:1724-1726 */
+
+/* observable-transform modes of Emulator.predict (src/emulator.py:558-601) */
+#define GPB_MODE_PCA            0
+#define GPB_MODE_NO_PCA         1  /* perform_no_PCA=True            :562-565,589-592 */
+#define GPB_MODE_EXPDIAG        2  /* exp_and_cov_diagonal=True      :567-568,594-601 */
+#define GPB_MODE_NO_PCA_EXPDIAG 3
+
+/* errors */
+#define GPB_E_ARG     (-1)
+#define GPB_E_STATE   (-2)
+#define GPB_E_HIP     (-3)
+#define GPB_E_NODEV   (-4)
+#define GPB_E_ALLOC   (-5)
+#define GPB_E_RCCL    (-6)
+
+/* gpb_gp_get selectors */
+#define GPB_GET_K      0  /* [P,N,N] K(X,X)+(noise+alpha)I as built (lower triangle valid after factor -> use before) */
+#define GPB_GET_L      1  /* [P,N,N] lower Cholesky factor, upper zeroed  == GPR.L_     */
+#define GPB_GET_LINV   2  /* [P,N,N] L^-1 (lower)                                       */
+#define GPB_GET_ALPHA  3  /* [P,N]   K^-1 z                               == GPR.alpha_ */
+
+typedef struct gpb_ctx gpb_ctx;
+
+/* ---- lifetime -------------------------------------------------------------------- */
+int  gpb_version(void);
+int  gpb_device_count(void);
+/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream), or
+ * NULL to create a private one. */
+int  gpb_ctx_create(int device, void* stream, gpb_ctx** out);
+int  gpb_ctx_destroy(gpb_ctx* ctx);
+/* Re-target the context onto a caller stream; NULL selects the legacy default stream (what
+ * torch.cuda.current_stream() is unless the caller changed it). */
+int  gpb_ctx_set_stream(gpb_ctx* ctx, void* stream);
+int  gpb_sync(gpb_ctx* ctx);
+const char* gpb_last_error(gpb_ctx* ctx);
+void* gpb_stream(gpb_ctx* ctx);
+
+/* ---- GP state: replaces sklearn GaussianProcessRegressor state ------------------- *
+ * gpb_gp_set        <- GPR(kernel, alpha).fit(X, z) inputs          src/emulator.py:309-315
+ * gpb_gp_set_theta  <- kernel_.theta                                sk:_gpr.py:332
+ * gpb_gp_factor     <- K=kernel_(X); K_ii+=alpha; L_=cholesky(K); alpha_=cho_solve   sk:_gpr.py:346-364
+ * gpb_gp_lml        <- GPR.log_marginal_likelihood(theta, eval_gradient)             sk:_gpr.py:537-652
+ * gpb_gp_predict    <- GPR.predict(X, return_cov=True) + .diagonal()   sk:_gpr.py:441-469, src/emulator.py:553,573-575
+ */
+int gpb_gp_set(gpb_ctx* ctx, int64_t N, int64_t d, int64_t P,
+               const double* X_host /*[N,d]*/, const double* Z_host /*[P,N]*/,
+               int kernel_id, double alpha);
+int gpb_gp_set_theta(gpb_ctx* ctx, const double* theta_host /*[P,d+2]*/);
+int gpb_gp_factor(gpb_ctx* ctx, int* info_host /*[P], may be NULL*/);
+int gpb_gp_get(gpb_ctx* ctx, int what, double* out_host);
+/* Evaluates at theta_host (state of the context's factorisation is overwritten; call
+ * gpb_gp_set_theta+gpb_gp_factor afterwards to restore).  grad_host may be NULL.
+ * Non-PD K for GP p: lml[p] = -inf, grad[p,:] = 0, info[p] > 0 (sk:_gpr.py:588-589). */
+int gpb_gp_lml(gpb_ctx* ctx, const double* theta_host /*[P,d+2]*/,
+               double* lml_host /*[P]*/, double* grad_host /*[P,d+2] or NULL*/,
+               int* info_host /*[P] or NULL*/);
+/* mean/var are [W,P] (reference layout of the concatenated per-GP outputs). */
+int gpb_gp_predict(gpb_ctx* ctx, const double* Xs, int64_t W, int on_device,
+                   double* mean /*[W,P]*/, double* var /*[W,P] or NULL*/);
+
+/* ---- emulator transform: replaces Emulator.predict after the per-GP calls -------- *
+ * gpb_emu_set_transform <- _trans_matrix[:npc], scaler.mean_, _cov_trunc, scaler.scale_  src/emulator.py:335-363
+ * gpb_emu_predict       <- Emulator.predict(X, return_cov, extra_std)                   src/emulator.py:465-605
+ */
+int gpb_emu_set_transform(gpb_ctx* ctx, int mode, int64_t M,
+                          const double* A_host /*[P,M] or NULL (no-PCA)*/,
+                          const double* mu_host /*[M]*/,
+                          const double* cov_trunc_host /*[M,M] or NULL*/,
+                          const double* scale_host /*[M] or NULL (PCA)*/);
+int gpb_emu_predict(gpb_ctx* ctx, const double* Xs, int64_t W, int on_device,
+                    const double* extra_std /*[W] or NULL (=0), same memory space as Xs*/,
+                    double* mean /*[W,M]*/, double* cov /*[W,M,M] or NULL*/);
+
+/* ---- likelihood block: replaces Chain._predict + mvn_loglike for ONE emulator ---- *
+ * gpb_like_set   <- expdata[i0:i0+M], expdata_cov[i0:i0+M, i0:i0+M]    src/mcmc.py:139,302-324
+ * gpb_loglike    <- -1/2 dY^T C^-1 dY - sum log diag chol(C), C = cov_model + cov_exp
+ *                   for this emulator's diagonal block                 src/mcmc.py:23-65,153-166,288-293
+ * The reference's covariance is block-diagonal over emulators (src/mcmc.py:163-164) and
+ * the experimental covariance is diagonal (src/mcmc.py:320-322), so the multivariate
+ * normal factorises: log-likelihood = sum over emulators of gpb_loglike blocks.
+ * Rows whose block is not positive definite get NaN (the reference yields garbage there,
+ * src/mcmc.py:44-54); *n_notpd_host counts them.
+ */
+int gpb_like_set(gpb_ctx* ctx, const double* yexp_host /*[M]*/, const double* cov_exp_host /*[M,M]*/);
+int gpb_loglike(gpb_ctx* ctx, const double* Xs, int64_t W, int on_device,
+                double* ll /*[W], same memory space as Xs*/, int accumulate,
+                int* n_notpd_host /*may be NULL; forces a sync when non-NULL*/);
+
+/* gpb_mvn_loglike <- map(mvn_loglike, dY, cov): generic batched form on caller-provided
+ *                    dY[W,M], cov[W,M,M] (any covariance, e.g. from foreign emulators)   src/mcmc.py:23-65,293 */
+int gpb_mvn_loglike(gpb_ctx* ctx, const double* dY, const double* cov, int64_t W, int64_t M, int on_device,
+                    double* ll /*[W]*/, int* n_notpd_host /*may be NULL*/);
+
+/* ---- chain-level helpers (device, for resident sampling loops) ------------------- *
+ * gpb_box_finish <- inside=all(min<X<max) (strict); lp[~inside]=-inf|-1e300;
+ *                   lp[inside] = ll + const                             src/mcmc.py:194-198,220-221,275-276,296-297
+ */
+int gpb_box_finish(gpb_ctx* ctx, const double* X_dev /*[W,d]*/, int64_t W,
+                   const double* lo_dev, const double* hi_dev, double outside_value,
+                   double inside_const, double* ll_inout_dev /*[W]*/);
+
+/* ---- emcee-equivalent stretch move (device resident) ------------------------------ *
+ * Replaces emcee.EnsembleSampler.sample as driven by LoggingEnsembleSampler.run_mcmc
+ * (src/mcmc.py:68-92,372-412): red/blue stretch move, a=2, counter-based Philox RNG
+ * replicated on every rank.
+ * gpb_stretch_propose: for the walkers of half `half` (walker k of the half is index 2k+half,
+ *   i.e. emcee's inds = arange(nwalkers) % 2) draw the complementary walker and z, write
+ *   proposals q[nhalf,d] and the (d-1) ln z factor[nhalf].
+ * gpb_stretch_accept: accept where (d-1)*ln z + lp' - lp > ln u; updates pos, lp, naccept.
+ */
+int gpb_stretch_propose(gpb_ctx* ctx, const double* pos_dev /*[nw,d]*/, int64_t nwalkers, int64_t d,
+                        int half, uint64_t seed, uint64_t step, double a,
+                        double* q_dev /*[nw/2,d]*/, double* factor_dev /*[nw/2]*/);
+int gpb_stretch_accept(gpb_ctx* ctx, double* pos_dev, double* lp_dev /*[nw]*/, int64_t nwalkers, int64_t d,
+                       int half, uint64_t seed, uint64_t step,
+                       const double* q_dev, const double* factor_dev, const double* lpq_dev /*[nw/2]*/,
+                       int64_t* naccept_dev /*[nw]*/);
+
+/* ---- walker sharding over RCCL (one process per GPU) ------------------------------ *
+ * gpb_dist_uid: rank 0 obtains a 128-byte ncclUniqueId to broadcast out of band.
+ * gpb_dist_init / gpb_dist_allgather: in-stream ncclAllGather of per-walker
+ * log-posteriors (count doubles per rank) — the one exchange per log-prob batch.
+ */
+int gpb_dist_uid(void* uid128_host);
+int gpb_dist_init(gpb_ctx* ctx, int rank, int nranks, const void* uid128_host);
+int gpb_dist_allgather(gpb_ctx* ctx, const double* send_dev, double* recv_dev, int64_t count);
+int gpb_dist_finalize(gpb_ctx* ctx);
+
+/* ---- micro-benchmarks / self-tests (device) --------------------------------------- */
+/* C[M,N] = A[M,K] * B[K,N] through the f64 MFMA tile engine (all multiples of 128/16). */
+int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K,
+                  const double* A_host, const double* B_host, double* C_host, int b_trans);
+/* issue-rate probe: returns measured TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64
+ * (mode 0), v_fma_f64 (mode 1) or both co-issued (mode 2). */
+int gpb_probe_fp64(gpb_ctx* ctx, int mode, double* tflops_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPBAYES_H */

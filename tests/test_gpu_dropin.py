@@ -1,0 +1,135 @@
+"""
+GPU tier: the drop-in `Emulator` / `Chain` classes against vectors captured from the reference's
+own src/emulator.py and src/mcmc.py (every flag combination the reference has).
+"""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import golden, relerr, maxrel
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = {
+    "pca_rbf": ("RBF", {}),
+    "pca_trunc": ("RBF", {}),
+    "nopca_rbf": ("RBF", dict(perform_no_PCA=True)),
+    "logexp_rbf": ("RBF", dict(logTrafo=True, exp_and_cov_diagonal=True)),
+    "pca_matern": ("Matern", {}),
+}
+
+
+def _make_emulator(tmp_path, g, kw, tag="e"):
+    from gpbayestools_hic_amd import Emulator, synth
+    tp, pf = str(tmp_path / f"{tag}_train.pkl"), str(tmp_path / f"{tag}_par.txt")
+    synth.write_training_pickle(tp, g["X"], g["Y"], g["Yerr"])
+    synth.write_parameter_file(pf, g["lo"], g["hi"])
+    return Emulator(training_set_path=tp, parameter_file=pf, npc=int(g["npc"]), **kw)
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_g3_g4_emulator_at_reference_theta(tmp_path, name):
+    g = golden(f"g3_emulator_{name}.npz")
+    ktype, kw = VARIANTS[name]
+    emu = _make_emulator(tmp_path, g, kw)
+    assert maxrel(emu.model_data, g["model_data"]) < 1e-15
+    emu.trainEmulator([True] * emu.nev, kernel_type=ktype, thetas=g["thetas"])
+    assert maxrel(emu.scaler.mean_, g["scaler_mean"]) < 1e-14
+    assert maxrel(emu.scaler.scale_, g["scaler_scale"]) < 1e-14
+    if "trans_matrix" in g.files:
+        assert maxrel(emu._trans_matrix, g["trans_matrix"]) < 1e-11
+        assert maxrel(emu._cov_trunc, g["cov_trunc"]) < 1e-11
+        assert maxrel(emu._var_trans, g["var_trans"]) < 1e-11
+    assert relerr(emu.lml_, g["lml"]) < 1e-10
+    assert maxrel(np.array([gp.alpha_ for gp in emu.gps]), g["alpha_"]) < 1e-10
+    assert maxrel(np.array([np.diag(gp.L_) for gp in emu.gps]), g["Ldiag"]) < 1e-11
+    mean, cov = emu.predict(g["Xs"], return_cov=True, extra_std=g["extra_std"])
+    assert relerr(mean, g["mean"]) < 1e-11
+    assert maxrel(cov, g["cov"]) < 1e-10
+    mean0, cov0 = emu.predict(g["Xs"], return_cov=True, extra_std=0)      # scalar works (crashes in the reference under numpy>=2)
+    assert maxrel(cov0, g["cov0"]) < 1e-10
+    assert relerr(emu.predict(g["Xs"], return_cov=False), g["mean_only"]) < 1e-11
+    # pickling round trip drops and rebuilds the device state
+    import dill
+    emu2 = dill.loads(dill.dumps(emu))
+    m2, c2 = emu2.predict(g["Xs"], return_cov=True, extra_std=g["extra_std"])
+    assert np.array_equal(m2, mean) and np.array_equal(c2, cov)
+
+
+@pytest.mark.parametrize("name", ["pca_rbf", "pca_matern", "nopca_rbf"])
+def test_g3_hyperparameter_search_on_device(tmp_path, name):
+    """fit() drop-in: L-BFGS-B over the device LML reaches the reference optimum
+    (theta* to optimiser tolerance, LML* to 1e-7 relative; SURVEY §7 tier ii)."""
+    g = golden(f"g3_emulator_{name}.npz")
+    ktype, kw = VARIANTS[name]
+    emu = _make_emulator(tmp_path, g, kw)
+    emu.trainEmulator([True] * emu.nev, kernel_type=ktype)
+    assert relerr(emu.lml_, g["lml"]) < 1e-7
+    assert np.allclose(emu.thetas_, g["thetas"], atol=5e-3)
+    mean, cov = emu.predict(g["Xs"], return_cov=True, extra_std=g["extra_std"])
+    assert relerr(mean, g["mean"]) < 1e-4
+
+
+def _chain(tmp_path, g):
+    from gpbayestools_hic_amd import Chain, Emulator, synth
+    pf = str(tmp_path / "par.txt")
+    synth.write_parameter_file(pf, g["lo"], g["hi"])
+    emus = []
+    for tag in ("A", "B"):
+        tp = str(tmp_path / f"{tag}.pkl")
+        synth.write_training_pickle(tp, g["X"], g[f"Y_{tag}"], 0.01)
+        e = Emulator(training_set_path=tp, parameter_file=pf, npc=int(g[f"npc_{tag}"]))
+        e.trainEmulator([True] * e.nev, thetas=g[f"thetas_{tag}"])
+        emus.append(e)
+    ep = str(tmp_path / "exp.pkl")
+    synth.write_experiment_pickle(ep, g["yexp"], g["yerr"])
+    ch = Chain(mcmc_path=str(tmp_path / "mcmc" / "chain.pkl"), expdata_path=ep, model_parafile=pf)
+    ch.emuList = emus
+    return ch
+
+
+def test_g5_chain_log_probabilities(tmp_path):
+    g = golden("g5_chain.npz")
+    ch = _chain(tmp_path, g)
+    Xw, ins = g["Xw"], g["inside"]
+    assert np.array_equal(ch.expdata, g["expdata"]) and np.array_equal(ch.expdata_cov, g["expdata_cov"])
+    assert np.array_equal(ch.log_prior(Xw), g["log_prior"])
+    pm, pc = ch._predict(Xw[ins], extra_std=0.0)
+    assert relerr(pm, g["predict_mean"]) < 1e-11
+    assert maxrel(pc, g["predict_cov"]) < 1e-10
+    post = ch.log_posterior(Xw)
+    assert np.all(np.isneginf(post[~ins])) and np.array_equal(np.isneginf(post), ~ins)
+    assert relerr(post[ins], g["log_posterior"][ins]) < 1e-10
+    like = ch.log_likelihood(Xw)
+    assert relerr(like[ins], g["log_likelihood"][ins]) < 1e-10
+    likef = ch.log_likelihood(Xw, finite=True)
+    assert np.all(likef[~ins] == -1e300)
+    assert relerr(likef[ins], g["log_likelihood_finite"][ins]) < 1e-10
+    assert np.array_equal(ch.log_posterior(g["Xout"]), g["log_posterior_out"])      # all-outside batch
+    assert np.array_equal(ch.log_likelihood(g["Xout"], finite=True), g["log_likelihood_out_finite"])
+    assert relerr(ch.log_posterior(Xw[0]), g["log_posterior_1d"]) < 1e-10          # 1-D input is promoted
+    assert relerr(ch.log_likelihood_point_by_point(Xw)[ins], g["log_likelihood"][ins]) < 1e-10
+    # generic (foreign-emulator) path gives the same numbers through _predict + device MVN
+    class Foreign:
+        def __init__(self, e): self.e, self.nobs = e, e.nobs
+        def predict(self, X, return_cov=True, extra_std=0): return self.e.predict(X, return_cov, extra_std)
+    ch2 = _chain(tmp_path, g)
+    ch2.emuList = [Foreign(e) for e in ch2.emuList]
+    assert relerr(ch2.log_posterior(Xw)[ins], g["log_posterior"][ins]) < 1e-10
+
+
+def test_g6_mvn_loglike_function():
+    from gpbayestools_hic_amd import mvn_loglike
+    g = golden("g6_mvn.npz")
+    for M in (4, 16, 64):
+        assert abs(mvn_loglike(g[f"y_{M}"][0], g[f"cov_{M}"][0]) - g[f"ll_{M}"][0]) < 1e-11 * abs(g[f"ll_{M}"][0])
+    with pytest.raises(np.linalg.LinAlgError):
+        mvn_loglike(np.ones(4), -np.eye(4))
+
+
+def test_emulator_flag_validation(tmp_path):
+    g = golden("g3_emulator_pca_rbf.npz")
+    with pytest.raises(ValueError):
+        _make_emulator(tmp_path, g, dict(exp_and_cov_diagonal=True))      # needs logTrafo (src/emulator.py:59-60)

@@ -1,0 +1,173 @@
+"""
+GPU tier (MI355X): the HIP path through the C ABI against (a) the golden vectors captured from
+the reference and (b) the CPU oracle on seeded inputs.  Tolerances (fp64):
+kernels/L/alpha 1e-11, mean 1e-11, var/cov 1e-10 relative, LML 1e-10, log-likelihood 1e-10.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, relerr, maxrel
+
+pytestmark = pytest.mark.gpu
+
+KINDS = {"rbf": ("RBF", 0), "m15": ("Matern15", 1), "m25": ("Matern25", 2)}
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from gpbayestools_hic_amd import GPEngine
+    e = GPEngine(0)
+    yield e
+    e.close()
+
+
+# ---------------------------------------------------------------- MFMA tile engine
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(128, 128, 16), (256, 384, 64), (192, 130, 48), (64, 64, 64), (130, 66, 32)])
+def test_mfma_tile_gemm(eng, mode, shape):
+    """Asymmetric operands catch a transposed C/D fragment map (v_mfma_f64_16x16x4_f64)."""
+    M, N, K = shape
+    rng = np.random.default_rng(M * 7 + N * 3 + K + mode)
+    A = rng.standard_normal((M, K)); B = rng.standard_normal((K, N))
+    ref = A @ B
+    if mode == 0:
+        got = eng.test_gemm(A, B, 0)
+    elif mode == 1:
+        got = eng.test_gemm(A, np.ascontiguousarray(B.T), 1)
+    else:
+        got = eng.test_gemm(np.ascontiguousarray(A.T), B, 2)
+    assert maxrel(got, ref) < 1e-13
+
+
+def test_mfma_exact_integers(eng):
+    rng = np.random.default_rng(5)
+    A = rng.integers(-8, 9, (128, 32)).astype(float); B = rng.integers(-8, 9, (32, 128)).astype(float)
+    assert np.array_equal(eng.test_gemm(A, B, 0), A @ B)
+
+
+# ---------------------------------------------------------------- G1/G2: kernels, factor, LML, predict
+@pytest.mark.parametrize("name", list(KINDS))
+def test_g1_kernel_matrix_via_factor(eng, name):
+    g = golden("g1_kernels.npz")
+    X, Xs, th = g["X"], g["Xs"], g["theta"]
+    eng.set_data(X, np.zeros((1, X.shape[0])), KINDS[name][0], alpha=0.0)
+    eng.set_theta(th[None, :])
+    eng.factor()
+    L = eng.get("L")[0]
+    assert maxrel(L @ L.T, g[f"{name}_K"]) < 1e-13          # K = L L^T reproduces sklearn's K(X,X)
+    Linv = eng.get("Linv")[0]
+    assert np.max(np.abs(Linv @ L - np.eye(L.shape[0]))) < 1e-11
+    assert np.all(np.triu(Linv, 1) == 0.0)
+
+
+@pytest.mark.parametrize("name", list(KINDS))
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_g2_factor_lml_predict(eng, name, i):
+    g = golden("g2_gpr.npz")
+    X, z, Xs, th = g["X"], g["z"], g["Xs"], g["thetas"][i]
+    eng.set_data(X, z[None, :], KINDS[name][0], alpha=float(g["alpha"]))
+    val, grad = eng.lml(th[None, :])
+    assert abs(val[0] - g[f"{name}_{i}_lml"]) < 1e-10 * abs(g[f"{name}_{i}_lml"])
+    assert maxrel(grad[0], g[f"{name}_{i}_grad"]) < 1e-9
+    eng.set_theta(th[None, :]); eng.factor()
+    assert maxrel(eng.get("alpha")[0], g[f"{name}_{i}_alpha_"]) < 1e-10
+    if i == 0:
+        assert maxrel(eng.get("L")[0], g[f"{name}_{i}_L"]) < 1e-11
+    m, v = eng.predict(Xs)
+    assert maxrel(m[:, 0], g[f"{name}_{i}_mean"]) < 1e-11
+    assert relerr(v[:, 0], g[f"{name}_{i}_var"]) < 1e-10
+
+
+def test_not_positive_definite_is_reported(eng):
+    from gpbayestools_hic_amd.engine import NotPositiveDefinite
+    X = np.zeros((70, 3)); X[:, 0] = np.linspace(0, 1e-9, 70)    # (near-)duplicate points, no jitter
+    eng.set_data(X, np.zeros((2, 70)), "RBF", alpha=-1.02)
+    th = np.array([[0.0, 0, 0, 0, np.log(1e-2)]] * 2)
+    eng.set_theta(th)
+    with pytest.raises(NotPositiveDefinite):
+        eng.factor()
+    info = eng.factor(raise_on_fail=False)
+    assert np.all(info > 0)
+    val, grad = eng.lml(th)
+    assert np.all(np.isneginf(val)) and np.all(grad == 0.0)       # sk:_gpr.py:588-589
+
+
+# ---------------------------------------------------------------- G6: batched MVN
+@pytest.mark.parametrize("M", [4, 16, 64])
+def test_g6_mvn(eng, M):
+    g = golden("g6_mvn.npz")
+    got = eng.mvn_loglike(g[f"y_{M}"], g[f"cov_{M}"])
+    assert relerr(got, g[f"ll_{M}"]) < 1e-11
+    assert eng.last_not_pd == 0
+    bad = g[f"cov_{M}"].copy(); bad[1] = -np.eye(M)
+    got = eng.mvn_loglike(g[f"y_{M}"], bad)
+    assert np.isnan(got[1]) and eng.last_not_pd == 1 and np.isfinite(got[0])
+
+
+def test_mvn_large_block_global_slab(eng):
+    """M > 128 leaves LDS for an HBM slab (real analyses reach sum M ~ 540)."""
+    from oracle import gp_oracle as O
+    rng = np.random.default_rng(9)
+    M, W = 200, 5
+    B = rng.standard_normal((W, M, M))
+    cov = B @ B.transpose(0, 2, 1) / M + np.eye(M) * 0.1
+    y = rng.standard_normal((W, M))
+    ref = np.array([O.mvn_loglike(a, c) for a, c in zip(y, cov)])
+    assert relerr(eng.mvn_loglike(y, cov), ref) < 1e-10
+
+
+# ---------------------------------------------------------------- oracle parity at larger, ragged sizes
+@pytest.mark.parametrize("N,d,P,W,kind", [(200, 5, 3, 77, "RBF"), (333, 11, 2, 300, "Matern15"),
+                                          (1024, 15, 2, 513, "RBF"), (130, 20, 4, 1, "Matern25")])
+def test_predict_matches_oracle(eng, N, d, P, W, kind):
+    from oracle import gp_oracle as O
+    from gpbayestools_hic_amd import synth
+    kid = O.KIND_NAMES[kind]
+    rng = np.random.default_rng(N + d)
+    X = synth.lhs(N, d, seed=N)
+    Z = np.sin(X @ rng.standard_normal((d, P))).T + 0.05 * rng.standard_normal((P, N))
+    th = np.array([np.concatenate([[rng.uniform(-0.3, 0.5)], np.log(rng.uniform(0.5, 2.0, d)),
+                                   [np.log(rng.uniform(0.02, 0.1))]]) for _ in range(P)])
+    Xs = rng.random((W, d))
+    eng.set_data(X, Z, kind, alpha=0.1); eng.set_theta(th); eng.factor()
+    m, v = eng.predict(Xs)
+    for p in range(P):
+        L, a = O.gp_factor(X, Z[p], th[p], kid, 0.1)
+        mo, vo = O.gp_predict(Xs, X, th[p], L, a, kid)
+        assert maxrel(m[:, p], mo) < 1e-11
+        assert relerr(v[:, p], vo) < 1e-10
+    # empty batch and mean-only
+    assert eng.predict(np.zeros((0, d)))[0].shape == (0, P)
+    assert maxrel(eng.predict(Xs, return_var=False), m) == 0.0
+
+
+def test_predict_is_batch_independent(eng):
+    """A walker's numbers must not depend on how the batch is cut (bit-identical sharding)."""
+    from gpbayestools_hic_amd import synth
+    N, d, P = 300, 6, 2
+    rng = np.random.default_rng(3)
+    X = synth.lhs(N, d, seed=1)
+    Z = rng.standard_normal((P, N))
+    eng.set_data(X, Z, "RBF", 0.1); eng.set_theta(synth.fixed_theta(d, P)); eng.factor()
+    Xs = rng.random((400, d))
+    m, v = eng.predict(Xs)
+    for sl in (slice(0, 1), slice(5, 133), slice(200, 400), slice(399, 400)):
+        ms, vs = eng.predict(Xs[sl])
+        assert np.array_equal(ms, m[sl]) and np.array_equal(vs, v[sl])
+
+
+def test_lml_gradient_matches_oracle_and_finite_difference(eng):
+    from oracle import gp_oracle as O
+    from gpbayestools_hic_amd import synth
+    N, d, P = 190, 7, 3
+    rng = np.random.default_rng(17)
+    X = synth.lhs(N, d, seed=4)
+    Z = np.sin(X @ rng.standard_normal((d, P))).T
+    th = np.array([np.concatenate([[0.2 * p], np.log(rng.uniform(0.6, 1.8, d)), [np.log(0.05)]]) for p in range(P)])
+    for kind in ("RBF", "Matern15", "Matern25"):
+        eng.set_data(X, Z, kind, 0.1)
+        val, grad = eng.lml(th)
+        for p in range(P):
+            vo, go = O.lml(th[p], X, Z[p], O.KIND_NAMES[kind], 0.1, eval_gradient=True)
+            assert abs(val[p] - vo) < 1e-10 * abs(vo)
+            assert maxrel(grad[p], go) < 1e-9
