@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""
+bench.py — headline benchmark: MCMC steps/s x walkers (walker log-posterior evaluations per second)
+on BASELINE config 4 (2048 design points x 20 parameters x 64 observables, 10 GPs, 4096 walkers).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one emcee-equivalent stretch-move step of the whole ensemble = two half-ensemble
+log-posterior batches through the HIP engine (propose -> GP predict -> fused MVN -> accept), all
+resident in HBM.  With N > 1 the 4096 walkers are sharded over the ranks (strong scaling) and each
+log-probability batch ends in one RCCL all-gather.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6     # public MI355X fp64 matrix figure; the microarch guide lists no fp64 row
+
+
+def cpu_baseline(info, emu, nrows):
+    """The reference CPU path restated by the oracle in its *faithful* mode (full W x W predictive
+    covariance per GP as sklearn forms it, then per-row dpotrf/dpotrs), timed on the host cores for
+    ONE half-ensemble batch of `nrows` rows."""
+    from oracle import gp_oracle as O
+    from gpbayestools_hic_amd import synth
+    d, P = info["d"], info["P"]
+    kind = O.KIND_NAMES[{"RBF": "RBF", "Matern": "Matern", "Matern25": "Matern25"}[info["kernel_type"]]]
+    oe = O.OracleEmulator(info["X"], info["Y"], info["lo"], info["hi"], P, kind).fit(synth.fixed_theta(d, P))
+    Xw = synth.walkers(nrows, d, seed=synth.SEED + 7)
+    yexp = info["yexp"]
+    cexp = np.diag((0.05 * np.abs(yexp)) ** 2)
+    t0 = time.time()
+    lp = O.log_prob(Xw, info["lo"], info["hi"], lambda x, e: oe.predict(x, True, e, faithful=True), yexp, cexp,
+                    batched=False)
+    dt = time.time() - t0
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count()
+    return {"value": nrows / dt, "unit": "walker-evals/s", "cores": cores, "kind": "port",
+            "sample": f"one half-ensemble log_posterior call of {nrows} rows (faithful W x W covariance "
+                      f"per GP + per-row LAPACK MVN), {dt:.1f} s, numpy/scipy threaded BLAS"}, lp, Xw
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=4)
+    ap.add_argument("--walkers", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=None)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from gpbayestools_hic_amd import synth
+    from gpbayestools_hic_amd.dist import WalkerSharding, init_from_env
+    from gpbayestools_hic_amd.sampler import StretchSampler
+    from gpbayestools_hic_amd.workload import build_chain, flops_per_walker
+
+    rank, world, local = init_from_env()
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    chain, emu, info = build_chain(args.config, device=local)
+    N, d, M, P = info["N"], info["d"], info["M"], info["P"]
+    nwalkers = args.walkers or 2 * info["W"]
+    sharding = WalkerSharding() if world > 1 else None
+    sampler = StretchSampler(chain, nwalkers, seed=12345, sharding=sharding, device=local)
+    X0 = synth.walkers(nwalkers, d)
+    eng = emu._engine_ready()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sampler.run(X0, args.warmup, status=10 ** 9, store=False)
+    eng.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    sampler.run(None, args.steps, status=10 ** 9, store=False)      # continues from the resident state
+    barrier()
+    dt = time.perf_counter() - t0
+    launches, kms, units = eng.profile_read()
+    eng.profile(False)
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    acc = float(sampler.acceptance_fraction.mean())
+
+    if rank == 0:
+        value = nwalkers * args.steps / dt
+        alg_flops_per_launch = units / max(launches, 1) * float(N) * float(N)     # N^2 per (GP, walker): the trsm term
+        achieved = alg_flops_per_launch / (kms / max(launches, 1) * 1e-3) / 1e12 if launches else None
+        out = {
+            "metric": "MCMC steps/s x walkers (walker log-posterior evaluations per second, whole job)",
+            "value": value, "unit": "walker-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE config {args.config}: {N} design pts x {d} params x {M} observables, "
+                                   f"{P} GPs ({info['kernel']}), {nwalkers} walkers, stretch move, "
+                                   f"fixed hyper-parameters", "walkers": nwalkers,
+                       "parallelism": f"walker-shard x{world}" if world > 1 else "single GPU"},
+            "acceptance_fraction": acc,
+            "gflop_per_step_algorithmic": flops_per_walker(N, d, P, M, info["kernel"]) * nwalkers / 1e9,
+            "roofline": {"bound": "mfma", "kernel": "k_predict (V = L^-1 K*^T, fused sum of squares)",
+                         "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (achieved / FP64_MFMA_PEAK_TFLOPS) if achieved else None, "traffic": None,
+                         "launches": launches, "avg_launch_ms": kms / max(launches, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rows = args.cpu_rows or info["W"]
+            cb, lp_cpu, Xw = cpu_baseline(info, emu, rows)
+            lp_gpu = chain.log_posterior(Xw)
+            cb["max_rel_diff_vs_gpu"] = float(np.max(np.abs(lp_gpu - lp_cpu) / np.abs(lp_cpu)))
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -520,6 +520,32 @@ extern "C" int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K, cons
     return rc;
 }
 
+extern "C" int gpb_profile_enable(gpb_ctx* ctx, int on) {
+    if (!ctx) return GPB_E_ARG;
+    ctx->profile = on != 0;
+    return 0;
+}
+
+extern "C" int gpb_profile_read(gpb_ctx* ctx, int64_t* launches, double* total_ms, double* units) {
+    if (!ctx || !launches || !total_ms || !units) return GPB_E_ARG;
+    GPB_HIP(hipSetDevice(ctx->device));
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    double ms = 0.0;
+    for (auto& ev : ctx->prof_events) {
+        float t = 0.f;
+        GPB_HIP(hipEventElapsedTime(&t, ev.first, ev.second));
+        ms += t;
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    *launches = (int64_t)ctx->prof_events.size();
+    *total_ms = ms;
+    *units = ctx->prof_units;
+    ctx->prof_events.clear();
+    ctx->prof_units = 0.0;
+    return 0;
+}
+
 extern "C" int gpb_probe_fp64(gpb_ctx* ctx, int mode, double* tflops_out) {
     if (!ctx || !tflops_out || mode < 0 || mode > 2) return GPB_E_ARG;
     GPB_HIP(hipSetDevice(ctx->device));

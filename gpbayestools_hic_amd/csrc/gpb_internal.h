@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <utility>
+#include <vector>
 #include "../../include/gpbayes.h"
 
 namespace gpb {
@@ -71,6 +73,11 @@ struct gpb_ctx {
     double* mvn_ws = nullptr;      // global fallback for M > 128: [Wcap][M][M]
     int64_t mvn_ws_cap = 0;
     int* notpd = nullptr;          // device counter
+
+    // ---- profiling (HIP events around k_predict) ------------------------------------
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    double prof_units = 0.0;       // (GP, walker) pairs processed by the timed launches
 
     // ---- RCCL ---------------------------------------------------------------------
     void* comm = nullptr;

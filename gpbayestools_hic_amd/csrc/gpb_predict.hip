@@ -188,8 +188,19 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var)
     const int nI = (int)((ctx->Np + 127) / 128), nW = (int)(Wuse / 128);
     const int nchunk = (int)((ctx->Np + KX_CHUNK - 1) / KX_CHUNK);
     if (need_var) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (ctx->profile) {                    // live HIP-event timing of the dominant kernel (bench.py)
+            GPB_HIP(hipEventCreate(&e0));
+            GPB_HIP(hipEventCreate(&e1));
+            GPB_HIP(hipEventRecord(e0, ctx->stream));
+        }
         hipLaunchKernelGGL(k_predict, dim3((unsigned)((int64_t)ctx->P * nI * nW)), dim3(256), 0, ctx->stream,
                            ctx->Linv, ctx->KsT, ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW);
+        if (ctx->profile) {
+            GPB_HIP(hipEventRecord(e1, ctx->stream));
+            ctx->prof_events.push_back({e0, e1});
+            ctx->prof_units += (double)ctx->P * (double)W;
+        }
     }
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((Wuse + 255) / 256), (unsigned)ctx->P), dim3(256), 0, ctx->stream,
                        ctx->mpart, ctx->spart, ctx->amp, ctx->noise, ctx->mean_pc, ctx->var_pc, ctx->Wcap, Wuse,

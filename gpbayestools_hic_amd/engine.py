@@ -210,6 +210,15 @@ class GPEngine:
         self._ck(self.lib.gpb_test_gemm(self.h, M, N, K, nat.ptr(A), nat.ptr(B), nat.ptr(Cm), mode))
         return Cm
 
+    def profile(self, on=True):
+        self._ck(self.lib.gpb_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        """(launches, total_ms, gp_walker_pairs) of the timed k_predict launches since the last read."""
+        n, ms, u = C.c_int64(0), C.c_double(0.0), C.c_double(0.0)
+        self._ck(self.lib.gpb_profile_read(self.h, C.byref(n), C.byref(ms), C.byref(u)))
+        return n.value, ms.value, u.value
+
     def probe_fp64(self, mode):
         out = C.c_double(0.0)
         self._ck(self.lib.gpb_probe_fp64(self.h, int(mode), C.byref(out)))

@@ -86,8 +86,9 @@ class StretchSampler:
         eng = self._engine()
         lib, h = eng.lib, eng.h
         nw, d = self.nwalkers, self.ndim
-        self.pos.copy_(torch.as_tensor(np.ascontiguousarray(X0, dtype=np.float64)))
-        self._eval(self.pos, self.lp)
+        if X0 is not None:            # X0=None: continue from the resident state
+            self.pos.copy_(torch.as_tensor(np.ascontiguousarray(X0, dtype=np.float64)))
+            self._eval(self.pos, self.lp)
         if store:
             cd = torch.empty((nsteps, nw, d), dtype=torch.float64, device=self.device)
             ld = torch.empty((nsteps, nw), dtype=torch.float64, device=self.device)

@@ -166,6 +166,11 @@ int gpb_dist_finalize(gpb_ctx* ctx);
 /* C[M,N] = A[M,K] * B[K,N] through the f64 MFMA tile engine (all multiples of 128/16). */
 int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K,
                   const double* A_host, const double* B_host, double* C_host, int b_trans);
+/* HIP-event timing of the dominant kernel (k_predict: V = L^-1 K*^T + sum of squares) on the
+ * context's stream.  read: number of timed launches, their summed duration, and the (GP, walker)
+ * pairs they processed; resets the counters. */
+int gpb_profile_enable(gpb_ctx* ctx, int on);
+int gpb_profile_read(gpb_ctx* ctx, int64_t* launches, double* total_ms, double* units);
 /* issue-rate probe: returns measured TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64
  * (mode 0), v_fma_f64 (mode 1) or both co-issued (mode 2). */
 int gpb_probe_fp64(gpb_ctx* ctx, int mode, double* tflops_out);
