@@ -520,6 +520,12 @@ extern "C" int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K, cons
     return rc;
 }
 
+extern "C" int gpb_debug_force_generic_mvn(gpb_ctx* ctx, int on) {
+    if (!ctx) return GPB_E_ARG;
+    ctx->force_generic_mvn = on != 0;
+    return 0;
+}
+
 extern "C" int gpb_profile_enable(gpb_ctx* ctx, int on) {
     if (!ctx) return GPB_E_ARG;
     ctx->profile = on != 0;

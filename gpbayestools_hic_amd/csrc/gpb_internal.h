@@ -73,6 +73,7 @@ struct gpb_ctx {
     double* mvn_ws = nullptr;      // global fallback for M > 128: [Wcap][M][M]
     int64_t mvn_ws_cap = 0;
     int* notpd = nullptr;          // device counter
+    bool force_generic_mvn = false; // test hook: bypass the register-resident MVN fast path
 
     // ---- profiling (HIP events around k_predict) ------------------------------------
     bool profile = false;

@@ -115,6 +115,7 @@ __device__ __forceinline__ void chol_aug_finish(double* c, int ld, int M, double
 }
 
 // Generic batched mvn_loglike(y, cov) (src/mcmc.py:23-65) on caller-provided dY[W,M], cov[W,M,M].
+template <bool GWS>
 __global__ __launch_bounds__(256) void k_mvn(const double* __restrict__ dY, const double* __restrict__ cov, int M,
                                              double* __restrict__ gws, double* __restrict__ ll,
                                              int* __restrict__ notpd) {
@@ -122,7 +123,9 @@ __global__ __launch_bounds__(256) void k_mvn(const double* __restrict__ dY, cons
     const int64_t w = blockIdx.x;
     const int tid = threadIdx.x, ld = M + 1;
     double* dg = sm;
-    double* c = gws ? (gws + w * (int64_t)(M + 1) * ld) : (sm + M);
+    double* c;
+    if (GWS) c = gws + w * (int64_t)(M + 1) * ld;      // separate instantiations keep LDS accesses as ds_* ops
+    else     c = sm + M;
     const double* cw = cov + w * (int64_t)M * M;
     for (int e2 = tid; e2 < M * M; e2 += 256) {
         const int i = e2 / M, j = e2 % M;
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(256) void k_mvn(const double* __restrict__ dY, cons
 //        [ C   . ]            [ L    0 ]
 //        [ dY^T . ]   ->      [ v^T  . ]     with  L v = dY,
 // so that  -1/2 dY^T C^-1 dY - sum log L_ii = -1/2 |v|^2 - sum log L_ii   (src/mcmc.py:42-65).
+template <bool GWS>
 __global__ __launch_bounds__(256) void k_loglike(const double* __restrict__ mean_pc,
                                                  const double* __restrict__ var_pc, int64_t Wld, int P, int M,
                                                  int mode, const double* __restrict__ A,
@@ -154,7 +158,9 @@ __global__ __launch_bounds__(256) void k_loglike(const double* __restrict__ mean
     double* zv = sm + P;             // [P]
     double* mo = sm + 2 * P;         // [M]
     double* dg = sm + 2 * P + M;     // [M] pivots
-    double* c = gws ? (gws + w * (int64_t)(M + 1) * ld) : (sm + 2 * P + 2 * M);   // [(M+1)][ld]
+    double* c;                       // [(M+1)][ld]
+    if (GWS) c = gws + w * (int64_t)(M + 1) * ld;
+    else     c = sm + 2 * P + 2 * M;
     const bool no_pca = (mode == GPB_MODE_NO_PCA || mode == GPB_MODE_NO_PCA_EXPDIAG);
     const bool expdiag = (mode == GPB_MODE_EXPDIAG || mode == GPB_MODE_NO_PCA_EXPDIAG);
     for (int p = tid; p < P; p += 256) {
@@ -200,8 +206,104 @@ __global__ __launch_bounds__(256) void k_loglike(const double* __restrict__ mean
     chol_aug_finish(c, ld, M, dg, ll, w, accumulate, notpd);
 }
 
+// ------------------------------------------------------------------ fused block log-likelihood, register-resident
+// Fast path for the PCA mode with M <= 64 (every emulator of the reference's analyses): ONE WAVE per
+// walker, lane i owns row i of C = sum_p var_p A_p^T A_p + C_trunc + C_exp in VGPRs.  Right-looking
+// Cholesky fully unrolled: pivots and column entries are broadcast with v_readlane (-> SGPR operands of
+// the v_fma_f64), no LDS traffic and no barriers inside the factorisation; the forward solve L v = dY is
+// folded into the same sweep.  Rows >= M are padded with the identity (log 1 = 0, v = 0).
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <int MP>
+__global__ __launch_bounds__(256) void k_loglike_reg(const double* __restrict__ mean_pc,
+                                                     const double* __restrict__ var_pc, int64_t Wld, int64_t W, int P,
+                                                     int M, const double* __restrict__ A,
+                                                     const double* __restrict__ mu, const double* __restrict__ C0,
+                                                     const double* __restrict__ yexp, const double* __restrict__ Cexp,
+                                                     double* __restrict__ ll, int accumulate, int* __restrict__ notpd) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* sC = sm;                         // [64][MP+1]  C_trunc + C_exp, identity padded
+    double* sA = sm + 64 * (MP + 1);         // [P][64]     A, zero padded
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int e = tid; e < 64 * MP; e += 256) {
+        const int i = e / MP, k = e % MP;
+        double v = (i == k) ? 1.0 : 0.0;
+        if (i < M && k < M) v = C0[i * M + k] + Cexp[i * M + k];
+        sC[i * (MP + 1) + k] = v;
+    }
+    for (int e = tid; e < P * 64; e += 256) {
+        const int p = e >> 6, i = e & 63;
+        sA[e] = (i < M) ? A[p * M + i] : 0.0;
+    }
+    __syncthreads();
+    const int64_t w = (int64_t)blockIdx.x * 4 + wave;
+    if (w >= W) return;                      // wave-uniform
+    double a[MP];
+#pragma unroll
+    for (int k = 0; k < MP; ++k) a[k] = sC[lane * (MP + 1) + k];
+    double y = (lane < M) ? (mu[lane] - yexp[lane]) : 0.0;
+    for (int p = 0; p < P; ++p) {
+        const double zm = mean_pc[(int64_t)p * Wld + w];        // wave-uniform
+        const double zv = var_pc[(int64_t)p * Wld + w];         // extra_std == 0 on this path
+        const double ai = sA[p * 64 + lane];
+        y = fma(zm, ai, y);                                       // dY_i (src/emulator.py:559-561, src/mcmc.py:288)
+        const double t = zv * ai;
+#pragma unroll
+        for (int k = 0; k < MP; ++k) a[k] = fma(t, sA[p * 64 + k], a[k]);   // src/emulator.py:584-587
+    }
+    bool bad = false;
+    double q = 0.0, logdet = 0.0, prod = 1.0;
+#pragma unroll
+    for (int j = 0; j < MP; ++j) {
+        const double ajj = readlane_f64(a[j], j);
+        bad = bad || !(ajj > 0.0);
+        const double rinv = rsqrt(ajj);               // 1 / L_jj
+        const double lj = a[j] * rinv;                // column j of L for the lanes i > j
+        const double vj = readlane_f64(y, j) * rinv;  // forward solve: v_j
+        q = fma(vj, vj, q);
+        prod *= ajj;                                  // log det: sum log L_jj = 1/2 log prod a_jj, 4 pivots per log
+        if ((j & 3) == 3) { logdet += 0.5 * log(prod); prod = 1.0; }
+        y = fma(-lj, vj, y);                          // meaningful for lanes i > j
+#pragma unroll
+        for (int k = j + 1; k < MP; ++k) {
+            const double lkj = readlane_f64(lj, k);
+            a[k] = fma(-lj, lkj, a[k]);               // meaningful for lanes i >= k
+            if (((k - j) & 7) == 0) __builtin_amdgcn_sched_barrier(0);   // keep the SGPR broadcasts from piling up
+        }
+    }
+    if (lane == 0) {
+        double r = -0.5 * q - logdet;
+        if (bad) {
+            r = nan("");
+            atomicAdd(notpd, 1);
+        }
+        ll[w] = accumulate ? (ll[w] + r) : r;
+    }
+}
+
+template <int MP>
+static int launch_loglike_reg(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate) {
+    const size_t sh = (64 * (MP + 1) + (size_t)ctx->P * 64) * sizeof(double);
+    hipLaunchKernelGGL(k_loglike_reg<MP>, dim3((unsigned)((W + 3) / 4)), dim3(256), sh, ctx->stream, ctx->mean_pc,
+                       ctx->var_pc, ctx->Wcap, W, (int)ctx->P, (int)ctx->M, ctx->A, ctx->mu, ctx->C0, ctx->yexp,
+                       ctx->Cexp, ll_dev, accumulate ? 1 : 0, ctx->notpd);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate) {
     const int64_t M = ctx->M, P = ctx->P;
+    if (ctx->mode == GPB_MODE_PCA && M <= 64 && P <= 96 && !ctx->force_generic_mvn) {
+        if (M <= 8) return launch_loglike_reg<8>(ctx, W, ll_dev, accumulate);
+        if (M <= 16) return launch_loglike_reg<16>(ctx, W, ll_dev, accumulate);
+        if (M <= 32) return launch_loglike_reg<32>(ctx, W, ll_dev, accumulate);
+        return launch_loglike_reg<64>(ctx, W, ll_dev, accumulate);
+    }
     const size_t small = (2 * P + 2 * M) * sizeof(double);
     const size_t mat = (size_t)(M + 1) * (M + 1) * sizeof(double);
     double* gws = nullptr;
@@ -218,12 +320,17 @@ int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate) {
         sh = small;
     }
     if (sh > 64 * 1024) {
-        GPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loglike),
+        GPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loglike<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     }
-    hipLaunchKernelGGL(k_loglike, dim3((unsigned)W), dim3(256), sh, ctx->stream, ctx->mean_pc, ctx->var_pc,
-                       ctx->Wcap, (int)P, (int)M, ctx->mode, ctx->A, ctx->mu, ctx->scale, ctx->C0, ctx->yexp,
-                       ctx->Cexp, gws, ll_dev, accumulate ? 1 : 0, ctx->notpd);
+    if (gws)
+        hipLaunchKernelGGL(k_loglike<true>, dim3((unsigned)W), dim3(256), sh, ctx->stream, ctx->mean_pc, ctx->var_pc,
+                           ctx->Wcap, (int)P, (int)M, ctx->mode, ctx->A, ctx->mu, ctx->scale, ctx->C0, ctx->yexp,
+                           ctx->Cexp, gws, ll_dev, accumulate ? 1 : 0, ctx->notpd);
+    else
+        hipLaunchKernelGGL(k_loglike<false>, dim3((unsigned)W), dim3(256), sh, ctx->stream, ctx->mean_pc, ctx->var_pc,
+                           ctx->Wcap, (int)P, (int)M, ctx->mode, ctx->A, ctx->mu, ctx->scale, ctx->C0, ctx->yexp,
+                           ctx->Cexp, gws, ll_dev, accumulate ? 1 : 0, ctx->notpd);
     GPB_HIP(hipGetLastError());
     return 0;
 }
@@ -244,11 +351,15 @@ int launch_mvn(gpb_ctx* ctx, const double* dY_dev, const double* cov_dev, int64_
         sh = M * sizeof(double);
     }
     if (sh > 64 * 1024) {
-        GPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mvn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)sh));
+        GPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mvn<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     }
-    hipLaunchKernelGGL(k_mvn, dim3((unsigned)W), dim3(256), sh, ctx->stream, dY_dev, cov_dev, (int)M, gws, ll_dev,
-                       ctx->notpd);
+    if (gws)
+        hipLaunchKernelGGL(k_mvn<true>, dim3((unsigned)W), dim3(256), sh, ctx->stream, dY_dev, cov_dev, (int)M, gws,
+                           ll_dev, ctx->notpd);
+    else
+        hipLaunchKernelGGL(k_mvn<false>, dim3((unsigned)W), dim3(256), sh, ctx->stream, dY_dev, cov_dev, (int)M, gws,
+                           ll_dev, ctx->notpd);
     GPB_HIP(hipGetLastError());
     return 0;
 }

@@ -210,6 +210,10 @@ class GPEngine:
         self._ck(self.lib.gpb_test_gemm(self.h, M, N, K, nat.ptr(A), nat.ptr(B), nat.ptr(Cm), mode))
         return Cm
 
+    def force_generic_mvn(self, on=True):
+        """test hook: bypass the register-resident MVN fast path."""
+        self._ck(self.lib.gpb_debug_force_generic_mvn(self.h, 1 if on else 0))
+
     def profile(self, on=True):
         self._ck(self.lib.gpb_profile_enable(self.h, 1 if on else 0))
 

@@ -166,6 +166,9 @@ int gpb_dist_finalize(gpb_ctx* ctx);
 /* C[M,N] = A[M,K] * B[K,N] through the f64 MFMA tile engine (all multiples of 128/16). */
 int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K,
                   const double* A_host, const double* B_host, double* C_host, int b_trans);
+/* test hook: route gpb_loglike through the generic LDS/HBM Cholesky instead of the register-resident
+ * fast path (PCA mode, M <= 64) so that both implementations can be checked against each other. */
+int gpb_debug_force_generic_mvn(gpb_ctx* ctx, int on);
 /* HIP-event timing of the dominant kernel (k_predict: V = L^-1 K*^T + sum of squares) on the
  * context's stream.  read: number of timed launches, their summed duration, and the (GP, walker)
  * pairs they processed; resets the counters. */

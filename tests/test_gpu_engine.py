@@ -171,3 +171,35 @@ def test_lml_gradient_matches_oracle_and_finite_difference(eng):
             vo, go = O.lml(th[p], X, Z[p], O.KIND_NAMES[kind], 0.1, eval_gradient=True)
             assert abs(val[p] - vo) < 1e-10 * abs(vo)
             assert maxrel(grad[p], go) < 1e-9
+
+
+# ---------------------------------------------------------------- fused log-likelihood: both MVN kernels vs the oracle
+@pytest.mark.parametrize("M,P", [(4, 4), (13, 5), (32, 10), (64, 10), (64, 3), (100, 6)])
+def test_loglike_fast_and_generic_paths(eng, M, P):
+    from oracle import gp_oracle as O
+    from gpbayestools_hic_amd import synth
+    from gpbayestools_hic_amd.engine import MODE_PCA
+    N, d, W = 256, 6, 203
+    X = synth.lhs(N, d, seed=M)
+    Y = synth.observables(X, M, seed=M + 1)
+    oe = O.OracleEmulator(X, Y, np.zeros(d), np.ones(d), P).fit(synth.fixed_theta(d, P))
+    eng.set_data(X, oe.Z.T, "RBF", 0.1); eng.set_theta(oe.thetas); eng.factor()
+    eng.set_transform(MODE_PCA, oe.mu, A=oe.A, cov_trunc=oe.cov_trunc)
+    yexp = oe.predict(synth.truth_point(d)[None, :], return_cov=False)[0]
+    rng = np.random.default_rng(M * P)
+    Bm = rng.standard_normal((M, M)) * 0.01
+    cexp = np.diag((0.05 * np.abs(yexp)) ** 2) + Bm @ Bm.T       # full (non-diagonal) block is allowed
+    eng.set_likelihood(yexp, cexp)
+    Xw = synth.walkers(W, d, seed=5)
+    mY, mC = oe.predict(Xw, True, np.zeros(W))
+    ref = np.array([O.mvn_loglike(a, c) for a, c in zip(mY - yexp, mC + cexp)])
+    fast = eng.loglike(Xw).copy()
+    assert eng.last_not_pd == 0
+    eng.force_generic_mvn(True)
+    gen = eng.loglike(Xw).copy()
+    eng.force_generic_mvn(False)
+    assert relerr(fast, ref) < 1e-10
+    assert relerr(gen, ref) < 1e-10
+    # accumulate=True adds onto an existing vector (multi-emulator blocks)
+    acc = eng.loglike(Xw, out=np.full(W, 2.5), accumulate=True)
+    assert relerr(acc, fast + 2.5) < 1e-13
