@@ -553,7 +553,7 @@ extern "C" int gpb_profile_read(gpb_ctx* ctx, int64_t* launches, double* total_m
 }
 
 extern "C" int gpb_probe_fp64(gpb_ctx* ctx, int mode, double* tflops_out) {
-    if (!ctx || !tflops_out || mode < 0 || mode > 2) return GPB_E_ARG;
+    if (!ctx || !tflops_out || mode < 0 || mode > 4) return GPB_E_ARG;
     GPB_HIP(hipSetDevice(ctx->device));
     return launch_probe(ctx, mode, tflops_out);
 }

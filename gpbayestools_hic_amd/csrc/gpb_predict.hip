@@ -265,6 +265,26 @@ __global__ __launch_bounds__(256) void k_probe_mfma(double* out, int iters) {
     const d4 s = a0 + a1 + a2 + a3;
     if (s[0] + s[1] + s[2] + s[3] == 12345.678) out[0] = s[0];
 }
+// same loop, stamped with the shader clock (s_memtime) and the 100 MHz reference (s_memrealtime)
+__global__ __launch_bounds__(256) void k_probe_mfma_clk(double* out, int iters) {
+    d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+    const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, a3, 0, 0, 0);
+    }
+    const d4 s = a0 + a1 + a2 + a3;
+    asm volatile("" ::"v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]));
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[0] = (double)(t1 - t0);
+        out[1] = (double)(r1 - r0);
+    }
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678) out[2] = s[0];
+}
 __global__ __launch_bounds__(256) void k_probe_fma(double* out, int iters) {
     double a[8];
     const double x = 1.0 + threadIdx.x * 1e-12, y = 1e-9 * threadIdx.x;
@@ -322,6 +342,8 @@ int launch_probe(gpb_ctx* ctx, int mode, double* tflops) {
         if (mode == 0) {
             hipLaunchKernelGGL(k_probe_mfma, dim3(blocks), dim3(256), 0, ctx->stream, d_out, iters);
             flops = (double)blocks * 4 * iters * 4 * 2048.0;
+        } else if (mode == 3 || mode == 4) {
+            hipLaunchKernelGGL(k_probe_mfma_clk, dim3(mode == 3 ? 256 : 1024), dim3(256), 0, ctx->stream, d_out, iters);
         } else if (mode == 1) {
             hipLaunchKernelGGL(k_probe_fma, dim3(blocks), dim3(256), 0, ctx->stream, d_out, iters * 16);
             flops = (double)blocks * 256 * (double)iters * 16 * 8 * 2.0;
@@ -335,6 +357,12 @@ int launch_probe(gpb_ctx* ctx, int mode, double* tflops) {
     float ms = 0.f;
     GPB_HIP(hipEventElapsedTime(&ms, e0, e1));
     *tflops = flops / (ms * 1e-3) / 1e12;
+    if (mode == 3 || mode == 4) {
+        double h[2] = {0, 0};
+        GPB_HIP(hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost));
+        // mode 3: shader cycles per MFMA with one wave per SIMD; mode 4: clock (GHz) held with 4 waves per SIMD
+        *tflops = (mode == 3) ? h[0] / (4.0 * iters) : h[0] / h[1] * 0.1;
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(d_out);

@@ -175,7 +175,8 @@ int gpb_debug_force_generic_mvn(gpb_ctx* ctx, int on);
 int gpb_profile_enable(gpb_ctx* ctx, int on);
 int gpb_profile_read(gpb_ctx* ctx, int64_t* launches, double* total_ms, double* units);
 /* issue-rate probe: returns measured TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64
- * (mode 0), v_fma_f64 (mode 1) or both co-issued (mode 2). */
+ * (mode 0), v_fma_f64 (mode 1) or both co-issued (mode 2); mode 3: shader cycles per MFMA (one wave
+ * per SIMD); mode 4: shader clock in GHz held during the dense MFMA loop. */
 int gpb_probe_fp64(gpb_ctx* ctx, int mode, double* tflops_out);
 
 #ifdef __cplusplus

@@ -18,7 +18,8 @@ def main():
     N, d, M, P, W = c["N"], c["d"], c["M"], c["P"], c["W"]
     eng = GPEngine(0)
     out = {"mfma_f64_tflops": eng.probe_fp64(0), "valu_f64_tflops": eng.probe_fp64(1),
-           "both_tflops": eng.probe_fp64(2)}
+           "both_tflops": eng.probe_fp64(2), "mfma_f64_cycles_per_instr": eng.probe_fp64(3),
+           "clock_ghz_dense_mfma": eng.probe_fp64(4)}
     print(json.dumps(out), flush=True)
     X = synth.lhs(N, d)
     Z = np.random.default_rng(1).standard_normal((P, N))
