@@ -49,6 +49,7 @@ PROTOTYPES = {
     "gpb_dist_allgather": (C.c_int, [VP, VP, VP, c_i64]),
     "gpb_dist_finalize": (C.c_int, [VP]),
     "gpb_test_gemm": (C.c_int, [VP, c_i64, c_i64, c_i64, VP, VP, VP, C.c_int]),
+    "gpb_debug_force_tile": (C.c_int, [VP, C.c_int, c_i64]),
     "gpb_debug_force_generic_mvn": (C.c_int, [VP, C.c_int]),
     "gpb_profile_enable": (C.c_int, [VP, C.c_int]),
     "gpb_profile_read": (C.c_int, [VP, VP, VP, VP]),

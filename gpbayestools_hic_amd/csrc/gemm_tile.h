@@ -2,14 +2,16 @@
 //   predict (V = L^-1 K*^T, fused sum of squares), Cholesky trailing update (SYRK),
 //   triangular inverse (recursive block doubling) and K^-1 = L^-T L^-1 for the LML gradient.
 //
-// Block tile 128x128, K-step 16, 256 threads = 4 waves (2x2), wave tile 64x64 =
-// 4x4 v_mfma_f64_16x16x4_f64 tiles (16 accumulators of 4 f64 = 128 VGPRs).
-// Operand tiles are staged in LDS k-major ([k][m], [k][n]) with a 16-double row pad so
-// that the per-lane fragment reads (lane l: row k=l>>4, 16 consecutive m) are
-// bank-conflict free for ds_read_b64; global loads are register-prefetched one K-step
-// ahead.  fp64 MFMA is slow per byte (2048 flop per 1 KiB of fragments), so LDS and L2
-// traffic are far from their limits; the design goal is only to keep the matrix pipe
-// issuing back to back.
+// Block tile T x T (T = 128 or 64), K-step 16, 256 threads = 4 waves (2x2), wave tile T/2 x T/2 =
+// (T/32)^2 v_mfma_f64_16x16x4_f64 tiles (T=128: 16 accumulators of 4 f64 = 128 VGPRs).
+// Operand tiles are staged in LDS k-major ([k][m], [k][n]) with a 16-double row pad so that the
+// per-lane fragment reads (lane l: row k=l>>4, 16 consecutive m) are bank-conflict free for
+// ds_read_b64; global loads are register-prefetched one K-step ahead.
+// Measured on MI355X (profiles/r01_mfma_f64_issue_rate.txt): v_mfma_f64_16x16x4_f64 issues about
+// once per 100 cycles per SIMD (~50 TFLOP/s chip-wide at 2.4 GHz), i.e. 2048 flop per 1 KiB of
+// fragments, so LDS and L2 traffic are far from their limits; the design goal is only to keep the
+// matrix pipe issuing back to back.  T = 64 exists for small walker batches (multi-GPU shards),
+// where 128-wide tiles leave CUs idle behind the heaviest triangular row block.
 //
 // v_mfma_f64_16x16x4_f64 lane maps (cdna_hip_programming.md §3):
 //   A: lane l holds A[i=l&15][k=l>>4];  B: lane l holds B[k=l>>4][j=l&15];
@@ -22,132 +24,149 @@ namespace gpb {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int LDS_LD = 144;            // 128 + 16 pad: row stride = 288 dwords = 32 (mod 64) banks
+constexpr int BK = 16;
 constexpr int GEMM_THREADS = 256;
 
+template <int T>
 struct __attribute__((aligned(16))) TileLds {
-    double As[BK][LDS_LD];
-    double Bs[BK][LDS_LD];
-};                                      // 36,864 B -> up to 4 workgroups per CU by LDS
+    static constexpr int LD = T + 16;   // row stride = 2*(T+16) dwords = 32 (mod 64) banks
+    double As[BK][LD];
+    double Bs[BK][LD];
+};                                       // T=128: 36,864 B; T=64: 20,480 B
 
-struct Frag { double2 r[4]; };
+template <int T>
+struct Frag { double2 r[T / 32]; };
+template <int T>
+struct Acc { d4 v[T / 32][T / 32]; };
 
-// logical T[k][x] = G[(k0+k)*ld + x0+x]   (k<16, x<128); rows are contiguous in x.
-__device__ __forceinline__ void gload_direct(const double* __restrict__ G, int64_t ld, int64_t k0,
-                                             int64_t x0, int x_ext, Frag& f, int tid) {
-    const int row = tid >> 6, col = (tid & 63) * 2;
+// logical tile[k][x] = G[(k0+k)*ld + x0+x]   (k<16, x<T); rows are contiguous in x.
+template <int T>
+__device__ __forceinline__ void gload_direct(const double* __restrict__ G, int64_t ld, int64_t k0, int64_t x0,
+                                             int x_ext, Frag<T>& f, int tid) {
+    constexpr int TPR = T / 2;                 // threads per row (2 doubles each)
+    constexpr int RPP = 256 / TPR;             // rows per pass
+    const int row = tid / TPR, col = (tid % TPR) * 2;
     const bool ok = col < x_ext;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (ok) f.r[j] = *reinterpret_cast<const double2*>(G + (k0 + row + 4 * j) * ld + x0 + col);
+    for (int j = 0; j < T / 32; ++j) {
+        if (ok) f.r[j] = *reinterpret_cast<const double2*>(G + (k0 + row + RPP * j) * ld + x0 + col);
         else    f.r[j] = make_double2(0.0, 0.0);
     }
 }
-__device__ __forceinline__ void lstore_direct(double (*S)[LDS_LD], const Frag& f, int tid) {
-    const int row = tid >> 6, col = (tid & 63) * 2;
+template <int T>
+__device__ __forceinline__ void lstore_direct(double (*S)[T + 16], const Frag<T>& f, int tid) {
+    constexpr int TPR = T / 2, RPP = 256 / TPR;
+    const int row = tid / TPR, col = (tid % TPR) * 2;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<double2*>(&S[row + 4 * j][col]) = f.r[j];
+    for (int j = 0; j < T / 32; ++j) *reinterpret_cast<double2*>(&S[row + RPP * j][col]) = f.r[j];
 }
-// logical T[k][x] = G[(x0+x)*ld + k0+k]   (rows of G are contiguous in k): transpose on store.
-__device__ __forceinline__ void gload_trans(const double* __restrict__ G, int64_t ld, int64_t k0,
-                                            int64_t x0, int x_ext, Frag& f, int tid) {
-    const int x = tid >> 1, kh = (tid & 1) * 8;
+// logical tile[k][x] = G[(x0+x)*ld + k0+k]   (rows of G are contiguous in k): transpose on store.
+template <int T>
+__device__ __forceinline__ void gload_trans(const double* __restrict__ G, int64_t ld, int64_t k0, int64_t x0,
+                                            int x_ext, Frag<T>& f, int tid) {
+    constexpr int TPX = 256 / T;               // threads per x row: 2 (T=128) or 4 (T=64)
+    constexpr int KPT = BK / TPX;              // k's per thread: 8 or 4
+    const int x = tid / TPX, kh = (tid % TPX) * KPT;
     const bool ok = x < x_ext;
     const double* p = G + (x0 + x) * ld + k0 + kh;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < T / 32; ++j) {
         if (ok) f.r[j] = *reinterpret_cast<const double2*>(p + 2 * j);
         else    f.r[j] = make_double2(0.0, 0.0);
     }
 }
-__device__ __forceinline__ void lstore_trans(double (*S)[LDS_LD], const Frag& f, int tid) {
-    const int x = tid >> 1, kh = (tid & 1) * 8;
+template <int T>
+__device__ __forceinline__ void lstore_trans(double (*S)[T + 16], const Frag<T>& f, int tid) {
+    constexpr int TPX = 256 / T, KPT = BK / TPX;
+    const int x = tid / TPX, kh = (tid % TPX) * KPT;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < T / 32; ++j) {
         S[kh + 2 * j][x] = f.r[j].x;
         S[kh + 2 * j + 1][x] = f.r[j].y;
     }
 }
 
-__device__ __forceinline__ void acc_zero(d4 (&acc)[4][4]) {
+template <int T>
+__device__ __forceinline__ void acc_zero(Acc<T>& acc) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < T / 32; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < T / 32; ++j) acc.v[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 }
 
-__device__ __forceinline__ void tile_mma(const TileLds& L, d4 (&acc)[4][4], int lane, int m0, int n0) {
+template <int T>
+__device__ __forceinline__ void tile_mma(const TileLds<T>& L, Acc<T>& acc, int lane, int m0, int n0) {
+    constexpr int NI = T / 32;
     const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
-        double a[4], b[4];
+        double a[NI], b[NI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = L.As[kk + lk][m0 + 16 * i + lr];
+        for (int i = 0; i < NI; ++i) a[i] = L.As[kk + lk][m0 + 16 * i + lr];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = L.Bs[kk + lk][n0 + 16 * j + lr];
+        for (int j = 0; j < NI; ++j) b[j] = L.Bs[kk + lk][n0 + 16 * j + lr];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NI; ++j)
+                acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc.v[i][j], 0, 0, 0);
     }
 }
 
 // acc += A[m_base.., k] * B[k, n_base..] for k in [k_begin, k_end), both multiples of BK.
 //   A_TRANS=false: A[m][k] = Ag[(m_base+m)*lda + k]       A_TRANS=true: A[m][k] = Ag[k*lda + m_base+m]
 //   B_TRANS=false: B[k][n] = Bg[k*ldb + n_base+n]         B_TRANS=true: B[k][n] = Bg[(n_base+n)*ldb + k]
-// m_ext / n_ext (even, <=128) bound the valid rows / columns of this tile; the rest reads as 0.
-template <bool A_TRANS, bool B_TRANS>
+// m_ext / n_ext (even, <= T) bound the valid rows / columns of this tile; the rest reads as 0.
+template <int T, bool A_TRANS, bool B_TRANS>
 __device__ __forceinline__ void gemm_tile_loop(const double* __restrict__ Ag, int64_t lda,
-                                               const double* __restrict__ Bg, int64_t ldb,
-                                               int64_t m_base, int64_t n_base, int m_ext, int n_ext,
-                                               int64_t k_begin, int64_t k_end, TileLds& L,
-                                               d4 (&acc)[4][4]) {
+                                               const double* __restrict__ Bg, int64_t ldb, int64_t m_base,
+                                               int64_t n_base, int m_ext, int n_ext, int64_t k_begin, int64_t k_end,
+                                               TileLds<T>& L, Acc<T>& acc) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int m0 = (wave >> 1) * 64, n0 = (wave & 1) * 64;
-    Frag fa, fb;
+    const int m0 = (wave >> 1) * (T / 2), n0 = (wave & 1) * (T / 2);
+    Frag<T> fa, fb;
     if (k_begin < k_end) {
-        if (A_TRANS) gload_direct(Ag, lda, k_begin, m_base, m_ext, fa, tid);
-        else         gload_trans(Ag, lda, k_begin, m_base, m_ext, fa, tid);
-        if (B_TRANS) gload_trans(Bg, ldb, k_begin, n_base, n_ext, fb, tid);
-        else         gload_direct(Bg, ldb, k_begin, n_base, n_ext, fb, tid);
+        if (A_TRANS) gload_direct<T>(Ag, lda, k_begin, m_base, m_ext, fa, tid);
+        else         gload_trans<T>(Ag, lda, k_begin, m_base, m_ext, fa, tid);
+        if (B_TRANS) gload_trans<T>(Bg, ldb, k_begin, n_base, n_ext, fb, tid);
+        else         gload_direct<T>(Bg, ldb, k_begin, n_base, n_ext, fb, tid);
     }
     for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
         __syncthreads();
-        if (A_TRANS) lstore_direct(L.As, fa, tid); else lstore_trans(L.As, fa, tid);
-        if (B_TRANS) lstore_trans(L.Bs, fb, tid);  else lstore_direct(L.Bs, fb, tid);
+        if (A_TRANS) lstore_direct<T>(L.As, fa, tid); else lstore_trans<T>(L.As, fa, tid);
+        if (B_TRANS) lstore_trans<T>(L.Bs, fb, tid);  else lstore_direct<T>(L.Bs, fb, tid);
         __syncthreads();
         const int64_t kn = k0 + BK;
         if (kn < k_end) {
-            if (A_TRANS) gload_direct(Ag, lda, kn, m_base, m_ext, fa, tid);
-            else         gload_trans(Ag, lda, kn, m_base, m_ext, fa, tid);
-            if (B_TRANS) gload_trans(Bg, ldb, kn, n_base, n_ext, fb, tid);
-            else         gload_direct(Bg, ldb, kn, n_base, n_ext, fb, tid);
+            if (A_TRANS) gload_direct<T>(Ag, lda, kn, m_base, m_ext, fa, tid);
+            else         gload_trans<T>(Ag, lda, kn, m_base, m_ext, fa, tid);
+            if (B_TRANS) gload_trans<T>(Bg, ldb, kn, n_base, n_ext, fb, tid);
+            else         gload_direct<T>(Bg, ldb, kn, n_base, n_ext, fb, tid);
         }
-        tile_mma(L, acc, lane, m0, n0);
+        tile_mma<T>(L, acc, lane, m0, n0);
     }
 }
 
-// C[(m_base+row)*ldc + n_base+col] = beta*C + scale*acc   for row<m_ext, col<n_ext
-__device__ __forceinline__ void tile_store(double* __restrict__ C, int64_t ldc, int64_t m_base,
-                                           int64_t n_base, int m_ext, int n_ext, double scale,
-                                           bool accumulate, const d4 (&acc)[4][4]) {
+// C[(m_base+row)*ldc + n_base+col] = (accumulate ? C : 0) + scale*acc   for row<m_ext, col<n_ext
+template <int T>
+__device__ __forceinline__ void tile_store(double* __restrict__ C, int64_t ldc, int64_t m_base, int64_t n_base,
+                                           int m_ext, int n_ext, double scale, bool accumulate, const Acc<T>& acc) {
+    constexpr int NI = T / 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = (wave >> 1) * 64, n0 = (wave & 1) * 64;
+    const int m0 = (wave >> 1) * (T / 2), n0 = (wave & 1) * (T / 2);
     const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NI; ++j) {
             const int col = n0 + 16 * j + lr;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + 16 * i + lk + 4 * r;
                 if (row < m_ext && col < n_ext) {
                     double* p = C + (m_base + row) * ldc + n_base + col;
-                    const double v = scale * acc[i][j][r];
+                    const double v = scale * acc.v[i][j][r];
                     *p = accumulate ? (*p + v) : v;
                 }
             }

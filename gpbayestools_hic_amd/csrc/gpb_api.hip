@@ -520,6 +520,14 @@ extern "C" int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K, cons
     return rc;
 }
 
+extern "C" int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles) {
+    if (!ctx || (tile != 0 && tile != 64 && tile != 128)) return GPB_E_ARG;
+    ctx->force_tile = tile;
+    if (switch_tiles > 0) ctx->tile_switch = switch_tiles;
+    if (switch_tiles <= -10) ctx->force_xcd = (int)(-switch_tiles - 11);   // -10 -> auto(-1), -11 -> 0, -12 -> 1
+    return 0;
+}
+
 extern "C" int gpb_debug_force_generic_mvn(gpb_ctx* ctx, int on) {
     if (!ctx) return GPB_E_ARG;
     ctx->force_generic_mvn = on != 0;

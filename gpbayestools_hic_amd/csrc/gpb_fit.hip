@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ K, cons
 
 // Trailing update (SYRK): A[r0+.., r0+..] -= Lp Lp^T on the lower 128x128 tiles, K = 64 (MFMA).
 __global__ __launch_bounds__(256, 2) void k_syrk(double* __restrict__ K, int64_t Np, int64_t kb) {
-    __shared__ TileLds lds;
+    __shared__ TileLds<128> lds;
     const int p = blockIdx.y;
     // linear lower-triangle tile index -> (ti, tj), tj <= ti
     const int t = blockIdx.x;
@@ -229,10 +229,10 @@ __global__ __launch_bounds__(256, 2) void k_syrk(double* __restrict__ K, int64_t
     const int m_ext = (int)imin64(128, nt - mb), n_ext = (int)imin64(128, nt - nb);
     double* Kp = K + (int64_t)p * Np * Np;
     const double* Pn = Kp + r0 * Np + c0;   // panel: rows r0.., cols c0..c0+63
-    d4 acc[4][4];
-    acc_zero(acc);
-    gemm_tile_loop<false, true>(Pn, Np, Pn, Np, mb, nb, m_ext, n_ext, 0, 64, lds, acc);
-    tile_store(Kp + r0 * Np + r0, Np, mb, nb, m_ext, n_ext, -1.0, true, acc);
+    Acc<128> acc;
+    acc_zero<128>(acc);
+    gemm_tile_loop<128,false, true>(Pn, Np, Pn, Np, mb, nb, m_ext, n_ext, 0, 64, lds, acc);
+    tile_store<128>(Kp + r0 * Np + r0, Np, mb, nb, m_ext, n_ext, -1.0, true, acc);
 }
 
 int launch_potrf(gpb_ctx* ctx) {
@@ -264,7 +264,7 @@ template <int PHASE>
 __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict__ L, double* __restrict__ Linv,
                                                         double* __restrict__ T, int64_t Np, int64_t hs,
                                                         int ngroups) {
-    __shared__ TileLds lds;
+    __shared__ TileLds<128> lds;
     const int p = blockIdx.z / ngroups, g = blockIdx.z % ngroups;
     const int64_t c0 = (int64_t)g * 2 * hs, r0 = c0 + hs;
     const int64_t n2 = imin64(hs, Np - r0);
@@ -272,19 +272,19 @@ __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict
     if (n2 <= 0 || mb >= n2 || nb >= hs) return;
     const int m_ext = (int)imin64(128, n2 - mb), n_ext = (int)imin64(128, hs - nb);
     const int64_t off = (int64_t)p * Np * Np;
-    d4 acc[4][4];
-    acc_zero(acc);
+    Acc<128> acc;
+    acc_zero<128>(acc);
     if (PHASE == 1) {
         // T[r0+m][c0+n] = sum_{k>=n} L[r0+m][c0+k] * Linv[c0+k][c0+n]
-        gemm_tile_loop<false, false>(L + off + r0 * Np + c0, Np, Linv + off + c0 * Np + c0, Np, mb, nb, m_ext,
+        gemm_tile_loop<128,false, false>(L + off + r0 * Np + c0, Np, Linv + off + c0 * Np + c0, Np, mb, nb, m_ext,
                                      n_ext, nb, hs, lds, acc);
-        tile_store(T + off + r0 * Np + c0, Np, mb, nb, m_ext, n_ext, 1.0, false, acc);
+        tile_store<128>(T + off + r0 * Np + c0, Np, mb, nb, m_ext, n_ext, 1.0, false, acc);
     } else {
         // Linv[r0+m][c0+n] = -sum_{k<=m} Linv[r0+m][r0+k] * T[r0+k][c0+n]
         const int64_t k_end = imin64(mb + 128, n2);
-        gemm_tile_loop<false, false>(Linv + off + r0 * Np + r0, Np, T + off + r0 * Np + c0, Np, mb, nb, m_ext,
+        gemm_tile_loop<128,false, false>(Linv + off + r0 * Np + r0, Np, T + off + r0 * Np + c0, Np, mb, nb, m_ext,
                                      n_ext, 0, k_end, lds, acc);
-        tile_store(Linv + off + r0 * Np + c0, Np, mb, nb, m_ext, n_ext, -1.0, false, acc);
+        tile_store<128>(Linv + off + r0 * Np + c0, Np, mb, nb, m_ext, n_ext, -1.0, false, acc);
     }
 }
 
@@ -378,7 +378,7 @@ int launch_lml_value(gpb_ctx* ctx) {
 // K^-1 = L^-T L^-1 on the lower 128x128 tiles (TN MFMA GEMM, k >= m_base), into T.
 __global__ __launch_bounds__(256, 2) void k_kinv(const double* __restrict__ Linv, double* __restrict__ T,
                                                  int64_t Np) {
-    __shared__ TileLds lds;
+    __shared__ TileLds<128> lds;
     const int p = blockIdx.y, t = blockIdx.x;
     int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
@@ -387,10 +387,10 @@ __global__ __launch_bounds__(256, 2) void k_kinv(const double* __restrict__ Linv
     const int64_t mb = (int64_t)ti * 128, nb = (int64_t)tj * 128;
     const int m_ext = (int)imin64(128, Np - mb), n_ext = (int)imin64(128, Np - nb);
     const double* Lp = Linv + (int64_t)p * Np * Np;
-    d4 acc[4][4];
-    acc_zero(acc);
-    gemm_tile_loop<true, false>(Lp, Np, Lp, Np, mb, nb, m_ext, n_ext, mb, Np, lds, acc);
-    tile_store(T + (int64_t)p * Np * Np, Np, mb, nb, m_ext, n_ext, 1.0, false, acc);
+    Acc<128> acc;
+    acc_zero<128>(acc);
+    gemm_tile_loop<128,true, false>(Lp, Np, Lp, Np, mb, nb, m_ext, n_ext, mb, Np, lds, acc);
+    tile_store<128>(T + (int64_t)p * Np * Np, Np, mb, nb, m_ext, n_ext, 1.0, false, acc);
 }
 
 // grad_t = 1/2 sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta_t  (sk:_gpr.py:625-647), never

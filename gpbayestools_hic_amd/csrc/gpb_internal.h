@@ -54,7 +54,7 @@ struct gpb_ctx {
     double* estd = nullptr;        // [Wcap]
     double* KsT = nullptr;         // [P][Np][Wcap]
     double* mpart = nullptr;       // [Np/KX_CHUNK][P][Wcap]
-    double* spart = nullptr;       // [Np/128 (ceil)][P][Wcap]
+    double* spart = nullptr;       // [Np/64][P][Wcap]  sum-of-squares partials per 64-row block
     double* mean_pc = nullptr;     // [P][Wcap]
     double* var_pc = nullptr;      // [P][Wcap]
     double* out_stage = nullptr;   // staging for host outputs
@@ -73,6 +73,9 @@ struct gpb_ctx {
     double* mvn_ws = nullptr;      // global fallback for M > 128: [Wcap][M][M]
     int64_t mvn_ws_cap = 0;
     int* notpd = nullptr;          // device counter
+    int force_tile = 0;             // test hook: 0 = auto, 64 / 128 = force the k_predict tile size
+    int force_xcd = -1;             // tuning hook: -1 auto, 0 / 1 = k_predict XCD affinity by walker tile / row block
+    int64_t tile_switch = 1280;     // use 128x128 tiles when at least this many of them exist
     bool force_generic_mvn = false; // test hook: bypass the register-resident MVN fast path
 
     // ---- profiling (HIP events around k_predict) ------------------------------------

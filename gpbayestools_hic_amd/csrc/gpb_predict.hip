@@ -76,52 +76,81 @@ __global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, i
         mpart[((int64_t)chunk * P + p) * Wld + w] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
-// 1-D grid of P * nI * nW 128x128 tiles, heaviest row blocks first; consecutive blocks differ in
-// the walker tile so that the 8 XCDs (round-robin dispatch) each keep their own K*^T columns in L2.
+// 1-D grid of P * nI * nW tiles (T x T, T = 128 or 64), heaviest row blocks first; consecutive blocks
+// differ in the walker tile so that the 8 XCDs (round-robin dispatch) each keep their own K*^T columns in
+// L2.  The fused epilogue reduces V^2 over rows in a tree that depends only on the row index — 32-row
+// chains, lane groups, then the two halves of each 64-row block — so both tile sizes, and therefore any
+// sharding of the walkers, give bit-identical sums.  spart is indexed by 64-row block.
+template <int T>
 __global__ __launch_bounds__(256, 2) void k_predict(const double* __restrict__ Linv, const double* __restrict__ KsT,
                                                     double* __restrict__ spart, int64_t Np, int64_t Wld, int P,
-                                                    int nI, int nW) {
-    __shared__ TileLds lds;
+                                                    int nI, int nW, int xcd_rows) {
+    __shared__ TileLds<T> lds;
+    constexpr int NI = T / 32;
+    // Tile order: heaviest row blocks of every GP first (LPT).  XCD affinity (blocks b and b+8 share an
+    // XCD's L2 under round-robin dispatch; speed only, never correctness):
+    //   xcd_rows = 1 (small W: L^-1 is the big operand): the nW walker tiles of one (row block, GP) group
+    //                run on ONE XCD, so each L^-1 row block is fetched from HBM once;
+    //   xcd_rows = 0 (large W: K*^T is the big operand): b % 8 == wt % 8, each XCD keeps its own K*^T columns.
     const int b = blockIdx.x;
-    const int p = b / (nI * nW);
-    const int rem = b - p * nI * nW;
-    const int ib = nI - 1 - rem / nW;
-    const int wt = rem % nW;
-    const int64_t mb = (int64_t)ib * 128, nb = (int64_t)wt * 128;
-    const int m_ext = (int)imin64(128, Np - mb);
-    const int64_t k_end = imin64(mb + 128, Np);
-    d4 acc[4][4];
-    acc_zero(acc);
-    gemm_tile_loop<false, false>(Linv + (int64_t)p * Np * Np, Np, KsT + (int64_t)p * Np * Wld, Wld, mb, nb, m_ext,
-                                 128, 0, k_end, lds, acc);
-    // fused epilogue: column sums of squares over this tile's rows
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double s[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        double v = 0.0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v = fma(acc[i][j][r], acc[i][j][r], v);
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        s[j] = v;
+    int g, wt;
+    if (xcd_rows) {
+        const int q = b >> 3;
+        g = (q / nW) * 8 + (b & 7);
+        wt = q % nW;
+        if (g >= nI * P) return;             // whole workgroup exits together (grid padded to 8 groups)
+    } else {
+        g = b / nW;
+        wt = b - g * nW;
     }
-    __syncthreads();                       // all waves are done reading the operand tiles
-    double* red = &lds.As[0][0];           // [2 row-halves][128 columns]
+    const int ib = nI - 1 - g / P;
+    const int p = g - (g / P) * P;
+    const int64_t mb = (int64_t)ib * T, nb = (int64_t)wt * T;
+    const int m_ext = (int)imin64(T, Np - mb);
+    const int64_t k_end = imin64(mb + T, Np);
+    Acc<T> acc;
+    acc_zero<T>(acc);
+    gemm_tile_loop<T, false, false>(Linv + (int64_t)p * Np * Np, Np, KsT + (int64_t)p * Np * Wld, Wld, mb, nb, m_ext,
+                                    T, 0, k_end, lds, acc);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    double s[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        double h[NI / 2];                       // one chain per 32 rows: m-tiles (2g, 2g+1)
+#pragma unroll
+        for (int g = 0; g < NI / 2; ++g) {
+            double v = 0.0;
+#pragma unroll
+            for (int i = 2 * g; i < 2 * g + 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v = fma(acc.v[i][j][r], acc.v[i][j][r], v);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            h[g] = v;
+        }
+        s[j] = (NI == 4) ? (h[0] + h[NI / 2 - 1]) : h[0];     // T=128: rows 0-31 + rows 32-63 of the wave's block
+    }
+    __syncthreads();                            // all waves are done reading the operand tiles
+    double* red = &lds.As[0][0];                // [2 wave rows][T columns]
     if (lane < 16) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) red[(wave >> 1) * 128 + (wave & 1) * 64 + 16 * j + lane] = s[j];
+        for (int j = 0; j < NI; ++j) red[wm * T + wn * (T / 2) + 16 * j + lane] = s[j];
     }
     __syncthreads();
-    if (tid < 128) spart[((int64_t)ib * P + p) * Wld + nb + tid] = red[tid] + red[128 + tid];
+    if (T == 128) {                             // each wave row is one 64-row block
+        const int half = tid >> 7, col = tid & 127;
+        const int64_t blk = 2 * (int64_t)ib + half;
+        if (blk * 64 < Np) spart[(blk * P + p) * Wld + nb + col] = red[half * T + col];
+    } else {                                    // the two wave rows are the halves of one 64-row block
+        if (tid < T) spart[((int64_t)ib * P + p) * Wld + nb + tid] = red[tid] + red[T + tid];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ mpart, const double* __restrict__ spart,
                                                   const double* __restrict__ amp, const double* __restrict__ noise,
                                                   double* __restrict__ mean_pc, double* __restrict__ var_pc,
-                                                  int64_t Wld, int64_t Wuse, int P, int nchunk, int nI, int need_var) {
+                                                  int64_t Wld, int64_t Wuse, int P, int nchunk, int nI64, int need_var) {
     const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int p = blockIdx.y;
     if (w >= Wuse) return;
@@ -130,7 +159,7 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ mpa
     mean_pc[(int64_t)p * Wld + w] = m;
     if (need_var) {
         double s = 0.0;
-        for (int i = 0; i < nI; ++i) s += spart[((int64_t)i * P + p) * Wld + w];
+        for (int i = 0; i < nI64; ++i) s += spart[((int64_t)i * P + p) * Wld + w];
         var_pc[(int64_t)p * Wld + w] = (amp[p] + noise[p]) - s;
     }
 }
@@ -145,12 +174,12 @@ int ensure_wcap(gpb_ctx* ctx, int64_t W) {
     }
     ctx->Wcap = 0;
     const int64_t P = ctx->P, Np = ctx->Np;
-    const int64_t nchunk = (Np + KX_CHUNK - 1) / KX_CHUNK, nI = (Np + 127) / 128;
+    const int64_t nchunk = (Np + KX_CHUNK - 1) / KX_CHUNK, nI64 = Np / 64;
     GPB_HIP(hipMalloc(&ctx->Xs, sizeof(double) * need * ctx->d));
     GPB_HIP(hipMalloc(&ctx->estd, sizeof(double) * need));
     GPB_HIP(hipMalloc(&ctx->KsT, sizeof(double) * P * Np * need));
     GPB_HIP(hipMalloc(&ctx->mpart, sizeof(double) * nchunk * P * need));
-    GPB_HIP(hipMalloc(&ctx->spart, sizeof(double) * nI * P * need));
+    GPB_HIP(hipMalloc(&ctx->spart, sizeof(double) * nI64 * P * need));
     GPB_HIP(hipMalloc(&ctx->mean_pc, sizeof(double) * P * need));
     GPB_HIP(hipMalloc(&ctx->var_pc, sizeof(double) * P * need));
     ctx->Wcap = need;
@@ -185,17 +214,31 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var)
     if (ctx->kind == GPB_KERNEL_RBF) launch_kcross_kind<GPB_KERNEL_RBF>(ctx, Xs_dev, W, Wuse);
     else if (ctx->kind == GPB_KERNEL_MATERN15) launch_kcross_kind<GPB_KERNEL_MATERN15>(ctx, Xs_dev, W, Wuse);
     else launch_kcross_kind<GPB_KERNEL_MATERN25>(ctx, Xs_dev, W, Wuse);
-    const int nI = (int)((ctx->Np + 127) / 128), nW = (int)(Wuse / 128);
     const int nchunk = (int)((ctx->Np + KX_CHUNK - 1) / KX_CHUNK);
+    const int nI64 = (int)(ctx->Np / 64);
     if (need_var) {
+        // 128-wide tiles when they fill the chip several times over, 64-wide for small walker batches
+        const int64_t tiles128 = ctx->P * ((ctx->Np + 127) / 128) * (Wuse / 128);
+        int T = (tiles128 >= ctx->tile_switch) ? 128 : 64;
+        if (ctx->force_tile == 64 || ctx->force_tile == 128) T = ctx->force_tile;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (ctx->profile) {                    // live HIP-event timing of the dominant kernel (bench.py)
             GPB_HIP(hipEventCreate(&e0));
             GPB_HIP(hipEventCreate(&e1));
             GPB_HIP(hipEventRecord(e0, ctx->stream));
         }
-        hipLaunchKernelGGL(k_predict, dim3((unsigned)((int64_t)ctx->P * nI * nW)), dim3(256), 0, ctx->stream,
-                           ctx->Linv, ctx->KsT, ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW);
+        const int nI = (T == 128) ? (int)((ctx->Np + 127) / 128) : nI64, nW = (int)(Wuse / T);
+        // which operand is larger decides the XCD affinity: L^-1 (P Np^2/2) or K*^T (P Np W)
+        int xcd_rows = (2 * Wuse < ctx->Np) ? 1 : 0;
+        if (ctx->force_xcd >= 0) xcd_rows = ctx->force_xcd;
+        const int64_t ngroups = (int64_t)ctx->P * nI;
+        const int64_t nblocks = xcd_rows ? ((ngroups + 7) / 8) * 8 * nW : ngroups * nW;
+        if (T == 128)
+            hipLaunchKernelGGL(k_predict<128>, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT,
+                               ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW, xcd_rows);
+        else
+            hipLaunchKernelGGL(k_predict<64>, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT,
+                               ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW, xcd_rows);
         if (ctx->profile) {
             GPB_HIP(hipEventRecord(e1, ctx->stream));
             ctx->prof_events.push_back({e0, e1});
@@ -204,50 +247,36 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var)
     }
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((Wuse + 255) / 256), (unsigned)ctx->P), dim3(256), 0, ctx->stream,
                        ctx->mpart, ctx->spart, ctx->amp, ctx->noise, ctx->mean_pc, ctx->var_pc, ctx->Wcap, Wuse,
-                       (int)ctx->P, nchunk, nI, need_var ? 1 : 0);
+                       (int)ctx->P, nchunk, nI64, need_var ? 1 : 0);
     GPB_HIP(hipGetLastError());
     return 0;
 }
 
 // ------------------------------------------------------------------ test hooks
-__global__ __launch_bounds__(256, 2) void k_test_gemm_nn(const double* A, const double* B, double* C, int64_t M,
-                                                         int64_t N, int64_t K) {
-    __shared__ TileLds lds;
-    const int64_t mb = (int64_t)blockIdx.y * 128, nb = (int64_t)blockIdx.x * 128;
-    d4 acc[4][4];
-    acc_zero(acc);
-    gemm_tile_loop<false, false>(A, K, B, N, mb, nb, (int)imin64(128, M - mb), (int)imin64(128, N - nb), 0, K, lds,
-                                 acc);
-    tile_store(C, N, mb, nb, (int)imin64(128, M - mb), (int)imin64(128, N - nb), 1.0, false, acc);
-}
-__global__ __launch_bounds__(256, 2) void k_test_gemm_nt(const double* A, const double* B, double* C, int64_t M,
-                                                         int64_t N, int64_t K) {
-    __shared__ TileLds lds;
-    const int64_t mb = (int64_t)blockIdx.y * 128, nb = (int64_t)blockIdx.x * 128;
-    d4 acc[4][4];
-    acc_zero(acc);
-    gemm_tile_loop<false, true>(A, K, B, K, mb, nb, (int)imin64(128, M - mb), (int)imin64(128, N - nb), 0, K, lds,
-                                acc);
-    tile_store(C, N, mb, nb, (int)imin64(128, M - mb), (int)imin64(128, N - nb), 1.0, false, acc);
-}
-__global__ __launch_bounds__(256, 2) void k_test_gemm_tn(const double* A, const double* B, double* C, int64_t M,
-                                                         int64_t N, int64_t K) {
-    __shared__ TileLds lds;
-    const int64_t mb = (int64_t)blockIdx.y * 128, nb = (int64_t)blockIdx.x * 128;
-    d4 acc[4][4];
-    acc_zero(acc);
-    gemm_tile_loop<true, false>(A, M, B, N, mb, nb, (int)imin64(128, M - mb), (int)imin64(128, N - nb), 0, K, lds,
-                                acc);
-    tile_store(C, N, mb, nb, (int)imin64(128, M - mb), (int)imin64(128, N - nb), 1.0, false, acc);
+// MODE: 0 = C = A[M,K] B[K,N]; 1 = C = A[M,K] B[N,K]^T; 2 = C = A[K,M]^T B[K,N]
+template <int T, int MODE>
+__global__ __launch_bounds__(256, 2) void k_test_gemm(const double* A, const double* B, double* C, int64_t M,
+                                                      int64_t N, int64_t K) {
+    __shared__ TileLds<T> lds;
+    const int64_t mb = (int64_t)blockIdx.y * T, nb = (int64_t)blockIdx.x * T;
+    const int me = (int)imin64(T, M - mb), ne = (int)imin64(T, N - nb);
+    Acc<T> acc;
+    acc_zero<T>(acc);
+    if (MODE == 0) gemm_tile_loop<T, false, false>(A, K, B, N, mb, nb, me, ne, 0, K, lds, acc);
+    else if (MODE == 1) gemm_tile_loop<T, false, true>(A, K, B, K, mb, nb, me, ne, 0, K, lds, acc);
+    else gemm_tile_loop<T, true, false>(A, M, B, N, mb, nb, me, ne, 0, K, lds, acc);
+    tile_store<T>(C, N, mb, nb, me, ne, 1.0, false, acc);
 }
 
-// b_trans: 0 = C = A[M,K] B[K,N]; 1 = C = A[M,K] B[N,K]^T; 2 = C = A[K,M]^T B[K,N]
+// b_trans: bits 0-1 = MODE above, bit 2 set = 64x64 tiles instead of 128x128
 int launch_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K, const double* A, const double* B, double* C,
                      int b_trans) {
-    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
-    if (b_trans == 0) hipLaunchKernelGGL(k_test_gemm_nn, grid, dim3(256), 0, ctx->stream, A, B, C, M, N, K);
-    else if (b_trans == 1) hipLaunchKernelGGL(k_test_gemm_nt, grid, dim3(256), 0, ctx->stream, A, B, C, M, N, K);
-    else hipLaunchKernelGGL(k_test_gemm_tn, grid, dim3(256), 0, ctx->stream, A, B, C, M, N, K);
+    const int mode = b_trans & 3, T = (b_trans & 4) ? 64 : 128;
+    dim3 grid((unsigned)((N + T - 1) / T), (unsigned)((M + T - 1) / T));
+#define GPB_TG(TT, MM) hipLaunchKernelGGL((k_test_gemm<TT, MM>), grid, dim3(256), 0, ctx->stream, A, B, C, M, N, K)
+    if (T == 128) { if (mode == 0) GPB_TG(128, 0); else if (mode == 1) GPB_TG(128, 1); else GPB_TG(128, 2); }
+    else          { if (mode == 0) GPB_TG(64, 0);  else if (mode == 1) GPB_TG(64, 1);  else GPB_TG(64, 2); }
+#undef GPB_TG
     GPB_HIP(hipGetLastError());
     return 0;
 }

@@ -198,7 +198,7 @@ class GPEngine:
                                          float(outside), float(const), nat.ptr(ll_dev)))
 
     # ------------------------------------------------------------------ diagnostics
-    def test_gemm(self, A, B, mode=0):
+    def test_gemm(self, A, B, mode=0, tile=128):
         A, B = nat.f64(A), nat.f64(B)
         if mode == 0:
             M, K = A.shape; N = B.shape[1]
@@ -207,8 +207,13 @@ class GPEngine:
         else:
             K, M = A.shape; N = B.shape[1]
         Cm = np.empty((M, N))
-        self._ck(self.lib.gpb_test_gemm(self.h, M, N, K, nat.ptr(A), nat.ptr(B), nat.ptr(Cm), mode))
+        self._ck(self.lib.gpb_test_gemm(self.h, M, N, K, nat.ptr(A), nat.ptr(B), nat.ptr(Cm),
+                                        mode | (4 if tile == 64 else 0)))
         return Cm
+
+    def force_tile(self, tile=0, switch_tiles=0):
+        """test/tuning hook: k_predict tile size (0 auto, 64, 128)."""
+        self._ck(self.lib.gpb_debug_force_tile(self.h, int(tile), int(switch_tiles)))
 
     def force_generic_mvn(self, on=True):
         """test hook: bypass the register-resident MVN fast path."""

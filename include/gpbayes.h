@@ -163,9 +163,13 @@ int gpb_dist_allgather(gpb_ctx* ctx, const double* send_dev, double* recv_dev, i
 int gpb_dist_finalize(gpb_ctx* ctx);
 
 /* ---- micro-benchmarks / self-tests (device) --------------------------------------- */
-/* C[M,N] = A[M,K] * B[K,N] through the f64 MFMA tile engine (all multiples of 128/16). */
+/* C[M,N] = A*B through the f64 MFMA tile engine (K%16==0).  b_trans bits 0-1: 0 = A[M,K] B[K,N],
+ * 1 = A[M,K] B[N,K]^T, 2 = A[K,M]^T B[K,N]; bit 2: 64x64 tiles instead of 128x128. */
 int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K,
                   const double* A_host, const double* B_host, double* C_host, int b_trans);
+/* test/tuning hook: force the tile size of the predict kernel (0 = automatic, 64, 128) and, when
+ * switch_tiles > 0, the number of 128x128 tiles from which the automatic choice uses them. */
+int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
 /* test hook: route gpb_loglike through the generic LDS/HBM Cholesky instead of the register-resident
  * fast path (PCA mode, M <= 64) so that both implementations can be checked against each other. */
 int gpb_debug_force_generic_mvn(gpb_ctx* ctx, int on);

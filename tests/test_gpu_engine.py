@@ -203,3 +203,30 @@ def test_loglike_fast_and_generic_paths(eng, M, P):
     # accumulate=True adds onto an existing vector (multi-emulator blocks)
     acc = eng.loglike(Xw, out=np.full(W, 2.5), accumulate=True)
     assert relerr(acc, fast + 2.5) < 1e-13
+
+
+# ---------------------------------------------------------------- 64x64 tile variant (small walker batches / multi-GPU shards)
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_mfma_tile_gemm_64(eng, mode):
+    rng = np.random.default_rng(40 + mode)
+    M, N, K = 192, 130, 48
+    A = rng.standard_normal((M, K)); B = rng.standard_normal((K, N))
+    args = [(A, B), (A, np.ascontiguousarray(B.T)), (np.ascontiguousarray(A.T), B)][mode]
+    assert maxrel(eng.test_gemm(*args, mode, tile=64), A @ B) < 1e-13
+
+
+def test_predict_tile_sizes_are_bit_identical(eng):
+    """Both tile sizes reduce V^2 in the same tree, so the automatic switch (and hence the number of
+    ranks a walker ensemble is sharded over) never changes a bit of the variance."""
+    from gpbayestools_hic_amd import synth
+    rng = np.random.default_rng(8)
+    for N in (448, 512):                                  # Np = 448 (odd number of 64-blocks) and 512
+        d, P = 6, 3
+        X = synth.lhs(N, d, seed=N)
+        eng.set_data(X, rng.standard_normal((P, N)), "RBF", 0.1)
+        eng.set_theta(synth.fixed_theta(d, P)); eng.factor()
+        Xs = rng.random((300, d))
+        eng.force_tile(128); m1, v1 = eng.predict(Xs)
+        eng.force_tile(64); m2, v2 = eng.predict(Xs)
+        eng.force_tile(0)
+        assert np.array_equal(m1, m2) and np.array_equal(v1, v2)
