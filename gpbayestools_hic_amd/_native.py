@@ -40,6 +40,7 @@ PROTOTYPES = {
     "gpb_emu_predict": (C.c_int, [VP, VP, c_i64, C.c_int, VP, VP, VP]),
     "gpb_like_set": (C.c_int, [VP, VP, VP]),
     "gpb_loglike": (C.c_int, [VP, VP, c_i64, C.c_int, VP, C.c_int, VP]),
+    "gpb_logpost": (C.c_int, [VP, VP, c_i64, VP, C.c_int, VP, VP, C.c_double, C.c_double]),
     "gpb_mvn_loglike": (C.c_int, [VP, VP, VP, c_i64, c_i64, C.c_int, VP, VP]),
     "gpb_box_finish": (C.c_int, [VP, VP, c_i64, VP, VP, C.c_double, C.c_double, VP]),
     "gpb_stretch_propose": (C.c_int, [VP, VP, c_i64, c_i64, C.c_int, c_u64, c_u64, C.c_double, VP, VP]),
@@ -50,6 +51,7 @@ PROTOTYPES = {
     "gpb_dist_finalize": (C.c_int, [VP]),
     "gpb_test_gemm": (C.c_int, [VP, c_i64, c_i64, c_i64, VP, VP, VP, C.c_int]),
     "gpb_debug_force_tile": (C.c_int, [VP, C.c_int, c_i64]),
+    "gpb_debug_tune": (C.c_int, [VP, C.c_int, C.c_int]),
     "gpb_debug_force_generic_mvn": (C.c_int, [VP, C.c_int]),
     "gpb_profile_enable": (C.c_int, [VP, C.c_int]),
     "gpb_profile_read": (C.c_int, [VP, VP, VP, VP]),

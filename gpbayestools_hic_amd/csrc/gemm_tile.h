@@ -34,81 +34,84 @@ struct __attribute__((aligned(16))) TileLds {
     double Bs[BK][LD];
 };                                       // T=128: 36,864 B; T=64: 20,480 B
 
-template <int T>
-struct Frag { double2 r[T / 32]; };
-template <int T>
-struct Acc { d4 v[T / 32][T / 32]; };
+// NW = waves per workgroup (4: 2x2 waves, wave tile T/2 x T/2;  8: 2x4 waves, wave tile T/2 x T/4).
+// More waves per tile shorten a tile's critical path: ONE wave can issue an f64 MFMA only every
+// ~138 cycles (profiles/r01_mfma_f64_issue_rate.txt), two waves per SIMD reach ~70.
+template <int T, int NW = 4>
+struct Frag { double2 r[(8 * T) / (64 * NW)]; };
+template <int T, int NW = 4>
+struct Acc { d4 v[T / 32][(2 * T / NW) / 16]; };
 
 // logical tile[k][x] = G[(k0+k)*ld + x0+x]   (k<16, x<T); rows are contiguous in x.
-template <int T>
+template <int T, int NW>
 __device__ __forceinline__ void gload_direct(const double* __restrict__ G, int64_t ld, int64_t k0, int64_t x0,
-                                             int x_ext, Frag<T>& f, int tid) {
+                                             int x_ext, Frag<T, NW>& f, int tid) {
     constexpr int TPR = T / 2;                 // threads per row (2 doubles each)
-    constexpr int RPP = 256 / TPR;             // rows per pass
+    constexpr int RPP = (64 * NW) / TPR;       // rows per pass
     const int row = tid / TPR, col = (tid % TPR) * 2;
     const bool ok = col < x_ext;
 #pragma unroll
-    for (int j = 0; j < T / 32; ++j) {
+    for (int j = 0; j < (8 * T) / (64 * NW); ++j) {
         if (ok) f.r[j] = *reinterpret_cast<const double2*>(G + (k0 + row + RPP * j) * ld + x0 + col);
         else    f.r[j] = make_double2(0.0, 0.0);
     }
 }
-template <int T>
-__device__ __forceinline__ void lstore_direct(double (*S)[T + 16], const Frag<T>& f, int tid) {
-    constexpr int TPR = T / 2, RPP = 256 / TPR;
+template <int T, int NW>
+__device__ __forceinline__ void lstore_direct(double (*S)[T + 16], const Frag<T, NW>& f, int tid) {
+    constexpr int TPR = T / 2, RPP = (64 * NW) / TPR;
     const int row = tid / TPR, col = (tid % TPR) * 2;
 #pragma unroll
-    for (int j = 0; j < T / 32; ++j) *reinterpret_cast<double2*>(&S[row + RPP * j][col]) = f.r[j];
+    for (int j = 0; j < (8 * T) / (64 * NW); ++j) *reinterpret_cast<double2*>(&S[row + RPP * j][col]) = f.r[j];
 }
 // logical tile[k][x] = G[(x0+x)*ld + k0+k]   (rows of G are contiguous in k): transpose on store.
-template <int T>
+template <int T, int NW>
 __device__ __forceinline__ void gload_trans(const double* __restrict__ G, int64_t ld, int64_t k0, int64_t x0,
-                                            int x_ext, Frag<T>& f, int tid) {
-    constexpr int TPX = 256 / T;               // threads per x row: 2 (T=128) or 4 (T=64)
-    constexpr int KPT = BK / TPX;              // k's per thread: 8 or 4
+                                            int x_ext, Frag<T, NW>& f, int tid) {
+    constexpr int TPX = (64 * NW) / T;         // threads per x row
+    constexpr int KPT = BK / TPX;              // k's per thread
     const int x = tid / TPX, kh = (tid % TPX) * KPT;
     const bool ok = x < x_ext;
     const double* p = G + (x0 + x) * ld + k0 + kh;
 #pragma unroll
-    for (int j = 0; j < T / 32; ++j) {
+    for (int j = 0; j < KPT / 2; ++j) {
         if (ok) f.r[j] = *reinterpret_cast<const double2*>(p + 2 * j);
         else    f.r[j] = make_double2(0.0, 0.0);
     }
 }
-template <int T>
-__device__ __forceinline__ void lstore_trans(double (*S)[T + 16], const Frag<T>& f, int tid) {
-    constexpr int TPX = 256 / T, KPT = BK / TPX;
+template <int T, int NW>
+__device__ __forceinline__ void lstore_trans(double (*S)[T + 16], const Frag<T, NW>& f, int tid) {
+    constexpr int TPX = (64 * NW) / T, KPT = BK / TPX;
     const int x = tid / TPX, kh = (tid % TPX) * KPT;
 #pragma unroll
-    for (int j = 0; j < T / 32; ++j) {
+    for (int j = 0; j < KPT / 2; ++j) {
         S[kh + 2 * j][x] = f.r[j].x;
         S[kh + 2 * j + 1][x] = f.r[j].y;
     }
 }
 
-template <int T>
-__device__ __forceinline__ void acc_zero(Acc<T>& acc) {
+template <int T, int NW = 4>
+__device__ __forceinline__ void acc_zero(Acc<T, NW>& acc) {
 #pragma unroll
     for (int i = 0; i < T / 32; ++i)
 #pragma unroll
-        for (int j = 0; j < T / 32; ++j) acc.v[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < (2 * T / NW) / 16; ++j) acc.v[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 }
 
-template <int T>
-__device__ __forceinline__ void tile_mma(const TileLds<T>& L, Acc<T>& acc, int lane, int m0, int n0) {
-    constexpr int NI = T / 32;
+template <int T, int NW>
+__device__ __forceinline__ void tile_mma(const TileLds<T>& L, Acc<T, NW>& acc, int lane, int m0, int n0) {
+    constexpr int NI = T / 32, NJ = (2 * T / NW) / 16;
     const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
-        double a[NI], b[NI];
+        double a[NI], b[NJ];
 #pragma unroll
         for (int i = 0; i < NI; ++i) a[i] = L.As[kk + lk][m0 + 16 * i + lr];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) b[j] = L.Bs[kk + lk][n0 + 16 * j + lr];
+        for (int j = 0; j < NJ; ++j) b[j] = L.Bs[kk + lk][n0 + 16 * j + lr];
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
+            for (int j = 0; j < NJ; ++j)
                 acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc.v[i][j], 0, 0, 0);
     }
 }
@@ -117,34 +120,35 @@ __device__ __forceinline__ void tile_mma(const TileLds<T>& L, Acc<T>& acc, int l
 //   A_TRANS=false: A[m][k] = Ag[(m_base+m)*lda + k]       A_TRANS=true: A[m][k] = Ag[k*lda + m_base+m]
 //   B_TRANS=false: B[k][n] = Bg[k*ldb + n_base+n]         B_TRANS=true: B[k][n] = Bg[(n_base+n)*ldb + k]
 // m_ext / n_ext (even, <= T) bound the valid rows / columns of this tile; the rest reads as 0.
-template <int T, bool A_TRANS, bool B_TRANS>
+template <int T, bool A_TRANS, bool B_TRANS, int NW = 4>
 __device__ __forceinline__ void gemm_tile_loop(const double* __restrict__ Ag, int64_t lda,
                                                const double* __restrict__ Bg, int64_t ldb, int64_t m_base,
                                                int64_t n_base, int m_ext, int n_ext, int64_t k_begin, int64_t k_end,
-                                               TileLds<T>& L, Acc<T>& acc) {
+                                               TileLds<T>& L, Acc<T, NW>& acc) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int m0 = (wave >> 1) * (T / 2), n0 = (wave & 1) * (T / 2);
-    Frag<T> fa, fb;
+    constexpr int WN = NW / 2, TN = T / WN;     // waves along n, wave tile width
+    const int m0 = (wave / WN) * (T / 2), n0 = (wave % WN) * TN;
+    Frag<T, NW> fa, fb;
     if (k_begin < k_end) {
-        if (A_TRANS) gload_direct<T>(Ag, lda, k_begin, m_base, m_ext, fa, tid);
-        else         gload_trans<T>(Ag, lda, k_begin, m_base, m_ext, fa, tid);
-        if (B_TRANS) gload_trans<T>(Bg, ldb, k_begin, n_base, n_ext, fb, tid);
-        else         gload_direct<T>(Bg, ldb, k_begin, n_base, n_ext, fb, tid);
+        if (A_TRANS) gload_direct<T, NW>(Ag, lda, k_begin, m_base, m_ext, fa, tid);
+        else         gload_trans<T, NW>(Ag, lda, k_begin, m_base, m_ext, fa, tid);
+        if (B_TRANS) gload_trans<T, NW>(Bg, ldb, k_begin, n_base, n_ext, fb, tid);
+        else         gload_direct<T, NW>(Bg, ldb, k_begin, n_base, n_ext, fb, tid);
     }
     for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
         __syncthreads();
-        if (A_TRANS) lstore_direct<T>(L.As, fa, tid); else lstore_trans<T>(L.As, fa, tid);
-        if (B_TRANS) lstore_trans<T>(L.Bs, fb, tid);  else lstore_direct<T>(L.Bs, fb, tid);
+        if (A_TRANS) lstore_direct<T, NW>(L.As, fa, tid); else lstore_trans<T, NW>(L.As, fa, tid);
+        if (B_TRANS) lstore_trans<T, NW>(L.Bs, fb, tid);  else lstore_direct<T, NW>(L.Bs, fb, tid);
         __syncthreads();
         const int64_t kn = k0 + BK;
         if (kn < k_end) {
-            if (A_TRANS) gload_direct<T>(Ag, lda, kn, m_base, m_ext, fa, tid);
-            else         gload_trans<T>(Ag, lda, kn, m_base, m_ext, fa, tid);
-            if (B_TRANS) gload_trans<T>(Bg, ldb, kn, n_base, n_ext, fb, tid);
-            else         gload_direct<T>(Bg, ldb, kn, n_base, n_ext, fb, tid);
+            if (A_TRANS) gload_direct<T, NW>(Ag, lda, kn, m_base, m_ext, fa, tid);
+            else         gload_trans<T, NW>(Ag, lda, kn, m_base, m_ext, fa, tid);
+            if (B_TRANS) gload_trans<T, NW>(Bg, ldb, kn, n_base, n_ext, fb, tid);
+            else         gload_direct<T, NW>(Bg, ldb, kn, n_base, n_ext, fb, tid);
         }
-        tile_mma<T>(L, acc, lane, m0, n0);
+        tile_mma<T, NW>(L, acc, lane, m0, n0);
     }
 }
 

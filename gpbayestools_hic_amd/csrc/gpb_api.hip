@@ -96,10 +96,15 @@ extern "C" int gpb_ctx_create(int device, void* stream, gpb_ctx** out) {
         ctx->own_stream = true;
     }
     if (hipMalloc(&ctx->notpd, sizeof(int)) != hipSuccess ||
-        hipMemsetAsync(ctx->notpd, 0, sizeof(int), ctx->stream) != hipSuccess) {
+        hipMemsetAsync(ctx->notpd, 0, sizeof(int), ctx->stream) != hipSuccess ||
+        hipMalloc(&ctx->tile_counter, sizeof(unsigned)) != hipSuccess ||
+        hipMemsetAsync(ctx->tile_counter, 0, sizeof(unsigned), ctx->stream) != hipSuccess) {
         delete ctx;
         return GPB_E_ALLOC;
     }
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0)
+        ctx->num_cu = ncu;
     *out = ctx;
     return 0;
 }
@@ -116,7 +121,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     dev_free(&ctx->gpart); dev_free(&ctx->Xs); dev_free(&ctx->estd); dev_free(&ctx->KsT); dev_free(&ctx->mpart);
     dev_free(&ctx->spart); dev_free(&ctx->mean_pc); dev_free(&ctx->var_pc); dev_free(&ctx->out_stage);
     dev_free(&ctx->A); dev_free(&ctx->mu); dev_free(&ctx->scale); dev_free(&ctx->C0); dev_free(&ctx->yexp);
-    dev_free(&ctx->Cexp); dev_free(&ctx->mvn_ws); dev_free(&ctx->notpd);
+    dev_free(&ctx->Cexp); dev_free(&ctx->mvn_ws); dev_free(&ctx->notpd); dev_free(&ctx->tile_counter);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -416,6 +421,18 @@ extern "C" int gpb_loglike(gpb_ctx* ctx, const double* Xs, int64_t W, int on_dev
     return 0;
 }
 
+extern "C" int gpb_logpost(gpb_ctx* ctx, const double* Xs_dev, int64_t W, double* ll_dev, int accumulate,
+                           const double* lo_dev, const double* hi_dev, double outside_value, double inside_const) {
+    if (!ctx || !Xs_dev || !ll_dev || !lo_dev || !hi_dev || W < 0) return GPB_E_ARG;
+    if (!ctx->have_like) GPB_FAIL(GPB_E_STATE, "gpb_logpost before gpb_like_set");
+    if (W == 0) return 0;
+    GPB_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_wcap(ctx, W);
+    if (rc) return rc;
+    if ((rc = launch_predict(ctx, Xs_dev, W, true))) return rc;
+    return launch_loglike(ctx, W, ll_dev, accumulate != 0, Xs_dev, lo_dev, hi_dev, outside_value, inside_const);
+}
+
 extern "C" int gpb_mvn_loglike(gpb_ctx* ctx, const double* dY, const double* cov, int64_t W, int64_t M,
                                int on_device, double* ll, int* n_notpd_host) {
     if (!ctx || !dY || !cov || !ll || W < 0 || M < 1) return GPB_E_ARG;
@@ -524,7 +541,20 @@ extern "C" int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles
     if (!ctx || (tile != 0 && tile != 64 && tile != 128)) return GPB_E_ARG;
     ctx->force_tile = tile;
     if (switch_tiles > 0) ctx->tile_switch = switch_tiles;
-    if (switch_tiles <= -10) ctx->force_xcd = (int)(-switch_tiles - 11);   // -10 -> auto(-1), -11 -> 0, -12 -> 1
+    return 0;
+}
+
+// key: 0 = XCD affinity (-1 auto, 0 by walker tile, 1 by row block); 1 = persistent 64-tile workgroups per CU;
+//      2 = waves per predict tile (4 or 8); 3 = persistent workgroups per CU of the 128-tile 8-wave variant
+extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
+    if (!ctx) return GPB_E_ARG;
+    switch (key) {
+        case 0: if (value < -1 || value > 1) return GPB_E_ARG; ctx->force_xcd = value; break;
+        case 1: if (value < 1 || value > 8) return GPB_E_ARG; ctx->wgs_per_cu64 = value; break;
+        case 2: if (value != 4 && value != 8) return GPB_E_ARG; ctx->predict_waves = value; break;
+        case 3: if (value < 1 || value > 4) return GPB_E_ARG; ctx->wgs_per_cu128w8 = value; break;
+        default: return GPB_E_ARG;
+    }
     return 0;
 }
 

@@ -11,7 +11,7 @@ namespace gpb {
 
 constexpr int NB = 64;          // Cholesky diagonal block / padding granule of N
 constexpr int WPAD = 128;       // walker-batch padding granule (GEMM tile width)
-constexpr int KX_CHUNK = 256;   // design points per kcross workgroup (mean partial granule)
+constexpr int KX_CHUNK = 64;    // design points per kcross workgroup (mean partial granule)
 constexpr int MAX_D = 64;
 
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
@@ -73,7 +73,13 @@ struct gpb_ctx {
     double* mvn_ws = nullptr;      // global fallback for M > 128: [Wcap][M][M]
     int64_t mvn_ws_cap = 0;
     int* notpd = nullptr;          // device counter
-    int force_tile = 0;             // test hook: 0 = auto, 64 / 128 = force the k_predict tile size
+    int num_cu = 256;               // multiprocessor count of the device
+    int wgs_per_cu64 = 4;           // persistent k_predict<64> workgroups per CU
+    int wgs_per_cu128w8 = 2;        // ... for the 128-tile, 8-wave variant
+    int predict_waves = 4;          // waves per k_predict tile (4 or 8)
+    unsigned* tile_counter = nullptr;   // device ticket counter of the k_predict work queue (never reset)
+    unsigned tile_base = 0;         // tickets consumed so far
+    int force_tile = 0;            // test hook: 0 = auto, 64 / 128 = force the k_predict tile size
     int force_xcd = -1;             // tuning hook: -1 auto, 0 / 1 = k_predict XCD affinity by walker tile / row block
     int64_t tile_switch = 1280;     // use 128x128 tiles when at least this many of them exist
     bool force_generic_mvn = false; // test hook: bypass the register-resident MVN fast path
@@ -117,7 +123,9 @@ int ensure_wcap(gpb_ctx* ctx, int64_t W);
 int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var);
 // likelihood (gpb_like.hip)
 int launch_obs(gpb_ctx* ctx, int64_t W, const double* estd_dev, double* mean_dev, double* cov_dev);
-int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate);
+int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, const double* X_box = nullptr,
+                   const double* lo_dev = nullptr, const double* hi_dev = nullptr, double outside = 0.0,
+                   double inside_const = 0.0);
 int launch_mvn(gpb_ctx* ctx, const double* dY_dev, const double* cov_dev, int64_t W, int64_t M, double* ll_dev);
 // test hooks
 int launch_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K, const double* A, const double* B,

@@ -218,13 +218,24 @@ __device__ __forceinline__ double readlane_f64(double x, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// Optional fused prior box (src/mcmc.py:194-198,275-276,296-297): X == nullptr -> plain block log-likelihood.
+struct BoxArgs {
+    const double* X;      // [W][d] walker positions
+    const double* lo;     // [d]
+    const double* hi;     // [d]
+    int d;
+    double outside;       // -inf or -1e300
+    double inside_const;  // 2 log(1e-16)
+};
+
 template <int MP>
 __global__ __launch_bounds__(256) void k_loglike_reg(const double* __restrict__ mean_pc,
                                                      const double* __restrict__ var_pc, int64_t Wld, int64_t W, int P,
                                                      int M, const double* __restrict__ A,
                                                      const double* __restrict__ mu, const double* __restrict__ C0,
                                                      const double* __restrict__ yexp, const double* __restrict__ Cexp,
-                                                     double* __restrict__ ll, int accumulate, int* __restrict__ notpd) {
+                                                     double* __restrict__ ll, int accumulate, int* __restrict__ notpd,
+                                                     BoxArgs box) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* sC = sm;                         // [64][MP+1]  C_trunc + C_exp, identity padded
     double* sA = sm + 64 * (MP + 1);         // [P][64]     A, zero padded
@@ -276,33 +287,54 @@ __global__ __launch_bounds__(256) void k_loglike_reg(const double* __restrict__ 
             if (((k - j) & 7) == 0) __builtin_amdgcn_sched_barrier(0);   // keep the SGPR broadcasts from piling up
         }
     }
+    bool inside = true;
+    if (box.X) {                                      // strict box over the d parameters, one per lane
+        bool ok = true;
+        for (int k0 = 0; k0 < box.d; k0 += 64) {
+            const int k = k0 + lane;
+            if (k < box.d) {
+                const double x = box.X[w * box.d + k];
+                ok = ok && (x > box.lo[k]) && (x < box.hi[k]);
+            }
+        }
+        inside = __all(ok);
+    }
     if (lane == 0) {
         double r = -0.5 * q - logdet;
-        if (bad) {
+        if (bad && inside) {
             r = nan("");
             atomicAdd(notpd, 1);
         }
-        ll[w] = accumulate ? (ll[w] + r) : r;
+        r = accumulate ? (ll[w] + r) : r;
+        if (box.X) r = inside ? (r + box.inside_const) : box.outside;
+        ll[w] = r;
     }
 }
 
 template <int MP>
-static int launch_loglike_reg(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate) {
+static int launch_loglike_reg(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, const BoxArgs& box) {
     const size_t sh = (64 * (MP + 1) + (size_t)ctx->P * 64) * sizeof(double);
     hipLaunchKernelGGL(k_loglike_reg<MP>, dim3((unsigned)((W + 3) / 4)), dim3(256), sh, ctx->stream, ctx->mean_pc,
                        ctx->var_pc, ctx->Wcap, W, (int)ctx->P, (int)ctx->M, ctx->A, ctx->mu, ctx->C0, ctx->yexp,
-                       ctx->Cexp, ll_dev, accumulate ? 1 : 0, ctx->notpd);
+                       ctx->Cexp, ll_dev, accumulate ? 1 : 0, ctx->notpd, box);
     GPB_HIP(hipGetLastError());
     return 0;
 }
 
-int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate) {
+__global__ void k_box(const double* __restrict__ X, int64_t W, int d, const double* __restrict__ lo,
+                      const double* __restrict__ hi, double outside, double inside_const, double* __restrict__ ll);
+
+// box_* optional (X_box == nullptr: no prior box).  The register-resident kernel applies the box itself;
+// the generic kernels are followed by k_box.
+int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, const double* X_box,
+                   const double* lo_dev, const double* hi_dev, double outside, double inside_const) {
     const int64_t M = ctx->M, P = ctx->P;
+    const BoxArgs box{X_box, lo_dev, hi_dev, (int)ctx->d, outside, inside_const};
     if (ctx->mode == GPB_MODE_PCA && M <= 64 && P <= 96 && !ctx->force_generic_mvn) {
-        if (M <= 8) return launch_loglike_reg<8>(ctx, W, ll_dev, accumulate);
-        if (M <= 16) return launch_loglike_reg<16>(ctx, W, ll_dev, accumulate);
-        if (M <= 32) return launch_loglike_reg<32>(ctx, W, ll_dev, accumulate);
-        return launch_loglike_reg<64>(ctx, W, ll_dev, accumulate);
+        if (M <= 8) return launch_loglike_reg<8>(ctx, W, ll_dev, accumulate, box);
+        if (M <= 16) return launch_loglike_reg<16>(ctx, W, ll_dev, accumulate, box);
+        if (M <= 32) return launch_loglike_reg<32>(ctx, W, ll_dev, accumulate, box);
+        return launch_loglike_reg<64>(ctx, W, ll_dev, accumulate, box);
     }
     const size_t small = (2 * P + 2 * M) * sizeof(double);
     const size_t mat = (size_t)(M + 1) * (M + 1) * sizeof(double);
@@ -331,6 +363,9 @@ int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate) {
         hipLaunchKernelGGL(k_loglike<false>, dim3((unsigned)W), dim3(256), sh, ctx->stream, ctx->mean_pc, ctx->var_pc,
                            ctx->Wcap, (int)P, (int)M, ctx->mode, ctx->A, ctx->mu, ctx->scale, ctx->C0, ctx->yexp,
                            ctx->Cexp, gws, ll_dev, accumulate ? 1 : 0, ctx->notpd);
+    if (X_box)
+        hipLaunchKernelGGL(k_box, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, ctx->stream, X_box, W, (int)ctx->d,
+                           lo_dev, hi_dev, outside, inside_const, ll_dev);
     GPB_HIP(hipGetLastError());
     return 0;
 }

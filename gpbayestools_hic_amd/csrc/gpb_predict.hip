@@ -29,7 +29,7 @@ __device__ __forceinline__ double shape_fn_p(double r2) {
     }
 }
 
-// grid (Wpad/64, ceil(Np/256), P), 256 threads: lane = walker, the 4 waves stride the chunk's
+// grid (Wpad/64, Np/64, P), 256 threads: lane = walker, the 4 waves stride the 64-point chunk's
 // design points; the design row is wave-uniform (scalar loads), the walker row lives in VGPRs.
 template <int KIND, int DPAD>
 __global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, int64_t W, int d,
@@ -38,15 +38,21 @@ __global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, i
                                                 double* __restrict__ KsT, double* __restrict__ mpart,
                                                 int64_t N, int64_t Np, int64_t Wld, int P) {
     __shared__ double red[4][64];
+    __shared__ double sx[64][DPAD + 1];
     const int p = blockIdx.z, chunk = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t w = (int64_t)blockIdx.x * 64 + lane;
+    // walker tile / length scale, loaded coalesced and divided once per element, then one row per lane
+    for (int e = threadIdx.x; e < 64 * DPAD; e += 256) {
+        const int r = e / DPAD, k = e - r * DPAD;
+        const int64_t ww = (int64_t)blockIdx.x * 64 + r;
+        sx[r][k] = (k < d && ww < W) ? Xs[ww * d + k] / ls[p * DPAD + k] : 0.0;
+    }
+    __syncthreads();
     double xs[DPAD];
 #pragma unroll
-    for (int k = 0; k < DPAD; ++k) {
-        xs[k] = (k < d && w < W) ? Xs[w * d + k] / ls[p * DPAD + k] : 0.0;
-    }
+    for (int k = 0; k < DPAD; ++k) xs[k] = sx[lane][k];
     const double c = amp[p];
     const double* Xp = Xsc + (int64_t)p * Np * DPAD;
     const double* ap = alpha + (int64_t)p * Np;
@@ -81,18 +87,16 @@ __global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, i
 // L2.  The fused epilogue reduces V^2 over rows in a tree that depends only on the row index — 32-row
 // chains, lane groups, then the two halves of each 64-row block — so both tile sizes, and therefore any
 // sharding of the walkers, give bit-identical sums.  spart is indexed by 64-row block.
-template <int T>
-__global__ __launch_bounds__(256, 2) void k_predict(const double* __restrict__ Linv, const double* __restrict__ KsT,
-                                                    double* __restrict__ spart, int64_t Np, int64_t Wld, int P,
-                                                    int nI, int nW, int xcd_rows) {
-    __shared__ TileLds<T> lds;
-    constexpr int NI = T / 32;
+template <int T, int NW>
+__device__ __forceinline__ void predict_tile(TileLds<T>& lds, int b, const double* __restrict__ Linv,
+                                             const double* __restrict__ KsT, double* __restrict__ spart, int64_t Np,
+                                             int64_t Wld, int P, int nI, int nW, int xcd_rows) {
+    constexpr int NI = T / 32, WN = NW / 2, TN = T / WN, NJ = TN / 16;
     // Tile order: heaviest row blocks of every GP first (LPT).  XCD affinity (blocks b and b+8 share an
     // XCD's L2 under round-robin dispatch; speed only, never correctness):
     //   xcd_rows = 1 (small W: L^-1 is the big operand): the nW walker tiles of one (row block, GP) group
     //                run on ONE XCD, so each L^-1 row block is fetched from HBM once;
     //   xcd_rows = 0 (large W: K*^T is the big operand): b % 8 == wt % 8, each XCD keeps its own K*^T columns.
-    const int b = blockIdx.x;
     int g, wt;
     if (xcd_rows) {
         const int q = b >> 3;
@@ -108,15 +112,15 @@ __global__ __launch_bounds__(256, 2) void k_predict(const double* __restrict__ L
     const int64_t mb = (int64_t)ib * T, nb = (int64_t)wt * T;
     const int m_ext = (int)imin64(T, Np - mb);
     const int64_t k_end = imin64(mb + T, Np);
-    Acc<T> acc;
-    acc_zero<T>(acc);
-    gemm_tile_loop<T, false, false>(Linv + (int64_t)p * Np * Np, Np, KsT + (int64_t)p * Np * Wld, Wld, mb, nb, m_ext,
-                                    T, 0, k_end, lds, acc);
+    Acc<T, NW> acc;
+    acc_zero<T, NW>(acc);
+    gemm_tile_loop<T, false, false, NW>(Linv + (int64_t)p * Np * Np, Np, KsT + (int64_t)p * Np * Wld, Wld, mb, nb,
+                                        m_ext, T, 0, k_end, lds, acc);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    double s[NI];
+    const int wm = wave / WN, wn = wave % WN;
+    double s[NJ];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         double h[NI / 2];                       // one chain per 32 rows: m-tiles (2g, 2g+1)
 #pragma unroll
         for (int g = 0; g < NI / 2; ++g) {
@@ -135,15 +139,40 @@ __global__ __launch_bounds__(256, 2) void k_predict(const double* __restrict__ L
     double* red = &lds.As[0][0];                // [2 wave rows][T columns]
     if (lane < 16) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) red[wm * T + wn * (T / 2) + 16 * j + lane] = s[j];
+        for (int j = 0; j < NJ; ++j) red[wm * T + wn * TN + 16 * j + lane] = s[j];
     }
     __syncthreads();
     if (T == 128) {                             // each wave row is one 64-row block
-        const int half = tid >> 7, col = tid & 127;
-        const int64_t blk = 2 * (int64_t)ib + half;
-        if (blk * 64 < Np) spart[(blk * P + p) * Wld + nb + col] = red[half * T + col];
+        if (tid < 256) {
+            const int half = tid >> 7, col = tid & 127;
+            const int64_t blk = 2 * (int64_t)ib + half;
+            if (blk * 64 < Np) spart[(blk * P + p) * Wld + nb + col] = red[half * T + col];
+        }
     } else {                                    // the two wave rows are the halves of one 64-row block
         if (tid < T) spart[((int64_t)ib * P + p) * Wld + nb + tid] = red[tid] + red[T + tid];
+    }
+}
+
+// Persistent launch: `gridDim.x` workgroups (a few per CU) pull tile indices from one device-scope
+// ticket counter in LPT order, so the triangular row blocks balance dynamically whatever the
+// dispatcher does — with a plain grid of unequal tiles that are all resident at once (small walker
+// batches) the static placement left ~20 % of the chip idle behind the heaviest CUs.  The counter is
+// never reset: the host passes the running base (every launch consumes nblocks + gridDim.x tickets).
+// Exit condition: every workgroup eventually draws a ticket >= nblocks.
+template <int T, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 4)) void k_predict(const double* __restrict__ Linv, const double* __restrict__ KsT,
+                                                     double* __restrict__ spart, int64_t Np, int64_t Wld, int P,
+                                                     int nI, int nW, int xcd_rows, unsigned* __restrict__ counter,
+                                                     unsigned base, unsigned nblocks) {
+    __shared__ TileLds<T> lds;
+    __shared__ unsigned s_ticket;
+    for (;;) {
+        if (threadIdx.x == 0) s_ticket = atomicAdd(counter, 1u) - base;
+        __syncthreads();
+        const unsigned b = s_ticket;
+        if (b >= nblocks) break;                // uniform
+        predict_tile<T, NW>(lds, (int)b, Linv, KsT, spart, Np, Wld, P, nI, nW, xcd_rows);
+        __syncthreads();                        // s_ticket and the LDS tiles are reused
     }
 }
 
@@ -233,12 +262,18 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var)
         if (ctx->force_xcd >= 0) xcd_rows = ctx->force_xcd;
         const int64_t ngroups = (int64_t)ctx->P * nI;
         const int64_t nblocks = xcd_rows ? ((ngroups + 7) / 8) * 8 * nW : ngroups * nW;
-        if (T == 128)
-            hipLaunchKernelGGL(k_predict<128>, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT,
-                               ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW, xcd_rows);
-        else
-            hipLaunchKernelGGL(k_predict<64>, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT,
-                               ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW, xcd_rows);
+        const int nwv = ctx->predict_waves;             // 4 or 8 waves per tile
+        const int per_cu = (T == 128) ? (nwv == 8 ? ctx->wgs_per_cu128w8 : 2) : ctx->wgs_per_cu64;
+        const int64_t slots = (int64_t)ctx->num_cu * per_cu;
+        const unsigned grid = (unsigned)(nblocks < slots ? nblocks : slots);
+#define GPB_PRED(TT, WW)                                                                                         \
+    hipLaunchKernelGGL((k_predict<TT, WW>), dim3(grid), dim3(64 * WW), 0, ctx->stream, ctx->Linv, ctx->KsT,        \
+                       ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW, xcd_rows, ctx->tile_counter,           \
+                       ctx->tile_base, (unsigned)nblocks)
+        if (T == 128) { if (nwv == 8) GPB_PRED(128, 8); else GPB_PRED(128, 4); }
+        else          { if (nwv == 8) GPB_PRED(64, 8);  else GPB_PRED(64, 4); }
+#undef GPB_PRED
+        ctx->tile_base += (unsigned)nblocks + grid;      // tickets consumed by this launch (mod 2^32)
         if (ctx->profile) {
             GPB_HIP(hipEventRecord(e1, ctx->stream));
             ctx->prof_events.push_back({e0, e1});

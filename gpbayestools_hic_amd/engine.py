@@ -175,6 +175,13 @@ class GPEngine:
         self.last_not_pd = npd.value
         return out
 
+    def logpost(self, X_dev, out, accumulate, lo_dev, hi_dev, outside, const):
+        """Fused device log-posterior of the last emulator block: log-likelihood (+= when accumulate),
+        strict prior box, constant.  Asynchronous; torch cuda tensors only."""
+        self._ck(self.lib.gpb_logpost(self.h, nat.ptr(X_dev), X_dev.shape[0], nat.ptr(out), 1 if accumulate else 0,
+                                      nat.ptr(lo_dev), nat.ptr(hi_dev), float(outside), float(const)))
+        return out
+
     def mvn_loglike(self, dY, cov):
         """Batched mvn_loglike on explicit dY[W,M], cov[W,M,M] (numpy or torch cuda)."""
         npd = C.c_int(0)
@@ -214,6 +221,11 @@ class GPEngine:
     def force_tile(self, tile=0, switch_tiles=0):
         """test/tuning hook: k_predict tile size (0 auto, 64, 128)."""
         self._ck(self.lib.gpb_debug_force_tile(self.h, int(tile), int(switch_tiles)))
+
+    def tune(self, key, value):
+        """launch-geometry hook of the predict kernel: 'xcd', 'wgs64', 'waves', 'wgs128w8'."""
+        k = {"xcd": 0, "wgs64": 1, "waves": 2, "wgs128w8": 3}[key]
+        self._ck(self.lib.gpb_debug_tune(self.h, k, int(value)))
 
     def force_generic_mvn(self, on=True):
         """test hook: bypass the register-resident MVN fast path."""

@@ -154,12 +154,14 @@ class Chain:
         if lo_dev is None:
             lo_dev = torch.as_tensor(self.min, dtype=torch.float64, device=X_dev.device)
             hi_dev = torch.as_tensor(self.max, dtype=torch.float64, device=X_dev.device)
-        eng0 = None
-        for i, emu in enumerate(self.emuList):
+        X_dev = X_dev.contiguous()
+        last = len(self.emuList) - 1
+        for i, emu in enumerate(self.emuList):      # all engines enqueue on torch's current stream: ordered
             eng = emu._engine_ready()
-            eng.loglike(X_dev, out=out, accumulate=(i > 0), check=False)
-            eng0 = eng0 or eng      # all engines enqueue on torch's current stream: ordered
-        eng0.box_finish(X_dev, lo_dev, hi_dev, outside, EXTRA_STD_CONST, out)
+            if i < last:
+                eng.loglike(X_dev, out=out, accumulate=(i > 0), check=False)
+            else:                                    # last block: likelihood + prior box + constant, one call
+                eng.logpost(X_dev, out, i > 0, lo_dev, hi_dev, outside, EXTRA_STD_CONST)
         return out
 
     def _log_prob(self, X, outside):

@@ -122,6 +122,14 @@ int gpb_loglike(gpb_ctx* ctx, const double* Xs, int64_t W, int on_device,
                 double* ll /*[W], same memory space as Xs*/, int accumulate,
                 int* n_notpd_host /*may be NULL; forces a sync when non-NULL*/);
 
+/* gpb_logpost <- Chain.log_posterior / log_likelihood for the LAST (or only) emulator of a chain, all on the
+ *                device and asynchronous: block log-likelihood (added onto ll when accumulate != 0), then
+ *                inside = all(lo < x < hi) strictly; ll = inside ? ll + inside_const : outside_value
+ *                                                                       src/mcmc.py:188-222, 261-299 */
+int gpb_logpost(gpb_ctx* ctx, const double* Xs_dev /*[W,d]*/, int64_t W, double* ll_dev /*[W]*/, int accumulate,
+                const double* lo_dev /*[d]*/, const double* hi_dev /*[d]*/, double outside_value,
+                double inside_const);
+
 /* gpb_mvn_loglike <- map(mvn_loglike, dY, cov): generic batched form on caller-provided
  *                    dY[W,M], cov[W,M,M] (any covariance, e.g. from foreign emulators)   src/mcmc.py:23-65,293 */
 int gpb_mvn_loglike(gpb_ctx* ctx, const double* dY, const double* cov, int64_t W, int64_t M, int on_device,
@@ -170,6 +178,10 @@ int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K,
 /* test/tuning hook: force the tile size of the predict kernel (0 = automatic, 64, 128) and, when
  * switch_tiles > 0, the number of 128x128 tiles from which the automatic choice uses them. */
 int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
+/* tuning hook for the predict kernel's launch geometry (never changes results): key 0 = XCD affinity
+ * (-1 auto, 0 by walker tile, 1 by row block); 1 = persistent 64-tile workgroups per CU; 2 = waves per
+ * tile (4 or 8); 3 = persistent workgroups per CU of the 128-tile 8-wave variant. */
+int gpb_debug_tune(gpb_ctx* ctx, int key, int value);
 /* test hook: route gpb_loglike through the generic LDS/HBM Cholesky instead of the register-resident
  * fast path (PCA mode, M <= 64) so that both implementations can be checked against each other. */
 int gpb_debug_force_generic_mvn(gpb_ctx* ctx, int on);

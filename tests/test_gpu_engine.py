@@ -227,6 +227,8 @@ def test_predict_tile_sizes_are_bit_identical(eng):
         eng.set_theta(synth.fixed_theta(d, P)); eng.factor()
         Xs = rng.random((300, d))
         eng.force_tile(128); m1, v1 = eng.predict(Xs)
-        eng.force_tile(64); m2, v2 = eng.predict(Xs)
-        eng.force_tile(0)
-        assert np.array_equal(m1, m2) and np.array_equal(v1, v2)
+        for tile, waves in ((64, 4), (64, 8), (128, 8)):
+            eng.force_tile(tile); eng.tune("waves", waves)
+            m2, v2 = eng.predict(Xs)
+            assert np.array_equal(m1, m2) and np.array_equal(v1, v2), (tile, waves)
+        eng.force_tile(0); eng.tune("waves", 4)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""k_predict time vs walker-batch size and tile size (what a rank sees at 1/2/4/8-way sharding)."""
+"""k_predict / k_kcross time vs walker-batch size (what a rank sees at 1/2/4/8-way sharding)."""
 import json
 import os
 import sys
@@ -21,8 +21,11 @@ def main():
     for W in (128, 256, 512, 1024, 2048, 4096):
         Xs = torch.as_tensor(synth.walkers(W, d), device="cuda")
         row = {"W": W}
-        for tile, xcd in ((64, 0), (64, 1), (128, 0), (128, 1)):
-            eng.force_tile(tile, -11 - xcd)
+        for tile, waves, per_cu in ((64, 4, 4), (64, 8, 2), (64, 8, 3), (64, 8, 4), (128, 4, 2), (128, 8, 1),
+                                    (128, 8, 2)):
+            eng.force_tile(tile)
+            eng.tune("waves", waves)
+            eng.tune("wgs64" if tile == 64 else "wgs128w8", per_cu)
             for _ in range(2):
                 eng.predict(Xs)
             eng.profile(True)
@@ -30,8 +33,19 @@ def main():
                 eng.predict(Xs)
             n, ms, units = eng.profile_read()
             eng.profile(False)
-            row[f"t{tile}x{xcd}_ms"] = round(ms / n, 4)
-            row[f"t{tile}x{xcd}_tf"] = round(units / n * N * N / (ms / n * 1e-3) / 1e12, 1)
+            row[f"t{tile}w{waves}c{per_cu}"] = [round(ms / n, 4), round(units / n * N * N / (ms / n * 1e-3) / 1e12, 1)]
+        # whole predict call (kcross + predict + finalize) with the automatic choice
+        eng.force_tile(0)
+        eng.tune("waves", 4); eng.tune("wgs64", 4)
+        for _ in range(2):
+            eng.predict(Xs)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            eng.predict(Xs)
+        e1.record(); torch.cuda.synchronize()
+        row["predict_call_ms"] = round(e0.elapsed_time(e1) / 5, 4)
         print(json.dumps(row), flush=True)
 
 
