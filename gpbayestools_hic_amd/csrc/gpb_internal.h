@@ -74,7 +74,7 @@ struct gpb_ctx {
     int64_t mvn_ws_cap = 0;
     int* notpd = nullptr;          // device counter
     int num_cu = 256;               // multiprocessor count of the device
-    int wgs_per_cu64 = 4;           // persistent k_predict<64> workgroups per CU
+    int wgs_per_cu64 = 6;           // persistent k_predict<64> workgroups per CU
     int wgs_per_cu128w8 = 2;        // ... for the 128-tile, 8-wave variant
     int predict_waves = 4;          // waves per k_predict tile (4 or 8)
     unsigned* tile_counter = nullptr;   // device ticket counter of the k_predict work queue (never reset)

@@ -17,7 +17,10 @@ class Standardizer:
         self.mean_ = Y.mean(axis=0)
         self.var_ = Y.var(axis=0)
         self.scale_ = np.sqrt(self.var_)
-        self.scale_[self.scale_ == 0.0] = 1.0
+        # (numerically) constant columns keep their values: scale 1, as sklearn does
+        n, eps = Y.shape[0], np.finfo(np.float64).eps
+        constant = self.var_ <= n * eps * self.var_ + (n * self.mean_ * eps) ** 2
+        self.scale_[constant | (self.scale_ == 0.0)] = 1.0
         return (Y - self.mean_) / self.scale_
 
     def transform(self, Y):

@@ -222,6 +222,37 @@ def g5_chain(mcmc, Emulator):
     np.savez_compressed(os.path.join(OUT, "g5_chain.npz"), **out)
 
 
+def g7_param_pca(Emulator):
+    """parameterTrafoPCA=True (src/emulator.py:79-241, 492-551): 20 model parameters, three groups
+    replaced by principal components of zeta/s(T), eta/s(mu_B), y_loss(y_init)."""
+    N, d, M, npc = 96, 20, 4, 3
+    rng = np.random.default_rng(700)
+    lo = np.full(d, 0.1); hi = np.full(d, 1.0)
+    lo[[2, 3, 4]], hi[[2, 3, 4]] = 0.0, 2.0                   # yloss_2,4,6
+    lo[[12, 13, 14]], hi[[12, 13, 14]] = 0.01, 0.3            # eta_0,2,4
+    lo[15], hi[15] = 0.0, 0.2                                  # zeta_max
+    lo[16], hi[16] = 0.13, 0.3                                 # T_zeta0
+    lo[[17, 18]], hi[[17, 18]] = 0.01, 0.15                    # sigma_plus, sigma_minus
+    X = synth.lhs(N, d, seed=701, lo=lo, hi=hi)
+    U = (X - lo) / (hi - lo)
+    Y = synth.observables(U, M, seed=702)
+    tp, pf = os.path.join(_work, "ppca_train.pkl"), os.path.join(_work, "ppca_par.txt")
+    synth.write_training_pickle(tp, X, Y, np.full_like(Y, 0.01))
+    synth.write_parameter_file(pf, lo, hi)
+    emu = Emulator(training_set_path=tp, parameter_file=pf, npc=npc, parameterTrafoPCA=True)
+    emu.trainEmulatorAutoMask()
+    Xs = lo + (hi - lo) * rng.random((16, d))
+    mean, cov = emu.predict(Xs, return_cov=True, extra_std=np.zeros(16))
+    np.savez_compressed(
+        os.path.join(OUT, "g7_param_pca.npz"), lo=lo, hi=hi, X=X, Y=Y, npc=npc,
+        new_design_points=emu.PCA_new_design_points, design_min=emu.design_min, design_max=emu.design_max,
+        n_components=np.array([emu.paramTrafoPCA_bulk.n_components_, emu.paramTrafoPCA_shear.n_components_,
+                               emu.paramTrafoPCA_yloss.n_components_]),
+        thetas=np.array([gp.kernel_.theta for gp in emu.gps]),
+        lml=np.array([gp.log_marginal_likelihood_value_ for gp in emu.gps]),
+        Xs=Xs, mean=mean, cov=cov)
+
+
 def g6_mvn(mcmc):
     rng = np.random.default_rng(600)
     out = {}
@@ -245,6 +276,7 @@ def main():
     g3_g4_emulators(Emulator)
     g5_chain(mcmc, Emulator)
     g6_mvn(mcmc)
+    g7_param_pca(Emulator)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
