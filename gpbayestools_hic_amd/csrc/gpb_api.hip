@@ -97,8 +97,8 @@ extern "C" int gpb_ctx_create(int device, void* stream, gpb_ctx** out) {
     }
     if (hipMalloc(&ctx->notpd, sizeof(int)) != hipSuccess ||
         hipMemsetAsync(ctx->notpd, 0, sizeof(int), ctx->stream) != hipSuccess ||
-        hipMalloc(&ctx->tile_counter, sizeof(unsigned)) != hipSuccess ||
-        hipMemsetAsync(ctx->tile_counter, 0, sizeof(unsigned), ctx->stream) != hipSuccess) {
+        hipMalloc(&ctx->tile_counter, 129 * sizeof(unsigned)) != hipSuccess ||
+        hipMemsetAsync(ctx->tile_counter, 0, 129 * sizeof(unsigned), ctx->stream) != hipSuccess) {
         delete ctx;
         return GPB_E_ALLOC;
     }

@@ -153,26 +153,40 @@ __device__ __forceinline__ void predict_tile(TileLds<T>& lds, int b, const doubl
     }
 }
 
-// Persistent launch: `gridDim.x` workgroups (a few per CU) pull tile indices from one device-scope
-// ticket counter in LPT order, so the triangular row blocks balance dynamically whatever the
-// dispatcher does — with a plain grid of unequal tiles that are all resident at once (small walker
-// batches) the static placement left ~20 % of the chip idle behind the heaviest CUs.  The counter is
-// never reset: the host passes the running base (every launch consumes nblocks + gridDim.x tickets).
-// Exit condition: every workgroup eventually draws a ticket >= nblocks.
+// Persistent launch: `gridDim.x` workgroups (a few per CU) pull tile indices from device-scope ticket
+// queues in LPT order, so the triangular row blocks balance dynamically whatever the dispatcher does.
+// Exit condition: every workgroup walks all eight queues once and leaves each when its ticket is past
+// the queue's length; nothing spins.
 template <int T, int NW>
 __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 4)) void k_predict(const double* __restrict__ Linv, const double* __restrict__ KsT,
                                                      double* __restrict__ spart, int64_t Np, int64_t Wld, int P,
-                                                     int nI, int nW, int xcd_rows, unsigned* __restrict__ counter,
-                                                     unsigned base, unsigned nblocks) {
+                                                     int nI, int nW, int xcd_rows, unsigned* __restrict__ queue,
+                                                     unsigned nblocks) {
     __shared__ TileLds<T> lds;
     __shared__ unsigned s_ticket;
-    for (;;) {
-        if (threadIdx.x == 0) s_ticket = atomicAdd(counter, 1u) - base;
-        __syncthreads();
-        const unsigned b = s_ticket;
-        if (b >= nblocks) break;                // uniform
-        predict_tile<T, NW>(lds, (int)b, Linv, KsT, spart, Np, Wld, P, nI, nW, xcd_rows);
-        __syncthreads();                        // s_ticket and the LDS tiles are reused
+    // Eight ticket queues, one per XCD label (blockIdx % 8; workgroups with equal labels share an XCD's
+    // L2 under round-robin dispatch — speed only): queue x owns the tiles b = 8 t + x, i.e. a fixed set
+    // of walker tiles (or row blocks) whose operand panels stay in that XCD's L2 while its workgroups
+    // work through them in LPT order.  A workgroup whose own queue is empty steals from the others.
+    const int x = blockIdx.x & 7;
+    for (int s = 0; s < 8; ++s) {
+        const unsigned qx = (unsigned)((x + s) & 7);
+        const unsigned nq = (nblocks > qx) ? (nblocks - qx + 7u) / 8u : 0u;
+        for (;;) {
+            if (threadIdx.x == 0) s_ticket = atomicAdd(&queue[qx * 16], 1u);
+            __syncthreads();
+            const unsigned t = s_ticket;
+            __syncthreads();                    // everyone has read the ticket before it is redrawn
+            if (t >= nq) break;                 // uniform: this queue is exhausted
+            predict_tile<T, NW>(lds, (int)(t * 8u + qx), Linv, KsT, spart, Np, Wld, P, nI, nW, xcd_rows);
+        }
+    }
+    // the last workgroup to finish re-arms the queues for the next launch (all others are past their draws)
+    if (threadIdx.x == 0) {
+        if (atomicAdd(&queue[128], 1u) == gridDim.x - 1) {
+            for (int i = 0; i < 8; ++i) queue[i * 16] = 0u;
+            queue[128] = 0u;
+        }
     }
 }
 
@@ -269,11 +283,10 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var)
 #define GPB_PRED(TT, WW)                                                                                         \
     hipLaunchKernelGGL((k_predict<TT, WW>), dim3(grid), dim3(64 * WW), 0, ctx->stream, ctx->Linv, ctx->KsT,        \
                        ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW, xcd_rows, ctx->tile_counter,           \
-                       ctx->tile_base, (unsigned)nblocks)
+                       (unsigned)nblocks)
         if (T == 128) { if (nwv == 8) GPB_PRED(128, 8); else GPB_PRED(128, 4); }
         else          { if (nwv == 8) GPB_PRED(64, 8);  else GPB_PRED(64, 4); }
 #undef GPB_PRED
-        ctx->tile_base += (unsigned)nblocks + grid;      // tickets consumed by this launch (mod 2^32)
         if (ctx->profile) {
             GPB_HIP(hipEventRecord(e1, ctx->stream));
             ctx->prof_events.push_back({e0, e1});
