@@ -51,6 +51,49 @@ def cpu_baseline(info, emu, nrows):
                       f"per GP + per-row LAPACK MVN), {dt:.1f} s, numpy/scipy threaded BLAS"}, lp, Xw
 
 
+def extras(chain4, emu4, info4):
+    """The other two BASELINE metrics, measured on the same box (N=1 only): GP predict points/s on
+    BASELINE config 2 (1024 design pts x 15 params, 10 GPs, 10 000 test points) and the fixed-theta fit
+    (K build + Cholesky + L^-1 + alpha) expressed as Cholesky-equivalent GF/s (P N^3/3 flops / time)."""
+    import torch
+    from gpbayestools_hic_amd import synth
+    from gpbayestools_hic_amd.workload import build_chain
+
+    def timed(fn, reps):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    out = {}
+    _, emu2, info2 = build_chain(2)
+    eng2 = emu2._engine_ready()
+    Xs = torch.as_tensor(synth.walkers(10000, info2["d"]), device="cuda")
+    t = timed(lambda: eng2.predict(Xs), 5)
+    out["gp_predict_cfg2"] = {"points": 10000, "gps": info2["P"], "ms": t * 1e3, "points_per_s": 10000 / t,
+                              "what": "mean + variance of all 10 GPs per point, inputs/outputs resident in HBM"}
+    Xh = synth.walkers(10000, info2["d"])
+    t0 = time.perf_counter(); emu2.predict(Xh, return_cov=True, extra_std=0.0); th = time.perf_counter() - t0
+    out["emulator_predict_cfg2_host"] = {"points": 10000, "ms": th * 1e3, "points_per_s": 10000 / th,
+                                         "what": "Emulator.predict(return_cov=True): numpy in, mean[W,32] + cov[W,32,32] out (PCIe inclusive)"}
+    for tag, emu, info in (("cfg2", emu2, info2), ("cfg4", emu4, info4)):
+        eng = emu._engine_ready()
+        eng.factor(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            eng.factor()
+        torch.cuda.synchronize()
+        tf = (time.perf_counter() - t0) / 3
+        Nn, Pp = info["N"], info["P"]
+        out[f"fit_fixed_theta_{tag}"] = {"N": Nn, "gps": Pp, "ms": tf * 1e3,
+                                         "cholesky_equiv_gflops": Pp * Nn ** 3 / 3 / tf / 1e9,
+                                         "what": "K build + blocked Cholesky + L^-1 + alpha for all GPs; rate = P N^3/3 / time"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +102,7 @@ def main():
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--walkers", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=None)
     args = ap.parse_args()
 
@@ -122,6 +166,20 @@ def main():
                          "frac": (achieved / FP64_MFMA_PEAK_TFLOPS) if achieved else None, "traffic": None,
                          "launches": launches, "avg_launch_ms": kms / max(launches, 1)},
         }
+        # HBM-side traffic of the dominant kernel: PMC counters need rocprofv3, so the per-launch figure comes
+        # from the committed summary of the same command (profiles/r01_pmc_traffic.json), when it matches.
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            wl = pmc["workload"]
+            if (wl["config"], wl["N"], wl["P"], wl["W_per_launch"]) == (args.config, N, P, nwalkers // 2) and world == 1:
+                out["roofline"]["traffic"] = pmc["k_predict"]["bytes_per_launch_corrected"]
+                out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)"
+                out["roofline"]["algorithmic_bytes"] = pmc["k_predict"]["algorithmic_bytes_per_launch"]
+        except Exception:
+            pass
+        if world == 1 and not args.no_extras:
+            out["extras"] = extras(chain, emu, info)
         if world == 1 and not args.no_cpu_baseline:
             rows = args.cpu_rows or info["W"]
             cb, lp_cpu, Xw = cpu_baseline(info, emu, rows)

@@ -449,6 +449,7 @@ __global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, 
     const int64_t j = (int64_t)(((uint64_t)r.z * (uint64_t)nhalf) >> 32);
     const double* s = pos + (2 * k + half) * d;
     const double* c = pos + (2 * j + (1 - half)) * d;
+#pragma unroll 8
     for (int t = 0; t < d; ++t) q[k * d + t] = c[t] - (c[t] - s[t]) * zz;
     factor[k] = (d - 1.0) * log(zz);
 }
@@ -463,6 +464,7 @@ __global__ void k_accept(double* __restrict__ pos, double* __restrict__ lp, int6
     const int64_t idx = 2 * k + half;
     const double diff = factor[k] + lpq[k] - lp[idx];
     if (diff > log(u)) {                                             // emcee RedBlueMove.propose
+#pragma unroll 8
         for (int t = 0; t < d; ++t) pos[idx * d + t] = q[k * d + t];
         lp[idx] = lpq[k];
         if (naccept) naccept[idx] += 1;

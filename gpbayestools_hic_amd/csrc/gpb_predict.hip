@@ -198,10 +198,12 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ mpa
     const int p = blockIdx.y;
     if (w >= Wuse) return;
     double m = 0.0;
+#pragma unroll 8
     for (int c = 0; c < nchunk; ++c) m += mpart[((int64_t)c * P + p) * Wld + w];
     mean_pc[(int64_t)p * Wld + w] = m;
     if (need_var) {
         double s = 0.0;
+#pragma unroll 8
         for (int i = 0; i < nI64; ++i) s += spart[((int64_t)i * P + p) * Wld + w];
         var_pc[(int64_t)p * Wld + w] = (amp[p] + noise[p]) - s;
     }

@@ -66,6 +66,13 @@ class Chain:
         self.device = device
         self._like_sig = None
 
+    def __getstate__(self):                      # no device handles in pickles / forked workers
+        st = dict(self.__dict__)
+        st.pop("_box_dev", None)
+        st.pop("_box_key", None)
+        st["_like_sig"] = None
+        return st
+
     # ------------------------------------------------------------------ inputs
     def _read_in_exp_data_pickle(self, filepath):
         """One experimental event: values and errors; covariance = diag(err^2)
@@ -151,9 +158,13 @@ class Chain:
         self._prepare_blocks()
         if out is None:
             out = torch.empty(X_dev.shape[0], dtype=torch.float64, device=X_dev.device)
-        if lo_dev is None:
-            lo_dev = torch.as_tensor(self.min, dtype=torch.float64, device=X_dev.device)
-            hi_dev = torch.as_tensor(self.max, dtype=torch.float64, device=X_dev.device)
+        if lo_dev is None:                       # prior box resident in HBM, uploaded once per device
+            key = (str(X_dev.device), self.min.tobytes(), self.max.tobytes())
+            if getattr(self, "_box_key", None) != key:
+                self._box_dev = (torch.as_tensor(self.min, dtype=torch.float64, device=X_dev.device),
+                                 torch.as_tensor(self.max, dtype=torch.float64, device=X_dev.device))
+                self._box_key = key
+            lo_dev, hi_dev = self._box_dev
         X_dev = X_dev.contiguous()
         last = len(self.emuList) - 1
         for i, emu in enumerate(self.emuList):      # all engines enqueue on torch's current stream: ordered
