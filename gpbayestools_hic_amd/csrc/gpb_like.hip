@@ -437,18 +437,54 @@ __device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {   // 53-bit un
     return (double)b * (1.0 / 9007199254740992.0);
 }
 
-// halves: walker k of half h is index 2k+h (emcee inds = arange(nwalkers) % 2 without shuffling)
+// ---- red/blue split ----------------------------------------------------------------------------------
+// emcee's RedBlueMove shuffles which walkers form the two halves at every step (randomize_split=True,
+// its default).  Here the shuffle is a keyed pseudo-random permutation pi_step of [0, n) that every
+// thread (and every rank) can evaluate for a single index without communication or sorting: a 4-round
+// Feistel network on 2*hb >= log2(n) bits with cycle walking.  Walker k of half h is pi(2k + h); with
+// randomize = 0, pi is the identity (emcee's inds = arange(n) % 2).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+struct SplitPerm {
+    uint32_t n, hb, k0, k1, on;
+    __device__ __forceinline__ int64_t operator()(int64_t i) const {
+        if (!on) return i;
+        const uint32_t mask = (1u << hb) - 1u;
+        uint32_t x = (uint32_t)i;
+        do {
+            uint32_t L = x >> hb, R = x & mask;
+#pragma unroll
+            for (uint32_t r = 0; r < 4; ++r) {
+                const uint32_t F = mix32(R ^ (k0 + r * 0x9E3779B9u)) ^ mix32(k1 + r);
+                const uint32_t t = L ^ (F & mask);
+                L = R;
+                R = t;
+            }
+            x = (L << hb) | R;
+        } while (x >= n);                      // cycle walking keeps it a bijection on [0, n)
+        return (int64_t)x;
+    }
+};
+__device__ __forceinline__ SplitPerm make_perm(uint64_t seed, uint32_t step, int64_t n, int hb, int randomize) {
+    const U4 k = philox(seed, 0xFFFFFFFFu, step, 0u, 7u);
+    return SplitPerm{(uint32_t)n, (uint32_t)hb, k.x, k.y, (uint32_t)randomize};
+}
+
 __global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, int half, uint64_t seed,
-                          uint32_t step, double a, double* __restrict__ q, double* __restrict__ factor) {
+                          uint32_t step, double a, double* __restrict__ q, double* __restrict__ factor, int hb,
+                          int randomize) {
     const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (k >= nhalf) return;
+    const SplitPerm pi = make_perm(seed, step, 2 * nhalf, hb, randomize);
     const U4 r = philox(seed, (uint32_t)k, step, (uint32_t)half, 0u);
     const double u = u01(r.x, r.y);
     const double zs = (a - 1.0) * u + 1.0;
     const double zz = zs * zs / a;                                   // emcee StretchMove.get_proposal
     const int64_t j = (int64_t)(((uint64_t)r.z * (uint64_t)nhalf) >> 32);
-    const double* s = pos + (2 * k + half) * d;
-    const double* c = pos + (2 * j + (1 - half)) * d;
+    const double* s = pos + pi(2 * k + half) * d;
+    const double* c = pos + pi(2 * j + (1 - half)) * d;
 #pragma unroll 8
     for (int t = 0; t < d; ++t) q[k * d + t] = c[t] - (c[t] - s[t]) * zz;
     factor[k] = (d - 1.0) * log(zz);
@@ -456,12 +492,13 @@ __global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, 
 __global__ void k_accept(double* __restrict__ pos, double* __restrict__ lp, int64_t nhalf, int d, int half,
                          uint64_t seed, uint32_t step, const double* __restrict__ q,
                          const double* __restrict__ factor, const double* __restrict__ lpq,
-                         long long* __restrict__ naccept) {
+                         long long* __restrict__ naccept, int hb, int randomize) {
     const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (k >= nhalf) return;
+    const SplitPerm pi = make_perm(seed, step, 2 * nhalf, hb, randomize);
     const U4 r = philox(seed, (uint32_t)k, step, (uint32_t)half, 1u);
     const double u = u01(r.x, r.y);
-    const int64_t idx = 2 * k + half;
+    const int64_t idx = pi(2 * k + half);
     const double diff = factor[k] + lpq[k] - lp[idx];
     if (diff > log(u)) {                                             // emcee RedBlueMove.propose
 #pragma unroll 8
@@ -469,6 +506,19 @@ __global__ void k_accept(double* __restrict__ pos, double* __restrict__ lp, int6
         lp[idx] = lpq[k];
         if (naccept) naccept[idx] += 1;
     }
+}
+
+// test hook: out[i] = pi_step(i)
+__global__ void k_perm(long long* __restrict__ out, int64_t n, uint64_t seed, uint32_t step, int hb) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = make_perm(seed, step, n, hb, 1)(i);
+}
+
+static int half_bits(int64_t n) {
+    int b = 1;
+    while ((1ll << b) < n) ++b;
+    return (b + 1) / 2;
 }
 
 }  // namespace gpb
@@ -487,23 +537,35 @@ extern "C" int gpb_box_finish(gpb_ctx* ctx, const double* X_dev, int64_t W, cons
 }
 
 extern "C" int gpb_stretch_propose(gpb_ctx* ctx, const double* pos_dev, int64_t nwalkers, int64_t d, int half,
-                                   uint64_t seed, uint64_t step, double a, double* q_dev, double* factor_dev) {
-    if (!ctx || nwalkers < 2 || (nwalkers & 1) || d < 1 || (half != 0 && half != 1)) return GPB_E_ARG;
+                                   uint64_t seed, uint64_t step, double a, double* q_dev, double* factor_dev,
+                                   int randomize_split) {
+    if (!ctx || nwalkers < 2 || (nwalkers & 1) || nwalkers > (1ll << 30) || d < 1 || (half != 0 && half != 1))
+        return GPB_E_ARG;
     const int64_t nh = nwalkers / 2;
     hipLaunchKernelGGL(k_propose, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev, nh, (int)d,
-                       half, seed, (uint32_t)step, a, q_dev, factor_dev);
+                       half, seed, (uint32_t)step, a, q_dev, factor_dev, half_bits(nwalkers), randomize_split ? 1 : 0);
     GPB_HIP(hipGetLastError());
     return 0;
 }
 
 extern "C" int gpb_stretch_accept(gpb_ctx* ctx, double* pos_dev, double* lp_dev, int64_t nwalkers, int64_t d,
                                   int half, uint64_t seed, uint64_t step, const double* q_dev,
-                                  const double* factor_dev, const double* lpq_dev, int64_t* naccept_dev) {
-    if (!ctx || nwalkers < 2 || (nwalkers & 1) || d < 1 || (half != 0 && half != 1)) return GPB_E_ARG;
+                                  const double* factor_dev, const double* lpq_dev, int64_t* naccept_dev,
+                                  int randomize_split) {
+    if (!ctx || nwalkers < 2 || (nwalkers & 1) || nwalkers > (1ll << 30) || d < 1 || (half != 0 && half != 1))
+        return GPB_E_ARG;
     const int64_t nh = nwalkers / 2;
     hipLaunchKernelGGL(k_accept, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev, lp_dev, nh,
                        (int)d, half, seed, (uint32_t)step, q_dev, factor_dev, lpq_dev,
-                       reinterpret_cast<long long*>(naccept_dev));
+                       reinterpret_cast<long long*>(naccept_dev), half_bits(nwalkers), randomize_split ? 1 : 0);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gpb_test_split_perm(gpb_ctx* ctx, int64_t n, uint64_t seed, uint64_t step, int64_t* out_dev) {
+    if (!ctx || n < 2 || n > (1ll << 30) || !out_dev) return GPB_E_ARG;
+    hipLaunchKernelGGL(k_perm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<long long*>(out_dev), n, seed, (uint32_t)step, half_bits(n));
     GPB_HIP(hipGetLastError());
     return 0;
 }

@@ -25,7 +25,7 @@ log = logging.getLogger(__name__)
 
 class StretchSampler:
     def __init__(self, chain, nwalkers, seed=None, a=2.0, logprob_device=None, sharding=None,
-                 device=None):
+                 device=None, randomize_split=True):
         """chain: object with .min/.max/.ndim and log_prob_device(X_dev, out) (mcmc.Chain).
         logprob_device: optional override f(X_dev, out_dev) -> out_dev.
         sharding: optional dist.WalkerSharding (one process per GPU)."""
@@ -39,6 +39,7 @@ class StretchSampler:
         if self.nwalkers < 2 * self.ndim:
             log.warning("fewer walkers than 2*ndim")
         self.a = float(a)
+        self.randomize_split = 1 if randomize_split else 0      # emcee's RedBlueMove default is True
         self.seed = int(np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0]) if seed is None \
             else int(seed)
         self.device = torch.device("cuda", chain.device if device is None else device)
@@ -99,11 +100,11 @@ class StretchSampler:
             self._step_counter += 1
             for half in (0, 1):
                 eng._ck(lib.gpb_stretch_propose(h, nat.ptr(self.pos), nw, d, half, self.seed, step, self.a,
-                                                nat.ptr(self.q), nat.ptr(self.factor)))
+                                                nat.ptr(self.q), nat.ptr(self.factor), self.randomize_split))
                 self._eval(self.q, self.lpq)
                 eng._ck(lib.gpb_stretch_accept(h, nat.ptr(self.pos), nat.ptr(self.lp), nw, d, half, self.seed,
                                                step, nat.ptr(self.q), nat.ptr(self.factor), nat.ptr(self.lpq),
-                                               nat.ptr(self.naccept)))
+                                               nat.ptr(self.naccept), self.randomize_split))
             if store:
                 cd[n - 1].copy_(self.pos)
                 ld[n - 1].copy_(self.lp)

@@ -147,18 +147,21 @@ int gpb_box_finish(gpb_ctx* ctx, const double* X_dev /*[W,d]*/, int64_t W,
  * Replaces emcee.EnsembleSampler.sample as driven by LoggingEnsembleSampler.run_mcmc
  * (src/mcmc.py:68-92,372-412): red/blue stretch move, a=2, counter-based Philox RNG
  * replicated on every rank.
- * gpb_stretch_propose: for the walkers of half `half` (walker k of the half is index 2k+half,
- *   i.e. emcee's inds = arange(nwalkers) % 2) draw the complementary walker and z, write
- *   proposals q[nhalf,d] and the (d-1) ln z factor[nhalf].
+ * gpb_stretch_propose: for the walkers of half `half` draw the complementary walker and z, write
+ *   proposals q[nhalf,d] and the (d-1) ln z factor[nhalf].  Walker k of the half is index pi(2k+half):
+ *   pi = identity when randomize_split = 0 (emcee inds = arange(n) % 2), else a per-step keyed
+ *   pseudo-random permutation (emcee's default randomize_split=True), evaluated inline on every rank.
  * gpb_stretch_accept: accept where (d-1)*ln z + lp' - lp > ln u; updates pos, lp, naccept.
  */
 int gpb_stretch_propose(gpb_ctx* ctx, const double* pos_dev /*[nw,d]*/, int64_t nwalkers, int64_t d,
                         int half, uint64_t seed, uint64_t step, double a,
-                        double* q_dev /*[nw/2,d]*/, double* factor_dev /*[nw/2]*/);
+                        double* q_dev /*[nw/2,d]*/, double* factor_dev /*[nw/2]*/, int randomize_split);
 int gpb_stretch_accept(gpb_ctx* ctx, double* pos_dev, double* lp_dev /*[nw]*/, int64_t nwalkers, int64_t d,
                        int half, uint64_t seed, uint64_t step,
                        const double* q_dev, const double* factor_dev, const double* lpq_dev /*[nw/2]*/,
-                       int64_t* naccept_dev /*[nw]*/);
+                       int64_t* naccept_dev /*[nw]*/, int randomize_split);
+/* test hook: out_dev[i] = pi_step(i), the keyed permutation that shuffles the red/blue split */
+int gpb_test_split_perm(gpb_ctx* ctx, int64_t n, uint64_t seed, uint64_t step, int64_t* out_dev);
 
 /* ---- walker sharding over RCCL (one process per GPU) ------------------------------ *
  * gpb_dist_uid: rank 0 obtains a 128-byte ncclUniqueId to broadcast out of band.

@@ -112,3 +112,23 @@ def test_log_posterior_is_batch_independent(tmp_path):
     full = ch.log_posterior(X)
     for sl in (slice(0, 1), slice(3, 40), slice(40, 64)):
         assert np.array_equal(ch.log_posterior(X[sl]), full[sl], equal_nan=True)
+
+
+def test_split_permutation_is_a_bijection_and_changes_per_step():
+    import torch
+    from gpbayestools_hic_amd import GPEngine, _native as nat
+    eng = GPEngine(0)
+    for n in (2, 6, 64, 100, 4096, 5000):
+        outs = []
+        for step in (0, 1, 2):
+            out = torch.empty(n, dtype=torch.int64, device="cuda")
+            eng._ck(eng.lib.gpb_test_split_perm(eng.h, n, 99, step, nat.ptr(out)))
+            p = out.cpu().numpy()
+            assert np.array_equal(np.sort(p), np.arange(n)), (n, step)
+            outs.append(p)
+        if n >= 64:
+            assert not np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[1], outs[2])
+            # the induced halves look random: about half of the even positions land on even walkers
+            frac = np.mean(outs[0][0::2] % 2 == 0)
+            assert 0.3 < frac < 0.7
+    eng.close()
