@@ -145,6 +145,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     acc = float(sampler.acceptance_fraction.mean())
+    consistent = None
+    if world > 1:       # replicated RNG + gathered log-probabilities: every rank must hold the same ensemble
+        chk = torch.stack([sampler.pos.sum(), sampler.lp.sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        consistent = bool(torch.equal(lo, hi))
 
     if rank == 0:
         value = nwalkers * args.steps / dt
@@ -159,7 +166,7 @@ def main():
                                    f"{P} GPs ({info['kernel']}), {nwalkers} walkers, stretch move, "
                                    f"fixed hyper-parameters", "walkers": nwalkers,
                        "parallelism": f"walker-shard x{world}" if world > 1 else "single GPU"},
-            "acceptance_fraction": acc,
+            "acceptance_fraction": acc, "ranks_hold_identical_ensemble": consistent,
             "gflop_per_step_algorithmic": flops_per_walker(N, d, P, M, info["kernel"]) * nwalkers / 1e9,
             "roofline": {"bound": "mfma", "kernel": "k_predict (V = L^-1 K*^T, fused sum of squares)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -78,6 +78,7 @@ struct gpb_ctx {
     int wgs_per_cu128w8 = 2;        // ... for the 128-tile, 8-wave variant
     int predict_waves = 4;          // waves per k_predict tile (4 or 8)
     unsigned* tile_counter = nullptr;   // 8 ticket queues (stride 16) + done counter [128]; re-armed by the kernel
+    int64_t chol_outer = 256;       // outer panel width of the two-level blocked Cholesky
     int force_tile = 0;            // test hook: 0 = auto, 64 / 128 = force the k_predict tile size
     int force_xcd = -1;             // tuning hook: -1 auto, 0 / 1 = k_predict XCD affinity by walker tile / row block
     int64_t tile_switch = 1280;     // use 128x128 tiles when at least this many of them exist

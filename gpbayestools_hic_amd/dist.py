@@ -24,8 +24,10 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:     # GPB_DIST_BACKEND=gloo rehearses the N>1 path with several ranks on ONE GPU
+            backend = os.environ.get("GPB_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            local = local % max(torch.cuda.device_count(), 1)
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world,
@@ -56,6 +58,15 @@ class WalkerSharding:
         import torch
         W = X.shape[0]
         r0, r1, chunk = self.rows(W)
+        if self.world > 1 and X.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            # rehearsal only (several ranks sharing one GPU, gloo has no CUDA all-gather): stage through the host
+            local = torch.zeros(chunk, dtype=out.dtype, device=X.device)
+            if r1 > r0:
+                fn(X[r0:r1], local[:r1 - r0])
+            gathered = torch.empty(chunk * self.world, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(gathered, local.cpu(), group=self.group)
+            out.copy_(gathered[:W])
+            return out
         if self.world > 1 and W == chunk * self.world and out.is_contiguous():
             # even split: every rank writes its slice of `out` and the all-gather runs in place
             # (send buffer = receive buffer + rank*chunk) — no staging copies on the step's critical path
