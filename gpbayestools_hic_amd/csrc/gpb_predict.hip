@@ -88,27 +88,10 @@ __global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, i
 // chains, lane groups, then the two halves of each 64-row block — so both tile sizes, and therefore any
 // sharding of the walkers, give bit-identical sums.  spart is indexed by 64-row block.
 template <int T, int NW>
-__device__ __forceinline__ void predict_tile(TileLds<T>& lds, int b, const double* __restrict__ Linv,
+__device__ __forceinline__ void predict_tile(TileLds<T>& lds, int p, int ib, int wt, const double* __restrict__ Linv,
                                              const double* __restrict__ KsT, double* __restrict__ spart, int64_t Np,
-                                             int64_t Wld, int P, int nI, int nW, int xcd_rows) {
+                                             int64_t Wld, int P) {
     constexpr int NI = T / 32, WN = NW / 2, TN = T / WN, NJ = TN / 16;
-    // Tile order: heaviest row blocks of every GP first (LPT).  XCD affinity (blocks b and b+8 share an
-    // XCD's L2 under round-robin dispatch; speed only, never correctness):
-    //   xcd_rows = 1 (small W: L^-1 is the big operand): the nW walker tiles of one (row block, GP) group
-    //                run on ONE XCD, so each L^-1 row block is fetched from HBM once;
-    //   xcd_rows = 0 (large W: K*^T is the big operand): b % 8 == wt % 8, each XCD keeps its own K*^T columns.
-    int g, wt;
-    if (xcd_rows) {
-        const int q = b >> 3;
-        g = (q / nW) * 8 + (b & 7);
-        wt = q % nW;
-        if (g >= nI * P) return;             // whole workgroup exits together (grid padded to 8 groups)
-    } else {
-        g = b / nW;
-        wt = b - g * nW;
-    }
-    const int ib = nI - 1 - g / P;
-    const int p = g - (g / P) * P;
     const int64_t mb = (int64_t)ib * T, nb = (int64_t)wt * T;
     const int m_ext = (int)imin64(T, Np - mb);
     const int64_t k_end = imin64(mb + T, Np);
@@ -160,7 +143,7 @@ __device__ __forceinline__ void predict_tile(TileLds<T>& lds, int b, const doubl
 template <int T, int NW>
 __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 4)) void k_predict(const double* __restrict__ Linv, const double* __restrict__ KsT,
                                                      double* __restrict__ spart, int64_t Np, int64_t Wld, int P,
-                                                     int nI, int nW, int xcd_rows, unsigned* __restrict__ queue,
+                                                     int nI, int nW, int xcd_mode, unsigned* __restrict__ queue,
                                                      unsigned nblocks) {
     __shared__ TileLds<T> lds;
     __shared__ unsigned s_ticket;
@@ -168,17 +151,45 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 4)) void k_predict(const do
     // L2 under round-robin dispatch — speed only): queue x owns the tiles b = 8 t + x, i.e. a fixed set
     // of walker tiles (or row blocks) whose operand panels stay in that XCD's L2 while its workgroups
     // work through them in LPT order.  A workgroup whose own queue is empty steals from the others.
+    // Tile -> queue maps (xcd_mode), all heaviest-row-block-first within a queue:
+    //   0: queue = walker tile % 8   (each XCD keeps its own K*^T columns; all GPs interleaved)
+    //   1: queue = (row block, GP) group % 8   (small W: each L^-1 row block is fetched by one XCD)
+    //   2: queue = GP % 8: an XCD works through ONE GP at a time, so the ~64 tiles it has in flight share
+    //      4 L^-1 row panels and 16 K*^T column panels instead of ~32 + ~20 (L2 hit rate, fabric traffic)
     const int x = blockIdx.x & 7;
     for (int s = 0; s < 8; ++s) {
         const unsigned qx = (unsigned)((x + s) & 7);
-        const unsigned nq = (nblocks > qx) ? (nblocks - qx + 7u) / 8u : 0u;
+        unsigned nq;
+        if (xcd_mode == 2) nq = ((unsigned)P > qx) ? (((unsigned)P - qx + 7u) / 8u) * (unsigned)(nI * nW) : 0u;
+        else               nq = (nblocks > qx) ? (nblocks - qx + 7u) / 8u : 0u;
         for (;;) {
             if (threadIdx.x == 0) s_ticket = atomicAdd(&queue[qx * 16], 1u);
             __syncthreads();
             const unsigned t = s_ticket;
             __syncthreads();                    // everyone has read the ticket before it is redrawn
             if (t >= nq) break;                 // uniform: this queue is exhausted
-            predict_tile<T, NW>(lds, (int)(t * 8u + qx), Linv, KsT, spart, Np, Wld, P, nI, nW, xcd_rows);
+            int p, ib, wt;
+            if (xcd_mode == 2) {
+                const int j = (int)t / (nI * nW), rem = (int)t - j * (nI * nW);
+                p = (int)qx + 8 * j;
+                ib = nI - 1 - rem / nW;
+                wt = rem % nW;
+            } else {
+                const int b = (int)(t * 8u + qx);
+                int g;
+                if (xcd_mode == 1) {
+                    const int q = b >> 3;
+                    g = (q / nW) * 8 + (b & 7);
+                    wt = q % nW;
+                    if (g >= nI * P) continue;  // padding of the last group of eight (uniform)
+                } else {
+                    g = b / nW;
+                    wt = b - g * nW;
+                }
+                ib = nI - 1 - g / P;
+                p = g - (g / P) * P;
+            }
+            predict_tile<T, NW>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P);
         }
     }
     // the last workgroup to finish re-arms the queues for the next launch (all others are past their draws)
@@ -275,9 +286,9 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var)
         const int nI = (T == 128) ? (int)((ctx->Np + 127) / 128) : nI64, nW = (int)(Wuse / T);
         // which operand is larger decides the XCD affinity: L^-1 (P Np^2/2) or K*^T (P Np W)
         int xcd_rows = (2 * Wuse < ctx->Np) ? 1 : 0;
-        if (ctx->force_xcd >= 0) xcd_rows = ctx->force_xcd;
+        if (ctx->force_xcd >= 0) xcd_rows = ctx->force_xcd;      // 0, 1 or 2 (GP-affine)
         const int64_t ngroups = (int64_t)ctx->P * nI;
-        const int64_t nblocks = xcd_rows ? ((ngroups + 7) / 8) * 8 * nW : ngroups * nW;
+        const int64_t nblocks = (xcd_rows == 1) ? ((ngroups + 7) / 8) * 8 * nW : ngroups * nW;
         const int nwv = ctx->predict_waves;             // 4 or 8 waves per tile
         const int per_cu = (T == 128) ? (nwv == 8 ? ctx->wgs_per_cu128w8 : 2) : ctx->wgs_per_cu64;
         const int64_t slots = (int64_t)ctx->num_cu * per_cu;

@@ -231,4 +231,11 @@ def test_predict_tile_sizes_are_bit_identical(eng):
             eng.force_tile(tile); eng.tune("waves", waves)
             m2, v2 = eng.predict(Xs)
             assert np.array_equal(m1, m2) and np.array_equal(v1, v2), (tile, waves)
-        eng.force_tile(0); eng.tune("waves", 4)
+        eng.tune("waves", 4)
+        for xcd in (0, 1, 2):                             # tile -> XCD queue maps only reorder the work
+            eng.tune("xcd", xcd)
+            for tile in (64, 128):
+                eng.force_tile(tile)
+                m2, v2 = eng.predict(Xs)
+                assert np.array_equal(m1, m2) and np.array_equal(v1, v2), (tile, xcd)
+        eng.force_tile(0); eng.tune("xcd", -1)

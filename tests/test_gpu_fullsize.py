@@ -1,0 +1,96 @@
+"""
+GPU tier at BASELINE full sizes (config 4: N=2048, d=20, P=10 -> here P=3 to keep host memory small;
+config 5 kernel: Matern-5/2 at N=4096): size-independent properties instead of an oracle run.
+  * factorisation residual  K v == L (L^T v)  on random probes, L^-1 L == I on probes
+  * GP identity at the training points:  mean(x_i) = z_i - (sigma_n^2 + alpha) * alpha_i   (K alpha = z)
+  * 0 < var <= prior, var at training points equals  prior - [K_ii' - 2 s + s^2 (K^-1)_ii]
+  * linearity of alpha and of the predictive mean in the training targets
+  * bit-identical results for any batch split
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(eng, N, d, P, kernel, seed):
+    from gpbayestools_hic_amd import synth
+    rng = np.random.default_rng(seed)
+    X = synth.lhs(N, d, seed=seed)
+    Z = np.sin(X @ rng.standard_normal((d, P))).T + 0.05 * rng.standard_normal((P, N))
+    th = synth.fixed_theta(d, P) + 0.1 * rng.standard_normal((P, d + 2))
+    eng.set_data(X, Z, kernel, alpha=0.1)
+    eng.set_theta(th)
+    eng.factor()
+    return X, Z, th
+
+
+@pytest.mark.parametrize("N,d,kernel", [(2048, 20, "RBF"), (4096, 20, "Matern25")])
+def test_fullsize_factor_and_predict_properties(N, d, kernel):
+    from gpbayestools_hic_amd import GPEngine
+    from oracle import gp_oracle as O
+    P = 2
+    eng = GPEngine(0)
+    X, Z, th = _setup(eng, N, d, P, kernel, seed=N)
+    rng = np.random.default_rng(1)
+    L = eng.get("L"); Linv = eng.get("Linv"); alpha = eng.get("alpha")
+    kid = O.KIND_NAMES[kernel]
+    for p in range(P):
+        K = O.kernel_train(X, th[p], kid, 0.1)                      # oracle kernel matrix only (cheap, elementwise)
+        v = rng.standard_normal((N, 4))
+        assert np.max(np.abs(L[p] @ (L[p].T @ v) - K @ v)) < 1e-11 * np.max(np.abs(K @ v))
+        assert np.max(np.abs(Linv[p] @ (L[p] @ v) - v)) < 1e-10 * np.max(np.abs(v))
+        assert np.max(np.abs(K @ alpha[p] - Z[p])) < 1e-10 * np.max(np.abs(Z[p]))
+    idx = rng.choice(N, 300, replace=False)
+    m, var = eng.predict(X[idx])
+    for p in range(P):
+        c, noise = np.exp(th[p, 0]), np.exp(th[p, -1])
+        s = noise + 0.1
+        assert np.max(np.abs(m[:, p] - (Z[p, idx] - s * alpha[p, idx]))) < 1e-10 * np.max(np.abs(Z[p]))
+        kinv_ii = np.einsum("ki,ki->i", Linv[p][:, idx], Linv[p][:, idx])
+        expect = (c + noise) - ((c + s) - 2 * s + s * s * kinv_ii)
+        assert np.max(np.abs(var[:, p] - expect) / np.abs(expect)) < 1e-9
+        assert np.all(var[:, p] > 0) and np.all(var[:, p] <= c + noise)
+    Xs = rng.random((1000, d))
+    m1, v1 = eng.predict(Xs)
+    assert np.all(v1 > 0)
+    for sl in (slice(0, 1), slice(17, 400), slice(400, 1000)):
+        ms, vs = eng.predict(Xs[sl])
+        assert np.array_equal(ms, m1[sl]) and np.array_equal(vs, v1[sl])
+    eng.close()
+
+
+def test_fullsize_linearity_in_targets():
+    from gpbayestools_hic_amd import GPEngine, synth
+    N, d = 2048, 20
+    rng = np.random.default_rng(5)
+    X = synth.lhs(N, d, seed=9)
+    z1, z2 = rng.standard_normal(N), rng.standard_normal(N)
+    eng = GPEngine(0)
+    eng.set_data(X, np.stack([z1, z2, 2.0 * z1 - 0.5 * z2]), "RBF", 0.1)
+    eng.set_theta(synth.fixed_theta(d, 3)); eng.factor()
+    a = eng.get("alpha")
+    assert np.max(np.abs(a[2] - (2.0 * a[0] - 0.5 * a[1]))) < 1e-11 * np.max(np.abs(a))
+    Xs = rng.random((500, d))
+    m, v = eng.predict(Xs)
+    assert np.max(np.abs(m[:, 2] - (2.0 * m[:, 0] - 0.5 * m[:, 1]))) < 1e-11 * np.max(np.abs(m))
+    assert np.array_equal(v[:, 0], v[:, 1]) and np.array_equal(v[:, 0], v[:, 2])   # variance ignores the targets
+    eng.close()
+
+
+def test_fullsize_log_posterior_cfg4_against_oracle_sample():
+    """cfg 4 end to end (N=2048, d=20, M=64, P=10): 48 rows against the oracle (seconds on the host)."""
+    from gpbayestools_hic_amd import synth
+    from gpbayestools_hic_amd.workload import build_chain
+    from oracle import gp_oracle as O
+    chain, emu, info = build_chain(4)
+    d, P = info["d"], info["P"]
+    oe = O.OracleEmulator(info["X"], info["Y"], info["lo"], info["hi"], P).fit(synth.fixed_theta(d, P))
+    Xw = synth.walkers(48, d, seed=77)
+    Xw[5, 3] = 1.5; Xw[9, 0] = 0.0                                   # outside / on the boundary
+    yexp = info["yexp"]; cexp = np.diag((0.05 * np.abs(yexp)) ** 2)
+    ref = O.log_prob(Xw, info["lo"], info["hi"], lambda x, e: oe.predict(x, True, e), yexp, cexp)
+    got = chain.log_posterior(Xw)
+    ins = np.isfinite(ref)
+    assert np.array_equal(np.isneginf(got), ~ins) and ins.sum() == 46
+    assert np.max(np.abs(got[ins] - ref[ins]) / np.abs(ref[ins])) < 1e-10

@@ -21,10 +21,9 @@ def main():
     for W in (128, 256, 512, 1024, 2048):
         Xs = torch.as_tensor(synth.walkers(W, d), device="cuda")
         row = {"W": W}
-        for tile, waves, per_cu in ((64, 4, 3), (64, 4, 4), (64, 4, 6), (64, 4, 8), (128, 4, 2)):
+        for tile, xcd in ((64, 0), (64, 1), (64, 2), (128, 0), (128, 1), (128, 2)):
             eng.force_tile(tile)
-            eng.tune("waves", waves)
-            eng.tune("wgs64" if tile == 64 else "wgs128w8", per_cu)
+            eng.tune("xcd", xcd)
             for _ in range(2):
                 eng.predict(Xs)
             eng.profile(True)
@@ -32,7 +31,8 @@ def main():
                 eng.predict(Xs)
             n, ms, units = eng.profile_read()
             eng.profile(False)
-            row[f"t{tile}w{waves}c{per_cu}"] = [round(ms / n, 4), round(units / n * N * N / (ms / n * 1e-3) / 1e12, 1)]
+            row[f"t{tile}x{xcd}"] = [round(ms / n, 4), round(units / n * N * N / (ms / n * 1e-3) / 1e12, 1)]
+        eng.tune("xcd", -1)
         # whole predict call (kcross + predict + finalize) with the automatic choice
         eng.force_tile(0)
         eng.tune("waves", 4); eng.tune("wgs64", 6)
