@@ -36,6 +36,7 @@ PROTOTYPES = {
     "gpb_gp_get": (C.c_int, [VP, C.c_int, VP]),
     "gpb_gp_lml": (C.c_int, [VP, VP, VP, VP, VP]),
     "gpb_gp_predict": (C.c_int, [VP, VP, c_i64, C.c_int, VP, VP]),
+    "gpb_gp_predict_cov": (C.c_int, [VP, VP, c_i64, C.c_int, VP, VP]),
     "gpb_emu_set_transform": (C.c_int, [VP, C.c_int, c_i64, VP, VP, VP, VP]),
     "gpb_emu_predict": (C.c_int, [VP, VP, c_i64, C.c_int, VP, VP, VP]),
     "gpb_like_set": (C.c_int, [VP, VP, VP]),

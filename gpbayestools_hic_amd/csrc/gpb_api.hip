@@ -120,6 +120,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     dev_free(&ctx->alpha); dev_free(&ctx->apart); dev_free(&ctx->info); dev_free(&ctx->lmlbuf);
     dev_free(&ctx->gpart); dev_free(&ctx->Xs); dev_free(&ctx->estd); dev_free(&ctx->KsT); dev_free(&ctx->mpart);
     dev_free(&ctx->spart); dev_free(&ctx->mean_pc); dev_free(&ctx->var_pc); dev_free(&ctx->out_stage);
+    dev_free(&ctx->vbuf); dev_free(&ctx->covbuf);
     dev_free(&ctx->A); dev_free(&ctx->mu); dev_free(&ctx->scale); dev_free(&ctx->C0); dev_free(&ctx->yexp);
     dev_free(&ctx->Cexp); dev_free(&ctx->mvn_ws); dev_free(&ctx->notpd); dev_free(&ctx->tile_counter);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -323,6 +324,34 @@ extern "C" int gpb_gp_predict(gpb_ctx* ctx, const double* Xs, int64_t W, int on_
         hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->var_pc, ctx->out_stage + W * P, W, ctx->Wcap, (int)P);
         GPB_HIP(hipMemcpyAsync(var, ctx->out_stage + W * P, sizeof(double) * W * P, hipMemcpyDeviceToHost, ctx->stream));
     }
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int gpb_gp_predict_cov(gpb_ctx* ctx, const double* Xs, int64_t W, int on_device, double* mean,
+                                  double* cov) {
+    if (!ctx || !Xs || !mean || !cov || W < 0) return GPB_E_ARG;
+    if (W == 0) return 0;
+    if (W > 8192) GPB_FAIL(GPB_E_ARG, "gpb_gp_predict_cov: W > 8192 (the W x W covariance is for small batches)");
+    GPB_HIP(hipSetDevice(ctx->device));
+    const double* Xs_dev;
+    int rc = stage_inputs(ctx, Xs, W, on_device, nullptr, &Xs_dev, nullptr);
+    if (rc) return rc;
+    const int64_t P = ctx->P;
+    dim3 grid((unsigned)((W + 255) / 256));
+    if (on_device) {
+        if ((rc = launch_predict_cov(ctx, Xs_dev, W, cov))) return rc;
+        hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->mean_pc, mean, W, ctx->Wcap, (int)P);
+        GPB_HIP(hipGetLastError());
+        return 0;
+    }
+    if ((rc = ensure_out(ctx, W * P + P * W * W))) return rc;
+    double* dm = ctx->out_stage;
+    double* dc = dm + W * P;
+    if ((rc = launch_predict_cov(ctx, Xs_dev, W, dc))) return rc;
+    hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->mean_pc, dm, W, ctx->Wcap, (int)P);
+    GPB_HIP(hipMemcpyAsync(mean, dm, sizeof(double) * W * P, hipMemcpyDeviceToHost, ctx->stream));
+    GPB_HIP(hipMemcpyAsync(cov, dc, sizeof(double) * P * W * W, hipMemcpyDeviceToHost, ctx->stream));
     GPB_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -57,6 +57,10 @@ struct gpb_ctx {
     double* spart = nullptr;       // [Np/64][P][Wcap]  sum-of-squares partials per 64-row block
     double* mean_pc = nullptr;     // [P][Wcap]
     double* var_pc = nullptr;      // [P][Wcap]
+    double* vbuf = nullptr;        // [P][Np][Wcap] V = L^-1 K*^T (covariance path only)
+    int64_t vbuf_cap = 0;
+    double* covbuf = nullptr;      // [P][Wc][Wc]
+    int64_t covbuf_cap = 0;
     double* out_stage = nullptr;   // staging for host outputs
     int64_t out_cap = 0;
 
@@ -121,6 +125,7 @@ int launch_lml_grad(gpb_ctx* ctx, double* grad_host);
 // predict side (gpb_predict.hip)
 int ensure_wcap(gpb_ctx* ctx, int64_t W);
 int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var);
+int launch_predict_cov(gpb_ctx* ctx, const double* Xs_dev, int64_t W, double* cov_dev);
 // likelihood (gpb_like.hip)
 int launch_obs(gpb_ctx* ctx, int64_t W, const double* estd_dev, double* mean_dev, double* cov_dev);
 int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, const double* X_box = nullptr,

@@ -28,6 +28,17 @@ _KERNELS = {"RBF": ("RBF", (1e-1, 1e2)), "Matern": ("Matern15", (1e-3, 1e5)),
             "Matern25": ("Matern25", (1e-3, 1e5))}
 
 
+def _check_random_state(seed):
+    """sklearn.utils.check_random_state without importing sklearn."""
+    if seed is None or seed is np.random:
+        return np.random.mtrand._rand
+    if isinstance(seed, (int, np.integer)):
+        return np.random.RandomState(seed)
+    if isinstance(seed, np.random.RandomState):
+        return seed
+    raise ValueError("%r cannot be used to seed a numpy.random.RandomState instance" % seed)
+
+
 class FittedGP:
     """Read-only view of one fitted GP with the sklearn attribute names the reference reads
     (SURVEY §8b B3): kernel_theta (= kernel_.theta), log_marginal_likelihood_value_, alpha_, L_,
@@ -61,10 +72,17 @@ class FittedGP:
         m, v = m[:, self._i], v[:, self._i]
         if return_std:
             return m, np.sqrt(np.clip(v, 0.0, None))       # sk:_gpr.py:479-485
-        if return_cov:
-            raise NotImplementedError("full W x W covariance is never formed on the device; "
-                                      "use return_std or Emulator.predict")
+        if return_cov:                                     # joint covariance of the query points (small W)
+            mm, cc = self._emu._engine_ready().predict_cov(np.atleast_2d(X))
+            return mm[:, self._i], cc[self._i]
         return m
+
+    def sample_y(self, X, n_samples=1, random_state=0):
+        """Draw from the GP posterior at X (sk:_gpr.py:498-540): mean/covariance from the device, the
+        draw itself is numpy's RandomState.multivariate_normal exactly as sklearn calls it."""
+        rng = _check_random_state(random_state)
+        mean, cov = self.predict(X, return_cov=True)
+        return rng.multivariate_normal(mean, cov, n_samples).T
 
     def __repr__(self):
         th = self.kernel_theta
@@ -279,8 +297,23 @@ class Emulator:
         return eng.emu_predict(Xg, return_cov=True, extra_std=np.ascontiguousarray(es))
 
     def sample_y(self, X, n_samples=1, random_state=None):
-        raise NotImplementedError("sample_y needs the W x W predictive covariance, which this engine "
-                                  "never forms (SURVEY §8f item 4)")
+        """Sample model output at X -> [n_samples_X, n_samples, nobs] (src/emulator.py:608-633): one
+        posterior draw per emulated PC (each GP is handed the same `random_state`, as the reference does),
+        standard-normal draws from numpy's global generator for the neglected PCs, then the PC ->
+        observable map."""
+        if self.perform_no_PCA_:
+            log.warning("Sampling from raw data is not implemented.")
+            return None
+        X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        Xg = np.ascontiguousarray(self._map_parameters(X))
+        mean, cov = self._engine_ready().predict_cov(Xg)                  # [W,P], [P,W,W]
+        draws = []
+        for i in range(self._ngp):
+            rng = _check_random_state(random_state)
+            draws.append(rng.multivariate_normal(mean[:, i], cov[i], n_samples).T[:, :, np.newaxis])
+        rest = np.random.standard_normal((X.shape[0], n_samples, self.pca.n_components_ - self.npc))
+        Z = np.concatenate(draws + [rest], axis=2)
+        return np.dot(Z, self._trans_matrix[:Z.shape[-1]]) + self.scaler.mean_
 
     # ------------------------------------------------------------------ hold-out validation helpers
     def _holdout(self, nTestPoints, on_training):

@@ -119,6 +119,15 @@ class GPEngine:
         self._ck(self.lib.gpb_gp_predict(self.h, nat.ptr(Xs), W, 0, nat.ptr(mean), nat.ptr(var)))
         return (mean, var) if return_var else mean
 
+    def predict_cov(self, Xs):
+        """per-GP mean[W,P] and full covariance cov[P,W,W] between the query points (numpy in/out)."""
+        Xs = nat.f64(Xs).reshape(-1, self.d)
+        W = Xs.shape[0]
+        mean = np.empty((W, self.P))
+        cov = np.empty((self.P, W, W))
+        self._ck(self.lib.gpb_gp_predict_cov(self.h, nat.ptr(Xs), W, 0, nat.ptr(mean), nat.ptr(cov)))
+        return mean, cov
+
     # ------------------------------------------------------------------ emulator transform
     def set_transform(self, mode, mu, A=None, cov_trunc=None, scale=None):
         mu = nat.f64(mu)

@@ -94,6 +94,12 @@ int gpb_gp_lml(gpb_ctx* ctx, const double* theta_host /*[P,d+2]*/,
 int gpb_gp_predict(gpb_ctx* ctx, const double* Xs, int64_t W, int on_device,
                    double* mean /*[W,P]*/, double* var /*[W,P] or NULL*/);
 
+/* Full predictive covariance between the W query points, per GP (what GPR.predict(return_cov=True) returns
+ * and GPR.sample_y draws from: sk:_gpr.py:441-469, 498-540; src/emulator.py:608-633).  cov is [P,W,W].
+ * Small batches only (W <= 8192): the MCMC path never forms it. */
+int gpb_gp_predict_cov(gpb_ctx* ctx, const double* Xs, int64_t W, int on_device,
+                       double* mean /*[W,P]*/, double* cov /*[P,W,W]*/);
+
 /* ---- emulator transform: replaces Emulator.predict after the per-GP calls -------- *
  * gpb_emu_set_transform <- _trans_matrix[:npc], scaler.mean_, _cov_trunc, scaler.scale_  src/emulator.py:335-363
  * gpb_emu_predict       <- Emulator.predict(X, return_cov, extra_std)                   src/emulator.py:465-605

@@ -205,6 +205,19 @@ def gp_predict(Xs, X, theta, L, a, kind=KIND_RBF):
     return mean, var
 
 
+def gp_predict_cov(Xs, X, theta, L, a, kind=KIND_RBF):
+    """GPR.predict(return_cov=True) (sk:_gpr.py:441-469): mean and the full W x W covariance."""
+    Ks = kernel_cross(Xs, X, theta, kind)
+    mean = Ks @ a
+    V = solve_triangular(L, Ks.T, lower=True, check_finite=False)
+    d = X.shape[1]
+    c, _, noise = _unpack(theta, d)
+    Kss = kernel_cross(Xs, Xs, theta, kind)
+    np.fill_diagonal(Kss, c)
+    Kss[np.diag_indices_from(Kss)] += noise
+    return mean, Kss - V.T @ V
+
+
 def gp_predict_faithful(Xs, X, theta, L, a, kind=KIND_RBF):
     """What the reference really executes per GP: the full W x W covariance
     (sk:_gpr.py:460) and then its diagonal (src/emulator.py:573-575)."""

@@ -51,6 +51,18 @@ def test_g3_g4_emulator_at_reference_theta(tmp_path, name):
     mean0, cov0 = emu.predict(g["Xs"], return_cov=True, extra_std=0)      # scalar works (crashes in the reference under numpy>=2)
     assert maxrel(cov0, g["cov0"]) < 1e-10
     assert relerr(emu.predict(g["Xs"], return_cov=False), g["mean_only"]) < 1e-11
+    # joint covariance between query points and posterior draws (src/emulator.py:608-633)
+    for i, gp in enumerate(emu.gps):
+        mm, cfull = gp.predict(g["Xs"][:12], return_cov=True)
+        assert maxrel(cfull, g["gp_cov12"][i]) < 1e-9
+        assert maxrel(mm, g["gp_mean"][:12, i]) < 1e-11
+    if "sample_y" in g.files:
+        np.random.seed(4242)
+        ys = emu.sample_y(g["Xs"][:12], n_samples=5, random_state=7)
+        assert ys.shape == g["sample_y"].shape
+        assert maxrel(ys, g["sample_y"]) < 1e-6        # SVD-based draws amplify 1e-10 covariance differences
+    else:
+        assert emu.sample_y(g["Xs"][:4]) is None
     # pickling round trip drops and rebuilds the device state
     import dill
     emu2 = dill.loads(dill.dumps(emu))

@@ -72,6 +72,9 @@ def test_g3_emulator_preprocessing_and_predict(name):
     m, v = e.gp_predict(g["Xs"])
     assert maxrel(m, g["gp_mean"]) < 1e-11
     assert relerr(v, g["gp_var"]) < 1e-10
+    for p in range(e.npc):        # joint covariance of the first 12 query points
+        _, cfull = O.gp_predict_cov(g["Xs"][:12], e.X, e.thetas[p], e.L[p], e.a[p], e.kind)
+        assert maxrel(cfull, g["gp_cov12"][p]) < 1e-10
     mean, cov = e.predict(g["Xs"], True, g["extra_std"])
     assert relerr(mean, g["mean"]) < 1e-11
     assert maxrel(cov, g["cov"]) < 1e-10

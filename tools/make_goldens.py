@@ -142,6 +142,12 @@ def g3_g4_emulators(Emulator):
         mean, cov = emu.predict(Xs, return_cov=True, extra_std=extra)
         mean0, cov0 = emu.predict(Xs, return_cov=True, extra_std=np.zeros(32))
         mean_only = emu.predict(Xs, return_cov=False)
+        gp_cov_full = np.stack([c for _, c in per_gp], axis=0)[:, :12, :12]      # joint covariance of 12 points
+        per_gp12 = [gp.predict(Xs[:12], return_cov=True)[1] for gp in emu.gps]
+        samples = None
+        if not kw.get("perform_no_PCA"):
+            np.random.seed(4242)                                                  # neglected PCs use the global RNG
+            samples = emu.sample_y(Xs[:12], n_samples=5, random_state=7)         # src/emulator.py:608-633
         out = dict(
             lo=lo, hi=hi, X=X, Y=Y, Yerr=Yerr, npc=npc, kernel_type=ktype,
             model_data=emu.model_data,
@@ -154,7 +160,10 @@ def g3_g4_emulators(Emulator):
             scaler_mean=emu.scaler.mean_, scaler_scale=emu.scaler.scale_, scaler_var=emu.scaler.var_,
             Xs=Xs, extra_std=extra, gp_mean=gp_mean, gp_var=gp_var,
             mean=mean, cov=cov, mean0=mean0, cov0=cov0, mean_only=mean_only,
+            gp_cov12=np.stack(per_gp12, axis=0),
         )
+        if samples is not None:
+            out["sample_y"] = samples
         if not kw.get("perform_no_PCA"):
             out.update(pca_components=emu.pca.components_,
                        pca_explained_variance=emu.pca.explained_variance_,
