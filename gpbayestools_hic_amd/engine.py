@@ -63,6 +63,10 @@ class GPEngine:
     def sync(self):
         self._ck(self.lib.gpb_sync(self.h))
 
+    def _need_data(self):
+        if self.N == 0:
+            raise nat.GPBError("no GP data: call set_data / set_theta / factor first")
+
     # ------------------------------------------------------------------ GP state
     def set_data(self, X, Z, kernel="RBF", alpha=0.1):
         """X[N,d] design, Z[P,N] targets (one row per GP)."""
@@ -105,6 +109,7 @@ class GPEngine:
 
     def predict(self, Xs, return_var=True):
         """per-GP mean[W,P] (and var[W,P]); numpy in -> numpy out, torch(cuda) in -> torch out."""
+        self._need_data()
         if _is_torch(Xs):
             import torch
             W = Xs.shape[0]
@@ -121,6 +126,7 @@ class GPEngine:
 
     def predict_cov(self, Xs):
         """per-GP mean[W,P] and full covariance cov[P,W,W] between the query points (numpy in/out)."""
+        self._need_data()
         Xs = nat.f64(Xs).reshape(-1, self.d)
         W = Xs.shape[0]
         mean = np.empty((W, self.P))
@@ -139,6 +145,7 @@ class GPEngine:
                                                 nat.ptr(cov_trunc), nat.ptr(scale)))
 
     def emu_predict(self, Xs, return_cov=True, extra_std=None):
+        self._need_data()
         if _is_torch(Xs):
             import torch
             W = Xs.shape[0]
@@ -164,6 +171,7 @@ class GPEngine:
     def loglike(self, Xs, out=None, accumulate=False, check=True):
         """Block log-likelihood for every row of Xs.  torch(cuda) in/out stays on the device
         and is asynchronous when check=False."""
+        self._need_data()
         npd = C.c_int(0)
         if _is_torch(Xs):
             import torch
