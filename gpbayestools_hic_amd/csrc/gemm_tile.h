@@ -27,20 +27,21 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 16;
 constexpr int GEMM_THREADS = 256;
 
-template <int T>
+// T rows of A (the m extent) by TN columns of B (the n extent); TN = T except for the narrow predict tile.
+template <int T, int TN = T>
 struct __attribute__((aligned(16))) TileLds {
     static constexpr int LD = T + 16;   // row stride = 2*(T+16) dwords = 32 (mod 64) banks
-    double As[BK][LD];
-    double Bs[BK][LD];
-};                                       // T=128: 36,864 B; T=64: 20,480 B
+    double As[BK][T + 16];
+    double Bs[BK][TN + 16];
+};                                       // T=128: 36,864 B; T=64: 20,480 B; 64x32: 16,384 B
 
 // NW = waves per workgroup (4: 2x2 waves, wave tile T/2 x T/2;  8: 2x4 waves, wave tile T/2 x T/4).
 // More waves per tile shorten a tile's critical path: ONE wave can issue an f64 MFMA only every
 // ~138 cycles (profiles/r01_mfma_f64_issue_rate.txt), two waves per SIMD reach ~70.
 template <int T, int NW = 4>
 struct Frag { double2 r[(8 * T) / (64 * NW)]; };
-template <int T, int NW = 4>
-struct Acc { d4 v[T / 32][(2 * T / NW) / 16]; };
+template <int T, int NW = 4, int TN = T>
+struct Acc { d4 v[T / 32][(2 * TN / NW) / 16]; };
 
 // logical tile[k][x] = G[(k0+k)*ld + x0+x]   (k<16, x<T); rows are contiguous in x.
 template <int T, int NW>
@@ -89,17 +90,17 @@ __device__ __forceinline__ void lstore_trans(double (*S)[T + 16], const Frag<T, 
     }
 }
 
-template <int T, int NW = 4>
-__device__ __forceinline__ void acc_zero(Acc<T, NW>& acc) {
+template <int T, int NW = 4, int TN = T>
+__device__ __forceinline__ void acc_zero(Acc<T, NW, TN>& acc) {
 #pragma unroll
     for (int i = 0; i < T / 32; ++i)
 #pragma unroll
-        for (int j = 0; j < (2 * T / NW) / 16; ++j) acc.v[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < (2 * TN / NW) / 16; ++j) acc.v[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 }
 
-template <int T, int NW>
-__device__ __forceinline__ void tile_mma(const TileLds<T>& L, Acc<T, NW>& acc, int lane, int m0, int n0) {
-    constexpr int NI = T / 32, NJ = (2 * T / NW) / 16;
+template <int T, int NW, int TN>
+__device__ __forceinline__ void tile_mma(const TileLds<T, TN>& L, Acc<T, NW, TN>& acc, int lane, int m0, int n0) {
+    constexpr int NI = T / 32, NJ = (2 * TN / NW) / 16;
     const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
@@ -120,35 +121,36 @@ __device__ __forceinline__ void tile_mma(const TileLds<T>& L, Acc<T, NW>& acc, i
 //   A_TRANS=false: A[m][k] = Ag[(m_base+m)*lda + k]       A_TRANS=true: A[m][k] = Ag[k*lda + m_base+m]
 //   B_TRANS=false: B[k][n] = Bg[k*ldb + n_base+n]         B_TRANS=true: B[k][n] = Bg[(n_base+n)*ldb + k]
 // m_ext / n_ext (even, <= T) bound the valid rows / columns of this tile; the rest reads as 0.
-template <int T, bool A_TRANS, bool B_TRANS, int NW = 4>
+template <int T, bool A_TRANS, bool B_TRANS, int NW = 4, int TN = T>
 __device__ __forceinline__ void gemm_tile_loop(const double* __restrict__ Ag, int64_t lda,
                                                const double* __restrict__ Bg, int64_t ldb, int64_t m_base,
                                                int64_t n_base, int m_ext, int n_ext, int64_t k_begin, int64_t k_end,
-                                               TileLds<T>& L, Acc<T, NW>& acc) {
+                                               TileLds<T, TN>& L, Acc<T, NW, TN>& acc) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    constexpr int WN = NW / 2, TN = T / WN;     // waves along n, wave tile width
-    const int m0 = (wave / WN) * (T / 2), n0 = (wave % WN) * TN;
-    Frag<T, NW> fa, fb;
+    constexpr int WN = NW / 2, TNW = TN / WN;   // waves along n, wave tile width
+    const int m0 = (wave / WN) * (T / 2), n0 = (wave % WN) * TNW;
+    Frag<T, NW> fa;
+    Frag<TN, NW> fb;
     if (k_begin < k_end) {
         if (A_TRANS) gload_direct<T, NW>(Ag, lda, k_begin, m_base, m_ext, fa, tid);
         else         gload_trans<T, NW>(Ag, lda, k_begin, m_base, m_ext, fa, tid);
-        if (B_TRANS) gload_trans<T, NW>(Bg, ldb, k_begin, n_base, n_ext, fb, tid);
-        else         gload_direct<T, NW>(Bg, ldb, k_begin, n_base, n_ext, fb, tid);
+        if (B_TRANS) gload_trans<TN, NW>(Bg, ldb, k_begin, n_base, n_ext, fb, tid);
+        else         gload_direct<TN, NW>(Bg, ldb, k_begin, n_base, n_ext, fb, tid);
     }
     for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
         __syncthreads();
         if (A_TRANS) lstore_direct<T, NW>(L.As, fa, tid); else lstore_trans<T, NW>(L.As, fa, tid);
-        if (B_TRANS) lstore_trans<T, NW>(L.Bs, fb, tid);  else lstore_direct<T, NW>(L.Bs, fb, tid);
+        if (B_TRANS) lstore_trans<TN, NW>(L.Bs, fb, tid); else lstore_direct<TN, NW>(L.Bs, fb, tid);
         __syncthreads();
         const int64_t kn = k0 + BK;
         if (kn < k_end) {
             if (A_TRANS) gload_direct<T, NW>(Ag, lda, kn, m_base, m_ext, fa, tid);
             else         gload_trans<T, NW>(Ag, lda, kn, m_base, m_ext, fa, tid);
-            if (B_TRANS) gload_trans<T, NW>(Bg, ldb, kn, n_base, n_ext, fb, tid);
-            else         gload_direct<T, NW>(Bg, ldb, kn, n_base, n_ext, fb, tid);
+            if (B_TRANS) gload_trans<TN, NW>(Bg, ldb, kn, n_base, n_ext, fb, tid);
+            else         gload_direct<TN, NW>(Bg, ldb, kn, n_base, n_ext, fb, tid);
         }
-        tile_mma<T, NW>(L, acc, lane, m0, n0);
+        tile_mma<T, NW, TN>(L, acc, lane, m0, n0);
     }
 }
 

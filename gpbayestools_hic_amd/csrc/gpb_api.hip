@@ -567,14 +567,16 @@ extern "C" int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K, cons
 }
 
 extern "C" int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles) {
-    if (!ctx || (tile != 0 && tile != 64 && tile != 128)) return GPB_E_ARG;
+    if (!ctx || (tile != 0 && tile != 32 && tile != 64 && tile != 128)) return GPB_E_ARG;   // 32 = 64 rows x 32 walkers
     ctx->force_tile = tile;
     if (switch_tiles > 0) ctx->tile_switch = switch_tiles;
     return 0;
 }
 
 // key: 0 = XCD affinity (-1 auto, 0 by walker tile, 1 by row block); 1 = persistent 64-tile workgroups per CU;
-//      2 = waves per predict tile (4 or 8); 3 = persistent workgroups per CU of the 128-tile 8-wave variant
+//      2 = waves per predict tile (4 or 8); 3 = persistent workgroups per CU of the 128-tile 8-wave variant;
+//      4 = outer Cholesky panel width;
+//      6 = persistent 64x32-tile workgroups per CU; 7 = largest padded batch that uses 64x32 tiles
 extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
     if (!ctx) return GPB_E_ARG;
     switch (key) {
@@ -583,6 +585,10 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 2: if (value != 4 && value != 8) return GPB_E_ARG; ctx->predict_waves = value; break;
         case 3: if (value < 1 || value > 4) return GPB_E_ARG; ctx->wgs_per_cu128w8 = value; break;
         case 4: if (value < 64 || value % 64) return GPB_E_ARG; ctx->chol_outer = value; break;
+        case 5: if (value < 0 || value > 3) return GPB_E_ARG; ctx->resident_order = value; break;
+        case 6: if (value < 1 || value > 10) return GPB_E_ARG; ctx->wgs_per_cu32 = value; break;
+        case 7: if (value < 0) return GPB_E_ARG; ctx->narrow_switch = value; break;
+        case 8: if (value < 0) return GPB_E_ARG; ctx->mvn_wg_switch = value; break;
         default: return GPB_E_ARG;
     }
     return 0;

@@ -80,13 +80,17 @@ struct gpb_ctx {
     int num_cu = 256;               // multiprocessor count of the device
     int wgs_per_cu64 = 6;           // persistent k_predict<64> workgroups per CU
     int wgs_per_cu128w8 = 2;        // ... for the 128-tile, 8-wave variant
+    int wgs_per_cu32 = 4;           // ... for the 64x32 tile
+    int64_t narrow_switch = 128;    // padded walker batches up to this size use 64x32 tiles (0 = never)
     int predict_waves = 4;          // waves per k_predict tile (4 or 8)
     unsigned* tile_counter = nullptr;   // 8 ticket queues (stride 16) + done counter [128]; re-armed by the kernel
     int64_t chol_outer = 256;       // outer panel width of the two-level blocked Cholesky
-    int force_tile = 0;            // test hook: 0 = auto, 64 / 128 = force the k_predict tile size
+    int resident_order = 2;         // k_predict with one workgroup per tile: 0 = ticket queues, 1-3 = static orders (2 = snake)
+    int force_tile = 0;            // test hook: 0 = auto, 64 / 128 / 32 (= 64x32) force the k_predict tile
     int force_xcd = -1;             // tuning hook: -1 auto, 0 / 1 = k_predict XCD affinity by walker tile / row block
     int64_t tile_switch = 1280;     // use 128x128 tiles when at least this many of them exist
     bool force_generic_mvn = false; // test hook: bypass the register-resident MVN fast path
+    int64_t mvn_wg_switch = 768;    // batches up to this size use one workgroup per walker (32 < M <= 64)
 
     // ---- profiling (HIP events around k_predict) ------------------------------------
     bool profile = false;

@@ -321,6 +321,129 @@ static int launch_loglike_reg(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accu
     return 0;
 }
 
+// ------------------------------------------------------------------ fused block log-likelihood, one workgroup per walker
+// Low-latency variant of k_loglike_reg<64> for small walker batches (a rank's shard under 8-way sharding):
+// the one-wave kernel is a single dependent instruction stream of ~80 KB of straight-line code (larger than
+// the instruction cache) and takes ~50 us however few walkers there are.  Here 256 threads share one
+// walker: thread (ty, tx) owns the elements (ty + 16a, tx + 16b), a >= b, of the lower triangle in VGPRs
+// (2-D cyclic, so all threads stay busy to the last column); per column the owners publish the column and
+// y_j through a double-buffered LDS line, one barrier per column.  Every element sees exactly the same
+// sequence of operations as in k_loglike_reg (same build order over p, same rsqrt, same fma operands, same
+// grouping of the log-determinant), so the two kernels are bit-identical and the choice by batch size
+// never changes a result.
+__global__ __launch_bounds__(256) void k_loglike_wg(const double* __restrict__ mean_pc,
+                                                    const double* __restrict__ var_pc, int64_t Wld, int64_t W, int P,
+                                                    int M, const double* __restrict__ A,
+                                                    const double* __restrict__ mu, const double* __restrict__ C0,
+                                                    const double* __restrict__ yexp, const double* __restrict__ Cexp,
+                                                    double* __restrict__ ll, int accumulate, int* __restrict__ notpd,
+                                                    BoxArgs box) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* sA = sm;                         // [P][64]  A, zero padded
+    double* col = sm + (size_t)P * 64;       // [2][66]  column j of the trailing matrix (unscaled), y_j at [64]
+    __shared__ int s_outside;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int64_t w = blockIdx.x;
+    for (int e = tid; e < P * 64; e += 256) {
+        const int p = e >> 6, i = e & 63;
+        sA[e] = (i < M) ? A[p * M + i] : 0.0;
+    }
+    if (tid == 0) s_outside = 0;
+    __syncthreads();
+    if (box.X) {                             // strict box over the d parameters
+        bool ok = true;
+        for (int k = tid; k < box.d; k += 256) {
+            const double x = box.X[w * box.d + k];
+            ok = ok && (x > box.lo[k]) && (x < box.hi[k]);
+        }
+        if (!ok) s_outside = 1;              // all writers store the same value
+    }
+    double c[4][4];                          // c[a][b], b <= a: element (ty + 16a, tx + 16b)
+    double y[4];                             // dY rows ty + 16a (meaningful on the tx == 0 threads)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int i = ty + 16 * a;
+        y[a] = (i < M) ? (mu[i] - yexp[i]) : 0.0;
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            const int k = tx + 16 * b;
+            double v = (i == k) ? 1.0 : 0.0;
+            if (i < M && k < M) v = C0[i * M + k] + Cexp[i * M + k];
+            c[a][b] = v;
+        }
+    }
+    for (int p = 0; p < P; ++p) {
+        const double zm = mean_pc[(int64_t)p * Wld + w];        // uniform
+        const double zv = var_pc[(int64_t)p * Wld + w];         // extra_std == 0 on this path
+        double ak[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) ak[b] = sA[p * 64 + tx + 16 * b];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const double ai = sA[p * 64 + ty + 16 * a];
+            y[a] = fma(zm, ai, y[a]);                             // dY_i (src/emulator.py:559-561, src/mcmc.py:288)
+            const double t = zv * ai;
+#pragma unroll
+            for (int b = 0; b <= a; ++b) c[a][b] = fma(t, ak[b], c[a][b]);   // src/emulator.py:584-587
+        }
+    }
+    bool bad = false;
+    double q = 0.0, logdet = 0.0, prod = 1.0;
+    const int nblk = (M + 15) >> 4;          // identity-padded columns beyond M change nothing (pivot 1, v = 0)
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        if (jb < nblk) {
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = 16 * jb + jj;
+                double* buf = col + (j & 1) * 66;
+                if (tx == jj) {
+#pragma unroll
+                    for (int a = jb; a < 4; ++a) buf[ty + 16 * a] = c[a][jb];
+                }
+                if (tx == 0 && ty == jj) buf[64] = y[jb];
+                __syncthreads();             // one barrier per column: the line of column j-1 is not rewritten before j+1
+                const double ajj = buf[j];
+                bad = bad || !(ajj > 0.0);
+                const double rinv = rsqrt(ajj);                   // 1 / L_jj
+                const double vj = buf[64] * rinv;                 // forward solve: v_j
+                q = fma(vj, vj, q);
+                prod *= ajj;                                      // sum log L_jj = 1/2 log prod a_jj, 4 pivots per log
+                if ((j & 3) == 3) { logdet += 0.5 * log(prod); prod = 1.0; }
+                double lk[4];
+#pragma unroll
+                for (int b = jb; b < 4; ++b) lk[b] = buf[tx + 16 * b] * rinv;
+#pragma unroll
+                for (int a = jb; a < 4; ++a) {
+                    const double li = buf[ty + 16 * a] * rinv;    // L_ij for this thread's rows
+                    y[a] = fma(-li, vj, y[a]);
+#pragma unroll
+                    for (int b = jb; b <= a; ++b) c[a][b] = fma(-li, lk[b], c[a][b]);
+                }
+            }
+        }
+    }
+    if (tid == 0) {
+        const bool inside = !s_outside;
+        double r = -0.5 * q - logdet;
+        if (bad && inside) {
+            r = nan("");
+            atomicAdd(notpd, 1);
+        }
+        r = accumulate ? (ll[w] + r) : r;
+        if (box.X) r = inside ? (r + box.inside_const) : box.outside;
+        ll[w] = r;
+    }
+}
+
+static int launch_loglike_wg(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, const BoxArgs& box) {
+    const size_t sh = ((size_t)ctx->P * 64 + 2 * 66) * sizeof(double);
+    hipLaunchKernelGGL(k_loglike_wg, dim3((unsigned)W), dim3(256), sh, ctx->stream, ctx->mean_pc, ctx->var_pc,
+                       ctx->Wcap, W, (int)ctx->P, (int)ctx->M, ctx->A, ctx->mu, ctx->C0, ctx->yexp, ctx->Cexp, ll_dev,
+                       accumulate ? 1 : 0, ctx->notpd, box);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
 __global__ void k_box(const double* __restrict__ X, int64_t W, int d, const double* __restrict__ lo,
                       const double* __restrict__ hi, double outside, double inside_const, double* __restrict__ ll);
 
@@ -334,6 +457,7 @@ int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, con
         if (M <= 8) return launch_loglike_reg<8>(ctx, W, ll_dev, accumulate, box);
         if (M <= 16) return launch_loglike_reg<16>(ctx, W, ll_dev, accumulate, box);
         if (M <= 32) return launch_loglike_reg<32>(ctx, W, ll_dev, accumulate, box);
+        if (W <= ctx->mvn_wg_switch) return launch_loglike_wg(ctx, W, ll_dev, accumulate, box);   // same bits, lower latency
         return launch_loglike_reg<64>(ctx, W, ll_dev, accumulate, box);
     }
     const size_t small = (2 * P + 2 * M) * sizeof(double);

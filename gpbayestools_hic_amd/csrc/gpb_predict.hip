@@ -38,33 +38,52 @@ __global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, i
                                                 double* __restrict__ KsT, double* __restrict__ mpart,
                                                 int64_t N, int64_t Np, int64_t Wld, int P) {
     __shared__ double red[4][64];
-    __shared__ double sx[64][DPAD + 1];
+    __shared__ __attribute__((aligned(16))) double sbuf[64 * (DPAD + 1)];  // walker tile, then the design rows
+    __shared__ double sal[KX_CHUNK];
+    double (*sx)[DPAD + 1] = reinterpret_cast<double (*)[DPAD + 1]>(sbuf);
+    double* sxr = sbuf;                                 // [KX_CHUNK][DPAD] design rows / length scale
     const int p = blockIdx.z, chunk = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t w = (int64_t)blockIdx.x * 64 + lane;
-    // walker tile / length scale, loaded coalesced and divided once per element, then one row per lane
+    const int64_t nbeg = (int64_t)chunk * KX_CHUNK;     // Np is a multiple of KX_CHUNK: the chunk is always whole
+    const double* Xp = Xsc + ((int64_t)p * Np + nbeg) * DPAD;
+    // walker tile / length scale, loaded coalesced and divided once per element, then one row per lane;
+    // the design rows are one contiguous block: coalesced into LDS, read back as broadcasts (scalar loads
+    // of 64 x DPAD doubles per workgroup miss the scalar cache and serialise on L2 latency)
+    constexpr int NPRE = (KX_CHUNK * DPAD + 255) / 256;
+    double pre[NPRE];                                   // design rows in flight while the walker tile is set up
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+        const int e = threadIdx.x + 256 * j;
+        pre[j] = (e < KX_CHUNK * DPAD) ? Xp[e] : 0.0;
+    }
     for (int e = threadIdx.x; e < 64 * DPAD; e += 256) {
         const int r = e / DPAD, k = e - r * DPAD;
         const int64_t ww = (int64_t)blockIdx.x * 64 + r;
         sx[r][k] = (k < d && ww < W) ? Xs[ww * d + k] / ls[p * DPAD + k] : 0.0;
     }
+    if (threadIdx.x < KX_CHUNK) sal[threadIdx.x] = alpha[(int64_t)p * Np + nbeg + threadIdx.x];
     __syncthreads();
     double xs[DPAD];
 #pragma unroll
     for (int k = 0; k < DPAD; ++k) xs[k] = sx[lane][k];
+    __syncthreads();                                    // the walker tile is in registers: reuse its LDS
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+        const int e = threadIdx.x + 256 * j;
+        if (e < KX_CHUNK * DPAD) sxr[e] = pre[j];
+    }
+    __syncthreads();
     const double c = amp[p];
-    const double* Xp = Xsc + (int64_t)p * Np * DPAD;
-    const double* ap = alpha + (int64_t)p * Np;
     double* Kp = KsT + (int64_t)p * Np * Wld;
     double msum = 0.0;
-    const int64_t nbeg = (int64_t)chunk * KX_CHUNK;
     for (int t = 0; t < KX_CHUNK / 4; ++t) {
-        const int64_t n = nbeg + wave + 4 * t;          // wave-uniform
-        if (n >= Np) break;
+        const int pt = wave + 4 * t;                    // wave-uniform
+        const int64_t n = nbeg + pt;
         double kv = 0.0;
         if (n < N) {
-            const double* xr = Xp + n * DPAD;
+            const double* xr = sxr + pt * DPAD;
             double r2 = 0.0;
 #pragma unroll
             for (int k = 0; k < DPAD; ++k) {
@@ -72,7 +91,7 @@ __global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, i
                 r2 = fma(df, df, r2);
             }
             kv = c * shape_fn_p<KIND>(r2);
-            msum = fma(ap[n], kv, msum);
+            msum = fma(sal[pt], kv, msum);
         }
         Kp[n * Wld + w] = kv;
     }
@@ -87,18 +106,18 @@ __global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, i
 // L2.  The fused epilogue reduces V^2 over rows in a tree that depends only on the row index — 32-row
 // chains, lane groups, then the two halves of each 64-row block — so both tile sizes, and therefore any
 // sharding of the walkers, give bit-identical sums.  spart is indexed by 64-row block.
-template <int T, int NW>
-__device__ __forceinline__ void predict_tile(TileLds<T>& lds, int p, int ib, int wt, const double* __restrict__ Linv,
+template <int T, int NW, int TN>
+__device__ __forceinline__ void predict_tile(TileLds<T, TN>& lds, int p, int ib, int wt, const double* __restrict__ Linv,
                                              const double* __restrict__ KsT, double* __restrict__ spart, int64_t Np,
                                              int64_t Wld, int P) {
-    constexpr int NI = T / 32, WN = NW / 2, TN = T / WN, NJ = TN / 16;
-    const int64_t mb = (int64_t)ib * T, nb = (int64_t)wt * T;
+    constexpr int NI = T / 32, WN = NW / 2, TNW = TN / WN, NJ = TNW / 16;
+    const int64_t mb = (int64_t)ib * T, nb = (int64_t)wt * TN;
     const int m_ext = (int)imin64(T, Np - mb);
     const int64_t k_end = imin64(mb + T, Np);
-    Acc<T, NW> acc;
-    acc_zero<T, NW>(acc);
-    gemm_tile_loop<T, false, false, NW>(Linv + (int64_t)p * Np * Np, Np, KsT + (int64_t)p * Np * Wld, Wld, mb, nb,
-                                        m_ext, T, 0, k_end, lds, acc);
+    Acc<T, NW, TN> acc;
+    acc_zero<T, NW, TN>(acc);
+    gemm_tile_loop<T, false, false, NW, TN>(Linv + (int64_t)p * Np * Np, Np, KsT + (int64_t)p * Np * Wld, Wld, mb, nb,
+                                            m_ext, TN, 0, k_end, lds, acc);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     double s[NJ];
@@ -119,34 +138,88 @@ __device__ __forceinline__ void predict_tile(TileLds<T>& lds, int p, int ib, int
         s[j] = (NI == 4) ? (h[0] + h[NI / 2 - 1]) : h[0];     // T=128: rows 0-31 + rows 32-63 of the wave's block
     }
     __syncthreads();                            // all waves are done reading the operand tiles
-    double* red = &lds.As[0][0];                // [2 wave rows][T columns]
+    double* red = &lds.As[0][0];                // [2 wave rows][TN columns]
     if (lane < 16) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) red[wm * T + wn * TN + 16 * j + lane] = s[j];
+        for (int j = 0; j < NJ; ++j) red[wm * TN + wn * TNW + 16 * j + lane] = s[j];
     }
     __syncthreads();
     if (T == 128) {                             // each wave row is one 64-row block
         if (tid < 256) {
             const int half = tid >> 7, col = tid & 127;
             const int64_t blk = 2 * (int64_t)ib + half;
-            if (blk * 64 < Np) spart[(blk * P + p) * Wld + nb + col] = red[half * T + col];
+            if (blk * 64 < Np) spart[(blk * P + p) * Wld + nb + col] = red[half * TN + col];
         }
     } else {                                    // the two wave rows are the halves of one 64-row block
-        if (tid < T) spart[((int64_t)ib * P + p) * Wld + nb + tid] = red[tid] + red[T + tid];
+        if (tid < TN) spart[((int64_t)ib * P + p) * Wld + nb + tid] = red[tid] + red[TN + tid];
     }
+}
+
+// ticket t of queue qx -> tile (GP p, row block ib, walker tile wt); false for the padding of xcd_mode 1
+__device__ __forceinline__ bool decode_tile(int xcd_mode, unsigned t, unsigned qx, int nI, int nW, int P, int& p,
+                                            int& ib, int& wt) {
+    if (xcd_mode == 2) {
+        const int j = (int)t / (nI * nW), rem = (int)t - j * (nI * nW);
+        p = (int)qx + 8 * j;
+        ib = nI - 1 - rem / nW;
+        wt = rem % nW;
+        return true;
+    }
+    const int b = (int)(t * 8u + qx);
+    int g;
+    if (xcd_mode == 1) {
+        const int q = b >> 3;
+        g = (q / nW) * 8 + (b & 7);
+        wt = q % nW;
+        if (g >= nI * P) return false;
+    } else {
+        g = b / nW;
+        wt = b - g * nW;
+    }
+    ib = nI - 1 - g / P;
+    p = g - (g / P) * P;
+    return true;
 }
 
 // Persistent launch: `gridDim.x` workgroups (a few per CU) pull tile indices from device-scope ticket
 // queues in LPT order, so the triangular row blocks balance dynamically whatever the dispatcher does.
 // Exit condition: every workgroup walks all eight queues once and leaves each when its ticket is past
 // the queue's length; nothing spins.
-template <int T, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 4)) void k_predict(const double* __restrict__ Linv, const double* __restrict__ KsT,
+template <int T, int NW, int TN>
+__global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : 4)) void k_predict(const double* __restrict__ Linv, const double* __restrict__ KsT,
                                                      double* __restrict__ spart, int64_t Np, int64_t Wld, int P,
                                                      int nI, int nW, int xcd_mode, unsigned* __restrict__ queue,
-                                                     unsigned nblocks) {
-    __shared__ TileLds<T> lds;
+                                                     unsigned nblocks, int resident, unsigned ncu_x) {
+    __shared__ TileLds<T, TN> lds;
     __shared__ unsigned s_ticket;
+    if (resident) {
+        // Every tile has its own workgroup and all of them are co-resident: nothing can be balanced
+        // dynamically, so the tile is a fixed function of blockIdx.  The dispatcher deals an XCD's workgroups
+        // round-robin over its ncu_x CUs (tools/micro/dispatch_probe.hip): workgroup j of an XCD runs on CU
+        // j % ncu_x.  resident: 1 = weight-sorted order as is, 2 = snake over the CUs (equal sums),
+        // 3 = snake of neighbouring PAIRS (equal sums, and the two heaviest tiles of a CU finish together).
+        const unsigned qx = blockIdx.x & 7u;
+        unsigned nq;
+        if (xcd_mode == 2) nq = ((unsigned)P > qx) ? (((unsigned)P - qx + 7u) / 8u) * (unsigned)(nI * nW) : 0u;
+        else               nq = (nblocks > qx) ? (nblocks - qx + 7u) / 8u : 0u;
+        unsigned t = blockIdx.x >> 3;
+        if (t >= nq) return;
+        const unsigned k = t / ncu_x, c = t - k * ncu_x;
+        if (resident == 2) {
+            if ((k & 1u) && (k + 1u) * ncu_x <= nq) t = k * ncu_x + (ncu_x - 1u - c);
+        } else if (resident == 3) {
+            const unsigned n2 = (nq / (2u * ncu_x)) * (2u * ncu_x);
+            if (t < n2) {
+                const unsigned kp = k >> 1;
+                const unsigned pi = kp * ncu_x + ((kp & 1u) ? (ncu_x - 1u - c) : c);
+                t = 2u * pi + (k & 1u);
+            }
+        }
+        int p, ib, wt;
+        if (decode_tile(xcd_mode, t, qx, nI, nW, P, p, ib, wt))
+            predict_tile<T, NW, TN>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P);
+        return;
+    }
     // Eight ticket queues, one per XCD label (blockIdx % 8; workgroups with equal labels share an XCD's
     // L2 under round-robin dispatch — speed only): queue x owns the tiles b = 8 t + x, i.e. a fixed set
     // of walker tiles (or row blocks) whose operand panels stay in that XCD's L2 while its workgroups
@@ -169,27 +242,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 4)) void k_predict(const do
             __syncthreads();                    // everyone has read the ticket before it is redrawn
             if (t >= nq) break;                 // uniform: this queue is exhausted
             int p, ib, wt;
-            if (xcd_mode == 2) {
-                const int j = (int)t / (nI * nW), rem = (int)t - j * (nI * nW);
-                p = (int)qx + 8 * j;
-                ib = nI - 1 - rem / nW;
-                wt = rem % nW;
-            } else {
-                const int b = (int)(t * 8u + qx);
-                int g;
-                if (xcd_mode == 1) {
-                    const int q = b >> 3;
-                    g = (q / nW) * 8 + (b & 7);
-                    wt = q % nW;
-                    if (g >= nI * P) continue;  // padding of the last group of eight (uniform)
-                } else {
-                    g = b / nW;
-                    wt = b - g * nW;
-                }
-                ib = nI - 1 - g / P;
-                p = g - (g / P) * P;
-            }
-            predict_tile<T, NW>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P);
+            if (!decode_tile(xcd_mode, t, qx, nI, nW, P, p, ib, wt)) continue;   // padding (uniform)
+            predict_tile<T, NW, TN>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P);
         }
     }
     // the last workgroup to finish re-arms the queues for the next launch (all others are past their draws)
@@ -275,30 +329,42 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var)
     if (need_var) {
         // 128-wide tiles when they fill the chip several times over, 64-wide for small walker batches
         const int64_t tiles128 = ctx->P * ((ctx->Np + 127) / 128) * (Wuse / 128);
+        // T rows x TN walkers per tile: 128x128, 64x64, or 64x32 ("32") for the smallest batches, where the
+        // heaviest tile's serial K loop (one wave issues an f64 MFMA every ~138 cycles) is the critical path
         int T = (tiles128 >= ctx->tile_switch) ? 128 : 64;
-        if (ctx->force_tile == 64 || ctx->force_tile == 128) T = ctx->force_tile;
+        int TN = T;
+        if (T == 64 && Wuse <= ctx->narrow_switch) TN = 32;
+        if (ctx->force_tile == 64 || ctx->force_tile == 128) T = TN = ctx->force_tile;
+        if (ctx->force_tile == 32) { T = 64; TN = 32; }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (ctx->profile) {                    // live HIP-event timing of the dominant kernel (bench.py)
             GPB_HIP(hipEventCreate(&e0));
             GPB_HIP(hipEventCreate(&e1));
             GPB_HIP(hipEventRecord(e0, ctx->stream));
         }
-        const int nI = (T == 128) ? (int)((ctx->Np + 127) / 128) : nI64, nW = (int)(Wuse / T);
+        const int nI = (T == 128) ? (int)((ctx->Np + 127) / 128) : nI64, nW = (int)(Wuse / TN);
         // which operand is larger decides the XCD affinity: L^-1 (P Np^2/2) or K*^T (P Np W)
         int xcd_rows = (2 * Wuse < ctx->Np) ? 1 : 0;
         if (ctx->force_xcd >= 0) xcd_rows = ctx->force_xcd;      // 0, 1 or 2 (GP-affine)
         const int64_t ngroups = (int64_t)ctx->P * nI;
         const int64_t nblocks = (xcd_rows == 1) ? ((ngroups + 7) / 8) * 8 * nW : ngroups * nW;
         const int nwv = ctx->predict_waves;             // 4 or 8 waves per tile
-        const int per_cu = (T == 128) ? (nwv == 8 ? ctx->wgs_per_cu128w8 : 2) : ctx->wgs_per_cu64;
+        const int per_cu = (T == 128) ? (nwv == 8 ? ctx->wgs_per_cu128w8 : 2)
+                                      : (TN == 32 ? ctx->wgs_per_cu32 : ctx->wgs_per_cu64);
         const int64_t slots = (int64_t)ctx->num_cu * per_cu;
         const unsigned grid = (unsigned)(nblocks < slots ? nblocks : slots);
-#define GPB_PRED(TT, WW)                                                                                         \
-    hipLaunchKernelGGL((k_predict<TT, WW>), dim3(grid), dim3(64 * WW), 0, ctx->stream, ctx->Linv, ctx->KsT,        \
+        // one workgroup per tile and all of them co-resident (registers allow 2 / 5 / 7 workgroups per CU):
+        // nothing is left to balance dynamically, so the kernel deals the tiles out statically instead
+        const int occ = (T == 128) ? 2 : (TN == 32 ? 7 : 5);
+        const int resident = (nblocks <= (int64_t)ctx->num_cu * occ && nblocks <= slots && nwv == 4 && xcd_rows != 2)
+                                 ? ctx->resident_order : 0;
+#define GPB_PRED(TT, WW, NN)                                                                                     \
+    hipLaunchKernelGGL((k_predict<TT, WW, NN>), dim3(grid), dim3(64 * WW), 0, ctx->stream, ctx->Linv, ctx->KsT,    \
                        ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW, xcd_rows, ctx->tile_counter,           \
-                       (unsigned)nblocks)
-        if (T == 128) { if (nwv == 8) GPB_PRED(128, 8); else GPB_PRED(128, 4); }
-        else          { if (nwv == 8) GPB_PRED(64, 8);  else GPB_PRED(64, 4); }
+                       (unsigned)nblocks, resident, (unsigned)(ctx->num_cu / 8))
+        if (T == 128)      { if (nwv == 8) GPB_PRED(128, 8, 128); else GPB_PRED(128, 4, 128); }
+        else if (TN == 32) GPB_PRED(64, 4, 32);
+        else               { if (nwv == 8) GPB_PRED(64, 8, 64); else GPB_PRED(64, 4, 64); }
 #undef GPB_PRED
         if (ctx->profile) {
             GPB_HIP(hipEventRecord(e1, ctx->stream));

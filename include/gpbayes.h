@@ -184,12 +184,18 @@ int gpb_dist_finalize(gpb_ctx* ctx);
  * 1 = A[M,K] B[N,K]^T, 2 = A[K,M]^T B[K,N]; bit 2: 64x64 tiles instead of 128x128. */
 int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K,
                   const double* A_host, const double* B_host, double* C_host, int b_trans);
-/* test/tuning hook: force the tile size of the predict kernel (0 = automatic, 64, 128) and, when
- * switch_tiles > 0, the number of 128x128 tiles from which the automatic choice uses them. */
+/* test/tuning hook: force the tile of the predict kernel (0 = automatic, 64, 128, 32 = 64 rows x 32
+ * walkers) and, when switch_tiles > 0, the number of 128x128 tiles from which the automatic choice
+ * uses them. */
 int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
-/* tuning hook for the predict kernel's launch geometry (never changes results): key 0 = XCD affinity
- * (-1 auto, 0 by walker tile, 1 by row block); 1 = persistent 64-tile workgroups per CU; 2 = waves per
- * tile (4 or 8); 3 = persistent workgroups per CU of the 128-tile 8-wave variant. */
+/* tuning hook for launch geometry (never changes results): key 0 = XCD affinity of the predict kernel
+ * (-1 auto, 0 by walker tile, 1 by row block, 2 by GP); 1 = persistent 64-tile workgroups per CU;
+ * 2 = waves per tile (4 or 8); 3 = persistent workgroups per CU of the 128-tile 8-wave variant;
+ * 4 = outer panel width of the blocked Cholesky; 5 = tile order when every predict tile has its own
+ * co-resident workgroup (0 ticket queues, 1 sorted, 2 snake over the CUs, 3 snake of pairs);
+ * 6 = persistent 64x32-tile workgroups per CU;
+ * 7 = largest padded walker batch that uses 64x32 tiles; 8 = largest batch whose block log-likelihood
+ * (PCA mode, 32 < M <= 64) runs one workgroup per walker instead of one wave per walker. */
 int gpb_debug_tune(gpb_ctx* ctx, int key, int value);
 /* test hook: route gpb_loglike through the generic LDS/HBM Cholesky instead of the register-resident
  * fast path (PCA mode, M <= 64) so that both implementations can be checked against each other. */

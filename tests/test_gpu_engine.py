@@ -174,7 +174,7 @@ def test_lml_gradient_matches_oracle_and_finite_difference(eng):
 
 
 # ---------------------------------------------------------------- fused log-likelihood: both MVN kernels vs the oracle
-@pytest.mark.parametrize("M,P", [(4, 4), (13, 5), (32, 10), (64, 10), (64, 3), (100, 6)])
+@pytest.mark.parametrize("M,P", [(4, 4), (13, 5), (32, 10), (41, 7), (64, 10), (64, 3), (100, 6)])
 def test_loglike_fast_and_generic_paths(eng, M, P):
     from oracle import gp_oracle as O
     from gpbayestools_hic_amd import synth
@@ -195,6 +195,13 @@ def test_loglike_fast_and_generic_paths(eng, M, P):
     ref = np.array([O.mvn_loglike(a, c) for a, c in zip(mY - yexp, mC + cexp)])
     fast = eng.loglike(Xw).copy()
     assert eng.last_not_pd == 0
+    if 32 < M <= 64:
+        # one wave per walker and one workgroup per walker apply the same operations to every element:
+        # the batch-size switch between them never changes a bit
+        eng.tune("mvn_wg_switch", 0); one_wave = eng.loglike(Xw).copy()
+        eng.tune("mvn_wg_switch", 1 << 30); one_wg = eng.loglike(Xw).copy()
+        eng.tune("mvn_wg_switch", 768)
+        assert np.array_equal(one_wave, one_wg) and np.array_equal(one_wave, fast)
     eng.force_generic_mvn(True)
     gen = eng.loglike(Xw).copy()
     eng.force_generic_mvn(False)
@@ -234,8 +241,10 @@ def test_predict_tile_sizes_are_bit_identical(eng):
         eng.tune("waves", 4)
         for xcd in (0, 1, 2):                             # tile -> XCD queue maps only reorder the work
             eng.tune("xcd", xcd)
-            for tile in (64, 128):
+            for tile in (64, 128, 32):                    # 32 = 64 rows x 32 walkers
                 eng.force_tile(tile)
-                m2, v2 = eng.predict(Xs)
-                assert np.array_equal(m1, m2) and np.array_equal(v1, v2), (tile, xcd)
-        eng.force_tile(0); eng.tune("xcd", -1)
+                for order in (0, 1, 2, 3):                # ticket queues / static orders of a resident grid
+                    eng.tune("resident", order)
+                    m2, v2 = eng.predict(Xs)
+                    assert np.array_equal(m1, m2) and np.array_equal(v1, v2), (tile, xcd, order)
+        eng.force_tile(0); eng.tune("xcd", -1); eng.tune("resident", 2)
