@@ -43,7 +43,9 @@ PROTOTYPES = {
     "gpb_loglike": (C.c_int, [VP, VP, c_i64, C.c_int, VP, C.c_int, VP]),
     "gpb_logpost": (C.c_int, [VP, VP, c_i64, VP, C.c_int, VP, VP, C.c_double, C.c_double]),
     "gpb_mvn_loglike": (C.c_int, [VP, VP, VP, c_i64, c_i64, C.c_int, VP, VP]),
-    "gpb_box_finish": (C.c_int, [VP, VP, c_i64, VP, VP, C.c_double, C.c_double, VP]),
+    "gpb_box_finish": (C.c_int, [VP, VP, c_i64, c_i64, VP, VP, C.c_double, C.c_double, VP]),
+    "gpb_param_map_set": (C.c_int, [VP, c_i64, c_i64, VP, C.c_int32, VP, VP, C.c_int32]),
+    "gpb_param_map": (C.c_int, [VP, VP, c_i64, VP]),
     "gpb_stretch_propose": (C.c_int, [VP, VP, c_i64, c_i64, C.c_int, c_u64, c_u64, C.c_double, VP, VP, C.c_int]),
     "gpb_stretch_accept": (C.c_int, [VP, VP, VP, c_i64, c_i64, C.c_int, c_u64, c_u64, VP, VP, VP, VP, C.c_int]),
     "gpb_test_split_perm": (C.c_int, [VP, c_i64, c_u64, c_u64, VP]),

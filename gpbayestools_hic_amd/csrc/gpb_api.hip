@@ -120,7 +120,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     dev_free(&ctx->alpha); dev_free(&ctx->apart); dev_free(&ctx->info); dev_free(&ctx->lmlbuf);
     dev_free(&ctx->gpart); dev_free(&ctx->Xs); dev_free(&ctx->estd); dev_free(&ctx->KsT); dev_free(&ctx->mpart);
     dev_free(&ctx->spart); dev_free(&ctx->mean_pc); dev_free(&ctx->var_pc); dev_free(&ctx->out_stage);
-    dev_free(&ctx->vbuf); dev_free(&ctx->covbuf);
+    dev_free(&ctx->vbuf); dev_free(&ctx->covbuf); dev_free(&ctx->pmap_int); dev_free(&ctx->pmap_tab);
     dev_free(&ctx->A); dev_free(&ctx->mu); dev_free(&ctx->scale); dev_free(&ctx->C0); dev_free(&ctx->yexp);
     dev_free(&ctx->Cexp); dev_free(&ctx->mvn_ws); dev_free(&ctx->notpd); dev_free(&ctx->tile_counter);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

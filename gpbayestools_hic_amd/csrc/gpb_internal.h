@@ -92,6 +92,12 @@ struct gpb_ctx {
     bool force_generic_mvn = false; // test hook: bypass the register-resident MVN fast path
     int64_t mvn_wg_switch = 768;    // batches up to this size use one workgroup per walker (32 < M <= 64)
 
+    // ---- parameterTrafoPCA input map (gpb_pmap.hip) ------------------------------------
+    int* pmap_int = nullptr;       // col_src[d_out] | group descriptors [G][6]
+    double* pmap_tab = nullptr;    // [G][4 + maxpc][100]
+    int64_t pmap_d_in = 0, pmap_d_out = 0;
+    int pmap_groups = 0, pmap_maxpc = 0;
+
     // ---- profiling (HIP events around k_predict) ------------------------------------
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

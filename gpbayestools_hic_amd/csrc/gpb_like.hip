@@ -649,12 +649,13 @@ static int half_bits(int64_t n) {
 
 using namespace gpb;
 
-extern "C" int gpb_box_finish(gpb_ctx* ctx, const double* X_dev, int64_t W, const double* lo_dev,
+extern "C" int gpb_box_finish(gpb_ctx* ctx, const double* X_dev, int64_t W, int64_t d, const double* lo_dev,
                               const double* hi_dev, double outside_value, double inside_const,
                               double* ll_inout_dev) {
-    if (!ctx || W < 0) return GPB_E_ARG;
+    if (!ctx || W < 0 || d < 1 || !X_dev || !lo_dev || !hi_dev || !ll_inout_dev) return GPB_E_ARG;
     if (W == 0) return 0;
-    hipLaunchKernelGGL(k_box, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, ctx->stream, X_dev, W, (int)ctx->d,
+    GPB_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_box, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, ctx->stream, X_dev, W, (int)d,
                        lo_dev, hi_dev, outside_value, inside_const, ll_inout_dev);
     GPB_HIP(hipGetLastError());
     return 0;

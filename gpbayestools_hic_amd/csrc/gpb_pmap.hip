@@ -1,0 +1,116 @@
+// gpb_pmap.hip — device pre-pass for the reference's parameterTrafoPCA option (src/emulator.py:492-551):
+// three groups of model parameters are replaced by the leading principal components of the functions they
+// parametrise (zeta/s(T) :102-108, eta/s(mu_B) :111-117, y_loss(y_init) :120-126), each evaluated on a
+// 100-point grid, standardised and projected.  The reference does this with Python double loops per
+// prediction row; inside an MCMC step it would be the only host round trip, so it runs here: one workgroup
+// per walker, the grid functions land in LDS, one thread per output column does the projection.
+#include "gpb_internal.h"
+#include <math.h>
+
+namespace gpb {
+
+constexpr int PMAP_GRID = 100;
+
+// fn 0: zeta/s(T; zeta_max, T_zeta0, sigma_plus, sigma_minus) at mu_B = 0
+// fn 1: eta/s(mu_B; eta_0, eta_2, eta_4)      fn 2: y_loss(y_init; yloss_2, yloss_4, yloss_6)
+__device__ __forceinline__ double pmap_fn(int fn, const double* par, double g) {
+    if (fn == 0) {
+        const double zmax = par[0], T0 = par[1], sp = par[2], sm = par[3];
+        const double Tmu = T0 - 0.15 * 0.0;
+        const double sig = (g < T0) ? sm : sp;
+        const double dT = g - Tmu;
+        return zmax * exp(-(dT * dT) / (2.0 * (sig * sig)));
+    } else if (fn == 1) {
+        const double e0 = par[0], e2 = par[1], e4 = par[2];
+        if (0.0 < g && g <= 0.2) return e0 + (e2 - e0) * (g / 0.2);
+        if (0.2 < g && g < 0.4) return e2 + (e4 - e2) * ((g - 0.2) / 0.2);
+        return e4 + 0.0 * g;
+    } else {
+        const double y2 = par[0], y4 = par[1], y6 = par[2];
+        if (0.0 < g && g <= 2.0) return y2 * (g / 2.0);
+        if (2.0 < g && g < 4.0) return y2 + (y4 - y2) * ((g - 2.0) / 2.0);
+        return y4 + (y6 - y4) * ((g - 4.0) / 2.0);
+    }
+}
+
+// desc[g] = {fn, col0, col1, col2, col3, npc};  tab[g] = grid | scaler mean | scaler scale | pca mean | comps[maxpc]
+__global__ __launch_bounds__(128) void k_param_map(const double* __restrict__ X, int64_t W, int d_in, int d_out,
+                                                   const int* __restrict__ col_src, int G, int maxpc,
+                                                   const int* __restrict__ desc, const double* __restrict__ tab,
+                                                   double* __restrict__ out) {
+    extern __shared__ double u[];            // [G][PMAP_GRID] standardised, centred function values
+    const int64_t w = blockIdx.x;
+    const int t = threadIdx.x;
+    const double* x = X + w * d_in;
+    if (t < PMAP_GRID) {
+        for (int g = 0; g < G; ++g) {
+            const int* dg = desc + 6 * g;
+            const double* tg = tab + (size_t)g * (4 + maxpc) * PMAP_GRID;
+            double par[4];
+            for (int k = 0; k < 4; ++k) par[k] = (dg[1 + k] >= 0) ? x[dg[1 + k]] : 0.0;
+            const double f = pmap_fn(dg[0], par, tg[t]);
+            u[g * PMAP_GRID + t] = (f - tg[PMAP_GRID + t]) / tg[2 * PMAP_GRID + t] - tg[3 * PMAP_GRID + t];
+        }
+    }
+    __syncthreads();
+    for (int j = t; j < d_out; j += 128) {
+        const int src = col_src[j];
+        double v;
+        if (src >= 0) {
+            v = x[src];
+        } else {
+            const int code = -1 - src, g = code / maxpc, c = code - g * maxpc;
+            const double* comp = tab + ((size_t)g * (4 + maxpc) + 4 + c) * PMAP_GRID;
+            v = 0.0;
+            for (int k = 0; k < PMAP_GRID; ++k) v = fma(u[g * PMAP_GRID + k], comp[k], v);
+        }
+        out[w * d_out + j] = v;
+    }
+}
+
+}  // namespace gpb
+
+using namespace gpb;
+
+extern "C" int gpb_param_map_set(gpb_ctx* ctx, int64_t d_in, int64_t d_out, const int32_t* col_src,
+                                 int32_t n_groups, const int32_t* group_desc, const double* tables, int32_t maxpc) {
+    if (!ctx) return GPB_E_ARG;
+    if (d_in < 1 || d_out < 1 || n_groups < 1 || n_groups > 8 || maxpc < 1 || !col_src || !group_desc || !tables)
+        GPB_FAIL(GPB_E_ARG, "gpb_param_map_set: bad sizes or null input");
+    for (int64_t j = 0; j < d_out; ++j) {
+        const int s = col_src[j];
+        if (s >= d_in || (s < 0 && (-1 - s) >= n_groups * maxpc)) GPB_FAIL(GPB_E_ARG, "gpb_param_map_set: bad column map");
+    }
+    for (int g = 0; g < n_groups; ++g) {
+        const int32_t* dg = group_desc + 6 * g;
+        if (dg[0] < 0 || dg[0] > 2 || dg[5] < 1 || dg[5] > maxpc) GPB_FAIL(GPB_E_ARG, "gpb_param_map_set: bad group");
+        for (int k = 1; k <= 4; ++k)
+            if (dg[k] >= d_in) GPB_FAIL(GPB_E_ARG, "gpb_param_map_set: group column out of range");
+    }
+    GPB_HIP(hipSetDevice(ctx->device));
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->pmap_int) { GPB_HIP(hipFree(ctx->pmap_int)); ctx->pmap_int = nullptr; }
+    if (ctx->pmap_tab) { GPB_HIP(hipFree(ctx->pmap_tab)); ctx->pmap_tab = nullptr; }
+    const size_t ni = (size_t)d_out + 6 * (size_t)n_groups;
+    const size_t nt = (size_t)n_groups * (4 + maxpc) * PMAP_GRID;
+    GPB_HIP(hipMalloc(&ctx->pmap_int, ni * sizeof(int)));
+    GPB_HIP(hipMalloc(&ctx->pmap_tab, nt * sizeof(double)));
+    GPB_HIP(hipMemcpy(ctx->pmap_int, col_src, (size_t)d_out * sizeof(int), hipMemcpyHostToDevice));
+    GPB_HIP(hipMemcpy(ctx->pmap_int + d_out, group_desc, 6 * (size_t)n_groups * sizeof(int), hipMemcpyHostToDevice));
+    GPB_HIP(hipMemcpy(ctx->pmap_tab, tables, nt * sizeof(double), hipMemcpyHostToDevice));
+    ctx->pmap_d_in = d_in; ctx->pmap_d_out = d_out; ctx->pmap_groups = n_groups; ctx->pmap_maxpc = maxpc;
+    return 0;
+}
+
+extern "C" int gpb_param_map(gpb_ctx* ctx, const double* X_dev, int64_t W, double* out_dev) {
+    if (!ctx || !X_dev || !out_dev || W < 0) return GPB_E_ARG;
+    if (!ctx->pmap_int) GPB_FAIL(GPB_E_STATE, "gpb_param_map before gpb_param_map_set");
+    if (W == 0) return 0;
+    GPB_HIP(hipSetDevice(ctx->device));
+    const int d_out = (int)ctx->pmap_d_out;
+    hipLaunchKernelGGL(k_param_map, dim3((unsigned)W), dim3(128), (size_t)ctx->pmap_groups * PMAP_GRID * sizeof(double),
+                       ctx->stream, X_dev, W, (int)ctx->pmap_d_in, d_out, ctx->pmap_int, ctx->pmap_groups,
+                       ctx->pmap_maxpc, ctx->pmap_int + d_out, ctx->pmap_tab, out_dev);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}

@@ -247,6 +247,8 @@ class Emulator:
             eng.set_transform(self._mode, self.scaler.mean_, scale=self.scaler.scale_)
         else:
             eng.set_transform(self._mode, self.scaler.mean_, A=self._A, cov_trunc=self._cov_trunc)
+        if self.parameterTrafoPCA_:                  # device pre-pass for resident log-posterior loops
+            eng.set_param_map(self._ppca, self.design_points.shape[1])
 
     # ------------------------------------------------------------------ engine lifetime
     def _new_engine(self):

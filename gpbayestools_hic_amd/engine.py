@@ -67,6 +67,11 @@ class GPEngine:
         if self.N == 0:
             raise nat.GPBError("no GP data: call set_data / set_theta / factor first")
 
+    def _check_cols(self, X_dev):
+        """device inputs are used as they are: the kernels index them with the engine's d"""
+        if X_dev.dim() != 2 or X_dev.shape[1] != self.d or str(X_dev.dtype) != "torch.float64":
+            raise ValueError("expected a float64 [W, %d] tensor, got %s %s" % (self.d, X_dev.dtype, tuple(X_dev.shape)))
+
     # ------------------------------------------------------------------ GP state
     def set_data(self, X, Z, kernel="RBF", alpha=0.1):
         """X[N,d] design, Z[P,N] targets (one row per GP)."""
@@ -112,6 +117,7 @@ class GPEngine:
         self._need_data()
         if _is_torch(Xs):
             import torch
+            self._check_cols(Xs)
             W = Xs.shape[0]
             mean = torch.empty((W, self.P), dtype=torch.float64, device=Xs.device)
             var = torch.empty((W, self.P), dtype=torch.float64, device=Xs.device) if return_var else None
@@ -148,6 +154,7 @@ class GPEngine:
         self._need_data()
         if _is_torch(Xs):
             import torch
+            self._check_cols(Xs)
             W = Xs.shape[0]
             mean = torch.empty((W, self.M), dtype=torch.float64, device=Xs.device)
             cov = torch.empty((W, self.M, self.M), dtype=torch.float64, device=Xs.device) if return_cov else None
@@ -175,6 +182,7 @@ class GPEngine:
         npd = C.c_int(0)
         if _is_torch(Xs):
             import torch
+            self._check_cols(Xs)
             W = Xs.shape[0]
             if out is None:
                 out = torch.empty(W, dtype=torch.float64, device=Xs.device)
@@ -195,6 +203,10 @@ class GPEngine:
     def logpost(self, X_dev, out, accumulate, lo_dev, hi_dev, outside, const):
         """Fused device log-posterior of the last emulator block: log-likelihood (+= when accumulate),
         strict prior box, constant.  Asynchronous; torch cuda tensors only."""
+        self._need_data()
+        self._check_cols(X_dev)
+        if lo_dev.numel() != self.d or hi_dev.numel() != self.d or out.numel() != X_dev.shape[0]:
+            raise ValueError("logpost: shapes of lo, hi, out do not match X")
         self._ck(self.lib.gpb_logpost(self.h, nat.ptr(X_dev), X_dev.shape[0], nat.ptr(out), 1 if accumulate else 0,
                                       nat.ptr(lo_dev), nat.ptr(hi_dev), float(outside), float(const)))
         return out
@@ -218,8 +230,48 @@ class GPEngine:
         return out
 
     def box_finish(self, X_dev, lo_dev, hi_dev, outside, const, ll_dev):
-        self._ck(self.lib.gpb_box_finish(self.h, nat.ptr(X_dev), X_dev.shape[0], nat.ptr(lo_dev), nat.ptr(hi_dev),
+        W, d = X_dev.shape
+        if lo_dev.numel() != d or hi_dev.numel() != d or ll_dev.numel() != W:
+            raise ValueError("box_finish: shapes of X, lo, hi, ll do not match")
+        self._ck(self.lib.gpb_box_finish(self.h, nat.ptr(X_dev), W, d, nat.ptr(lo_dev), nat.ptr(hi_dev),
                                          float(outside), float(const), nat.ptr(ll_dev)))
+
+    # ------------------------------------------------------------------ parameterTrafoPCA input map
+    def set_param_map(self, ppca, d_in):
+        """Upload the fitted parameter-space PCA (param_pca.ParameterPCA) for the device pre-pass."""
+        from .param_pca import IDX_BULK, IDX_SHEAR, IDX_YLOSS, T_GRID, MUB_GRID, YINIT_GRID
+        grids = (T_GRID, MUB_GRID, YINIT_GRID)
+        idx = (IDX_BULK, IDX_SHEAR, IDX_YLOSS)
+        G = len(ppca.groups)
+        maxpc = int(max(g.pca.n_components_ for g in ppca.groups))
+        # column bookkeeping exactly as the reference does it on the values (delete, then append)
+        cols = np.arange(d_in, dtype=np.int64)
+        desc = np.full((G, 6), -1, dtype=np.int32)
+        tab = np.zeros((G, 4 + maxpc, 100))
+        for gi, g in enumerate(ppca.groups):
+            k = int(g.pca.n_components_)
+            cols = np.concatenate((np.delete(cols, idx[gi]), -1 - (gi * maxpc + np.arange(k))))
+            desc[gi, 0] = gi
+            desc[gi, 1:1 + len(idx[gi])] = idx[gi]
+            desc[gi, 5] = k
+            tab[gi, 0], tab[gi, 1], tab[gi, 2], tab[gi, 3] = grids[gi], g.scaler.mean_, g.scaler.scale_, g.pca.mean_
+            tab[gi, 4:4 + k] = g.pca.components_
+        col_src = np.ascontiguousarray(cols, dtype=np.int32)
+        self.pmap_d_in, self.pmap_d_out = int(d_in), int(col_src.shape[0])
+        self._ck(self.lib.gpb_param_map_set(self.h, self.pmap_d_in, self.pmap_d_out, nat.ptr(col_src), G,
+                                            nat.ptr(np.ascontiguousarray(desc)), nat.ptr(np.ascontiguousarray(tab)),
+                                            maxpc))
+
+    def param_map(self, X_dev, out=None):
+        """X_dev[W, d_in] (torch cuda f64) -> GP input [W, d_out] on the device, asynchronous."""
+        import torch
+        W, d = X_dev.shape
+        if d != getattr(self, "pmap_d_in", -1):
+            raise ValueError("param_map: X has %d columns, the map expects %d" % (d, getattr(self, "pmap_d_in", -1)))
+        if out is None:
+            out = torch.empty((W, self.pmap_d_out), dtype=torch.float64, device=X_dev.device)
+        self._ck(self.lib.gpb_param_map(self.h, nat.ptr(X_dev.contiguous()), W, nat.ptr(out)))
+        return out
 
     # ------------------------------------------------------------------ diagnostics
     def test_gemm(self, A, B, mode=0, tile=128):

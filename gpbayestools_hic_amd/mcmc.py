@@ -167,10 +167,17 @@ class Chain:
             lo_dev, hi_dev = self._box_dev
         X_dev = X_dev.contiguous()
         last = len(self.emuList) - 1
+        if X_dev.shape[1] != self.ndim:
+            raise ValueError("log_prob_device: X has %d columns, the chain has %d parameters" % (X_dev.shape[1], self.ndim))
         for i, emu in enumerate(self.emuList):      # all engines enqueue on torch's current stream: ordered
             eng = emu._engine_ready()
-            if i < last:
-                eng.loglike(X_dev, out=out, accumulate=(i > 0), check=False)
+            mapped = getattr(emu, "parameterTrafoPCA_", False)
+            # parameterTrafoPCA emulators see the PCA-reduced parameters (src/emulator.py:492-551): device pre-pass
+            Xg = eng.param_map(X_dev) if mapped else X_dev
+            if i < last or mapped:
+                eng.loglike(Xg, out=out, accumulate=(i > 0), check=False)
+                if i == last:                        # the prior box is over the ORIGINAL parameters
+                    eng.box_finish(X_dev, lo_dev, hi_dev, outside, EXTRA_STD_CONST, out)
             else:                                    # last block: likelihood + prior box + constant, one call
                 eng.logpost(X_dev, out, i > 0, lo_dev, hi_dev, outside, EXTRA_STD_CONST)
         return out

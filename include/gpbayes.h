@@ -145,9 +145,22 @@ int gpb_mvn_loglike(gpb_ctx* ctx, const double* dY, const double* cov, int64_t W
  * gpb_box_finish <- inside=all(min<X<max) (strict); lp[~inside]=-inf|-1e300;
  *                   lp[inside] = ll + const                             src/mcmc.py:194-198,220-221,275-276,296-297
  */
-int gpb_box_finish(gpb_ctx* ctx, const double* X_dev /*[W,d]*/, int64_t W,
+int gpb_box_finish(gpb_ctx* ctx, const double* X_dev /*[W,d]*/, int64_t W, int64_t d,
                    const double* lo_dev, const double* hi_dev, double outside_value,
                    double inside_const, double* ll_inout_dev /*[W]*/);
+
+/* ---- parameterTrafoPCA input map (device pre-pass) -------------------------------- *
+ * gpb_param_map_set <- the fitted scalers / PCAs of the three parameter groups          src/emulator.py:79-241
+ * gpb_param_map     <- the per-row mapping X[W,d_in] -> GP input [W,d_out] that
+ *                      Emulator.predict performs with Python loops before the GP calls  src/emulator.py:492-551
+ * col_src[j] >= 0: output column j is original column col_src[j]; col_src[j] = -1 - (g*maxpc + c): principal
+ * component c of group g.  group_desc[g] = {fn, col0, col1, col2, col3 (-1 = unused), npc}, fn 0 = zeta/s(T)
+ * (:102-108), 1 = eta/s(mu_B) (:111-117), 2 = y_loss(y_init) (:120-126).  tables[g] = grid[100] | scaler mean[100]
+ * | scaler scale[100] | PCA mean[100] | components[maxpc][100]. */
+int gpb_param_map_set(gpb_ctx* ctx, int64_t d_in, int64_t d_out, const int32_t* col_src /*[d_out]*/,
+                      int32_t n_groups, const int32_t* group_desc /*[G][6]*/,
+                      const double* tables /*[G][4+maxpc][100]*/, int32_t maxpc);
+int gpb_param_map(gpb_ctx* ctx, const double* X_dev /*[W,d_in]*/, int64_t W, double* out_dev /*[W,d_out]*/);
 
 /* ---- emcee-equivalent stretch move (device resident) ------------------------------ *
  * Replaces emcee.EnsembleSampler.sample as driven by LoggingEnsembleSampler.run_mcmc

@@ -52,3 +52,42 @@ def test_emulator_with_parameter_pca_gpu(tmp_path):
     mean, cov = emu.predict(g["Xs"], return_cov=True, extra_std=0.0)
     assert relerr(mean, g["mean"]) < 1e-8
     assert maxrel(cov, g["cov"]) < 1e-7
+
+
+@pytest.mark.gpu
+def test_chain_with_parameter_pca_uses_device_map(tmp_path):
+    """Chain.log_posterior over a parameterTrafoPCA emulator: the device pre-pass (gpb_param_map) feeds the GP
+    kernels, the prior box stays on the original parameters (src/emulator.py:492-551, src/mcmc.py:261-299)."""
+    import torch
+    from oracle import gp_oracle as O
+    from gpbayestools_hic_amd import Chain, Emulator, synth
+    g = golden("g7_param_pca.npz")
+    tp, pf, ep = str(tmp_path / "t.pkl"), str(tmp_path / "p.txt"), str(tmp_path / "e.pkl")
+    synth.write_training_pickle(tp, g["X"], g["Y"], 0.01)
+    synth.write_parameter_file(pf, g["lo"], g["hi"])
+    emu = Emulator(training_set_path=tp, parameter_file=pf, npc=int(g["npc"]), parameterTrafoPCA=True)
+    emu.trainEmulator([True] * emu.nev, thetas=g["thetas"])
+    eng = emu._engine_ready()
+    Xd = torch.as_tensor(np.ascontiguousarray(g["Xs"]), device="cuda")
+    assert maxrel(eng.param_map(Xd).cpu().numpy(), emu._ppca.transform(g["Xs"])) < 1e-12
+    with pytest.raises(ValueError):
+        eng.loglike(Xd)                                   # 20 raw columns are not a GP input of this engine
+    yexp = g["mean"][0]
+    err = 0.05 * np.abs(yexp)
+    synth.write_experiment_pickle(ep, yexp, err)
+    chain = Chain(mcmc_path=str(tmp_path / "mcmc" / "c.pkl"), expdata_path=ep, model_parafile=pf)
+    chain.emuList = [emu]
+    Xw = g["Xs"].copy()
+    Xw[3, 0] = g["hi"][0] + 0.1                           # outside the prior box in an ORIGINAL parameter
+    Xw[5, 16] = g["lo"][16]                               # on the boundary: outside (strict inequalities)
+    inside = np.ones(len(Xw), bool); inside[[3, 5]] = False
+    lp = chain.log_posterior(Xw)
+    assert np.all(np.isneginf(lp[~inside])) and np.all(np.isfinite(lp[inside]))
+    assert np.all(chain.log_likelihood(Xw, finite=True)[~inside] == -1e300)
+    # against the reference's own predictions (golden) ...
+    ref = np.array([O.mvn_loglike(m - yexp, c + np.diag(err ** 2)) for m, c in zip(g["mean"], g["cov"])]) + O.EXTRA_STD_CONST
+    assert relerr(lp[inside], ref[inside]) < 1e-6
+    # ... and against the host-mapped route of this build (isolates the device map)
+    mY, mC = chain._predict(Xw[inside], 0.0)
+    ref2 = np.array([O.mvn_loglike(m - yexp, c + np.diag(err ** 2)) for m, c in zip(mY, mC)]) + O.EXTRA_STD_CONST
+    assert relerr(lp[inside], ref2) < 1e-10
