@@ -589,6 +589,7 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 6: if (value < 1 || value > 10) return GPB_E_ARG; ctx->wgs_per_cu32 = value; break;
         case 7: if (value < 0) return GPB_E_ARG; ctx->narrow_switch = value; break;
         case 8: if (value < 0) return GPB_E_ARG; ctx->mvn_wg_switch = value; break;
+        case 9: if (value != 64 && value != 128) return GPB_E_ARG; ctx->chol_inner_tile = value; break;
         default: return GPB_E_ARG;
     }
     return 0;

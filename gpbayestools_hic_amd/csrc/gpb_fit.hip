@@ -251,43 +251,21 @@ __global__ __launch_bounds__(256) void k_potf2_inv(double* __restrict__ K, doubl
     }
 }
 
-// Panel: L_ik = A_ik * L_kk^-T for the 64-row blocks below the diagonal block.
-__global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ K, const double* __restrict__ Linv,
-                                                    int64_t Np, int64_t kb) {
-    __shared__ double a[64][65];
-    __shared__ double x[64][65];
-    const int p = blockIdx.y, tid = threadIdx.x;
+// Panel: L_ik = A_ik * L_kk^-T for the 64-row blocks below the diagonal block — one 64x64x64 NT product per
+// workgroup on the MFMA tile engine, in place (every workgroup owns its rows; all of its reads are staged
+// through LDS before the first store).
+__global__ __launch_bounds__(256, 2) void k_trsm_panel(double* __restrict__ K, const double* __restrict__ Linv,
+                                                       int64_t Np, int64_t kb) {
+    __shared__ TileLds<64> lds;
+    const int p = blockIdx.y;
     const int64_t c0 = kb * 64, r0 = (kb + 1 + blockIdx.x) * 64;
     double* Ap = K + (int64_t)p * Np * Np + r0 * Np + c0;
     const double* Xp = Linv + (int64_t)p * Np * Np + c0 * Np + c0;
-    for (int e = tid; e < 64 * 64; e += 256) {
-        const int r = e >> 6, c = e & 63;
-        a[r][c] = Ap[(int64_t)r * Np + c];
-        x[r][c] = Xp[(int64_t)r * Np + c];
-    }
-    __syncthreads();
-    const int ty = tid >> 4, tx = tid & 15;
-    double o[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) o[u][v] = 0.0;
-    // out[i][j] = sum_k a[i][k] * x[j][k]
-    for (int k = 0; k < 64; ++k) {
-        double ai[4], xj[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) ai[u] = a[ty + 16 * u][k];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) xj[v] = x[tx + 16 * v][k];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) o[u][v] = fma(ai[u], xj[v], o[u][v]);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) Ap[(int64_t)(ty + 16 * u) * Np + tx + 16 * v] = o[u][v];
+    Acc<64> acc;
+    acc_zero<64>(acc);
+    // out[i][j] = sum_k A[i][k] * X[j][k]
+    gemm_tile_loop<64, false, true>(Ap, Np, Xp, Np, 0, 0, 64, 64, 0, 64, lds, acc);
+    tile_store<64>(Ap, Np, 0, 0, 64, 64, 1.0, false, acc);
 }
 
 // Trailing update (SYRK on MFMA): A[i][j] -= sum_{k in [c0, c0+kw)} L[i][k] L[j][k] for rows i >= r0 and
@@ -295,20 +273,21 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ K, cons
 // inside an outer panel of `NBO` columns the update after every 64-column step touches the panel's own
 // remaining columns only (kw = 64, ce = panel end); once per outer panel the whole trailing matrix is
 // updated with kw = NBO.  A K=64 update moves 384 KB per 2.1 MFLOP tile and is HBM-bound; K=256 is not.
+template <int T>
 __global__ __launch_bounds__(256, 2) void k_syrk(double* __restrict__ K, int64_t Np, int64_t c0, int kw,
                                                  int64_t r0, int64_t ce) {
-    __shared__ TileLds<128> lds;
+    __shared__ TileLds<T> lds;
     const int p = blockIdx.z;
-    const int64_t mb = (int64_t)blockIdx.y * 128, nb = (int64_t)blockIdx.x * 128;   // relative to (r0, r0)
-    if (mb + 128 <= nb) return;                        // entirely above the diagonal
-    const int m_ext = (int)imin64(128, Np - r0 - mb), n_ext = (int)imin64(128, ce - r0 - nb);
+    const int64_t mb = (int64_t)blockIdx.y * T, nb = (int64_t)blockIdx.x * T;       // relative to (r0, r0)
+    if (mb + T <= nb) return;                          // entirely above the diagonal
+    const int m_ext = (int)imin64(T, Np - r0 - mb), n_ext = (int)imin64(T, ce - r0 - nb);
     if (m_ext <= 0 || n_ext <= 0) return;
     double* Kp = K + (int64_t)p * Np * Np;
     const double* Pn = Kp + r0 * Np + c0;              // panel rows r0.., cols c0..c0+kw
-    Acc<128> acc;
-    acc_zero<128>(acc);
-    gemm_tile_loop<128, false, true>(Pn, Np, Pn, Np, mb, nb, m_ext, n_ext, 0, kw, lds, acc);
-    tile_store<128>(Kp + r0 * Np + r0, Np, mb, nb, m_ext, n_ext, -1.0, true, acc);
+    Acc<T> acc;
+    acc_zero<T>(acc);
+    gemm_tile_loop<T, false, true>(Pn, Np, Pn, Np, mb, nb, m_ext, n_ext, 0, kw, lds, acc);
+    tile_store<T>(Kp + r0 * Np + r0, Np, mb, nb, m_ext, n_ext, -1.0, true, acc);
 }
 
 int launch_potrf(gpb_ctx* ctx) {
@@ -325,12 +304,20 @@ int launch_potrf(gpb_ctx* ctx) {
         if (rem <= 0) break;
         hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)rem, (unsigned)ctx->P), dim3(256), 0, ctx->stream, ctx->K,
                            ctx->Linv, Np, kb);
-        if (r0 < pe) {                                  // inside the panel: its remaining columns only, K = 64
-            dim3 grid((unsigned)((pe - r0 + 127) / 128), (unsigned)((Np - r0 + 127) / 128), (unsigned)ctx->P);
-            hipLaunchKernelGGL(k_syrk, grid, dim3(256), 0, ctx->stream, ctx->K, Np, c0, 64, r0, pe);
+        if (r0 < pe) {
+            // inside the panel: its remaining columns only, K = 64.  Four K-steps per tile: the launch is pure
+            // latency (one wave issues an f64 MFMA every ~138 cycles), so 64x64 tiles — a quarter of the MFMA
+            // chain per wave, four times the workgroups
+            if (ctx->chol_inner_tile == 64) {
+                dim3 grid((unsigned)((pe - r0 + 63) / 64), (unsigned)((Np - r0 + 63) / 64), (unsigned)ctx->P);
+                hipLaunchKernelGGL(k_syrk<64>, grid, dim3(256), 0, ctx->stream, ctx->K, Np, c0, 64, r0, pe);
+            } else {
+                dim3 grid((unsigned)((pe - r0 + 127) / 128), (unsigned)((Np - r0 + 127) / 128), (unsigned)ctx->P);
+                hipLaunchKernelGGL(k_syrk<128>, grid, dim3(256), 0, ctx->stream, ctx->K, Np, c0, 64, r0, pe);
+            }
         } else {                                        // panel finished: whole trailing matrix, K = panel width
             dim3 grid((unsigned)((Np - r0 + 127) / 128), (unsigned)((Np - r0 + 127) / 128), (unsigned)ctx->P);
-            hipLaunchKernelGGL(k_syrk, grid, dim3(256), 0, ctx->stream, ctx->K, Np, pb, (int)(pe - pb), r0, Np);
+            hipLaunchKernelGGL(k_syrk<128>, grid, dim3(256), 0, ctx->stream, ctx->K, Np, pb, (int)(pe - pb), r0, Np);
         }
     }
     GPB_HIP(hipGetLastError());

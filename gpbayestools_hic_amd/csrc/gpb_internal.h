@@ -84,7 +84,8 @@ struct gpb_ctx {
     int64_t narrow_switch = 128;    // padded walker batches up to this size use 64x32 tiles (0 = never)
     int predict_waves = 4;          // waves per k_predict tile (4 or 8)
     unsigned* tile_counter = nullptr;   // 8 ticket queues (stride 16) + done counter [128]; re-armed by the kernel
-    int64_t chol_outer = 256;       // outer panel width of the two-level blocked Cholesky
+    int64_t chol_outer = 512;      // outer panel width of the two-level blocked Cholesky
+    int chol_inner_tile = 64;       // tile of the K=64 trailing updates inside an outer panel (64 or 128)
     int resident_order = 2;         // k_predict with one workgroup per tile: 0 = ticket queues, 1-3 = static orders (2 = snake)
     int force_tile = 0;            // test hook: 0 = auto, 64 / 128 / 32 (= 64x32) force the k_predict tile
     int force_xcd = -1;             // tuning hook: -1 auto, 0 / 1 = k_predict XCD affinity by walker tile / row block

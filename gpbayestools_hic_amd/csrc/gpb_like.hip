@@ -599,7 +599,11 @@ __device__ __forceinline__ SplitPerm make_perm(uint64_t seed, uint32_t step, int
 __global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, int half, uint64_t seed,
                           uint32_t step, double a, double* __restrict__ q, double* __restrict__ factor, int hb,
                           int randomize) {
-    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    // 32 lanes per walker (one parameter each): these kernels sit between the log-probability batches of a
+    // step, so they are organised for latency, not for thread economy — every lane redoes the walker's draws
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t k = gid >> 5;
+    const int t0 = (int)(gid & 31);
     if (k >= nhalf) return;
     const SplitPerm pi = make_perm(seed, step, 2 * nhalf, hb, randomize);
     const U4 r = philox(seed, (uint32_t)k, step, (uint32_t)half, 0u);
@@ -609,26 +613,33 @@ __global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, 
     const int64_t j = (int64_t)(((uint64_t)r.z * (uint64_t)nhalf) >> 32);
     const double* s = pos + pi(2 * k + half) * d;
     const double* c = pos + pi(2 * j + (1 - half)) * d;
-#pragma unroll 8
-    for (int t = 0; t < d; ++t) q[k * d + t] = c[t] - (c[t] - s[t]) * zz;
-    factor[k] = (d - 1.0) * log(zz);
+    for (int t = t0; t < d; t += 32) q[k * d + t] = c[t] - (c[t] - s[t]) * zz;
+    if (t0 == 0) factor[k] = (d - 1.0) * log(zz);
 }
 __global__ void k_accept(double* __restrict__ pos, double* __restrict__ lp, int64_t nhalf, int d, int half,
                          uint64_t seed, uint32_t step, const double* __restrict__ q,
                          const double* __restrict__ factor, const double* __restrict__ lpq,
                          long long* __restrict__ naccept, int hb, int randomize) {
-    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    // 32 lanes per walker, all inside one wave: every lane takes the same decision from the OLD lp[idx]
+    // (the load precedes lane 0's store in program order), then moves its own parameters
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t k = gid >> 5;
+    const int t0 = (int)(gid & 31);
     if (k >= nhalf) return;
     const SplitPerm pi = make_perm(seed, step, 2 * nhalf, hb, randomize);
     const U4 r = philox(seed, (uint32_t)k, step, (uint32_t)half, 1u);
     const double u = u01(r.x, r.y);
     const int64_t idx = pi(2 * k + half);
-    const double diff = factor[k] + lpq[k] - lp[idx];
-    if (diff > log(u)) {                                             // emcee RedBlueMove.propose
-#pragma unroll 8
-        for (int t = 0; t < d; ++t) pos[idx * d + t] = q[k * d + t];
-        lp[idx] = lpq[k];
-        if (naccept) naccept[idx] += 1;
+    const double lpq_k = lpq[k];
+    const double diff = factor[k] + lpq_k - lp[idx];
+    const bool take = diff > log(u);                                 // emcee RedBlueMove.propose
+    __builtin_amdgcn_wave_barrier();                                 // keep the loads above the stores below
+    if (take) {
+        for (int t = t0; t < d; t += 32) pos[idx * d + t] = q[k * d + t];
+        if (t0 == 0) {
+            lp[idx] = lpq_k;
+            if (naccept) naccept[idx] += 1;
+        }
     }
 }
 
@@ -667,7 +678,7 @@ extern "C" int gpb_stretch_propose(gpb_ctx* ctx, const double* pos_dev, int64_t 
     if (!ctx || nwalkers < 2 || (nwalkers & 1) || nwalkers > (1ll << 30) || d < 1 || (half != 0 && half != 1))
         return GPB_E_ARG;
     const int64_t nh = nwalkers / 2;
-    hipLaunchKernelGGL(k_propose, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev, nh, (int)d,
+    hipLaunchKernelGGL(k_propose, dim3((unsigned)((nh * 32 + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev, nh, (int)d,
                        half, seed, (uint32_t)step, a, q_dev, factor_dev, half_bits(nwalkers), randomize_split ? 1 : 0);
     GPB_HIP(hipGetLastError());
     return 0;
@@ -680,7 +691,7 @@ extern "C" int gpb_stretch_accept(gpb_ctx* ctx, double* pos_dev, double* lp_dev,
     if (!ctx || nwalkers < 2 || (nwalkers & 1) || nwalkers > (1ll << 30) || d < 1 || (half != 0 && half != 1))
         return GPB_E_ARG;
     const int64_t nh = nwalkers / 2;
-    hipLaunchKernelGGL(k_accept, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev, lp_dev, nh,
+    hipLaunchKernelGGL(k_accept, dim3((unsigned)((nh * 32 + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev, lp_dev, nh,
                        (int)d, half, seed, (uint32_t)step, q_dev, factor_dev, lpq_dev,
                        reinterpret_cast<long long*>(naccept_dev), half_bits(nwalkers), randomize_split ? 1 : 0);
     GPB_HIP(hipGetLastError());

@@ -208,7 +208,8 @@ int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
  * co-resident workgroup (0 ticket queues, 1 sorted, 2 snake over the CUs, 3 snake of pairs);
  * 6 = persistent 64x32-tile workgroups per CU;
  * 7 = largest padded walker batch that uses 64x32 tiles; 8 = largest batch whose block log-likelihood
- * (PCA mode, 32 < M <= 64) runs one workgroup per walker instead of one wave per walker. */
+ * (PCA mode, 32 < M <= 64) runs one workgroup per walker instead of one wave per walker;
+ * 9 = tile (64 or 128) of the K=64 trailing updates inside an outer Cholesky panel. */
 int gpb_debug_tune(gpb_ctx* ctx, int key, int value);
 /* test hook: route gpb_loglike through the generic LDS/HBM Cholesky instead of the register-resident
  * fast path (PCA mode, M <= 64) so that both implementations can be checked against each other. */
