@@ -57,6 +57,8 @@ PROTOTYPES = {
     "gpb_debug_force_tile": (C.c_int, [VP, C.c_int, c_i64]),
     "gpb_debug_tune": (C.c_int, [VP, C.c_int, C.c_int]),
     "gpb_debug_force_generic_mvn": (C.c_int, [VP, C.c_int]),
+    "gpb_debug_tile_trace": (C.c_int, [VP, c_i64]),
+    "gpb_debug_tile_trace_read": (C.c_int, [VP, VP, c_i64, VP]),
     "gpb_profile_enable": (C.c_int, [VP, C.c_int]),
     "gpb_profile_read": (C.c_int, [VP, VP, VP, VP]),
     "gpb_probe_fp64": (C.c_int, [VP, C.c_int, VP]),

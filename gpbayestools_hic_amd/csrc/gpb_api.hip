@@ -121,6 +121,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     dev_free(&ctx->gpart); dev_free(&ctx->Xs); dev_free(&ctx->estd); dev_free(&ctx->KsT); dev_free(&ctx->mpart);
     dev_free(&ctx->spart); dev_free(&ctx->mean_pc); dev_free(&ctx->var_pc); dev_free(&ctx->out_stage);
     dev_free(&ctx->vbuf); dev_free(&ctx->covbuf); dev_free(&ctx->pmap_int); dev_free(&ctx->pmap_tab);
+    dev_free(&ctx->tile_trace);
     dev_free(&ctx->A); dev_free(&ctx->mu); dev_free(&ctx->scale); dev_free(&ctx->C0); dev_free(&ctx->yexp);
     dev_free(&ctx->Cexp); dev_free(&ctx->mvn_ws); dev_free(&ctx->notpd); dev_free(&ctx->tile_counter);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -590,6 +591,7 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 7: if (value < 0) return GPB_E_ARG; ctx->narrow_switch = value; break;
         case 8: if (value < 0) return GPB_E_ARG; ctx->mvn_wg_switch = value; break;
         case 9: if (value != 64 && value != 128) return GPB_E_ARG; ctx->chol_inner_tile = value; break;
+        case 10: if (value < 0 || value > 1) return GPB_E_ARG; ctx->tile_priority = value; break;
         default: return GPB_E_ARG;
     }
     return 0;
@@ -624,6 +626,38 @@ extern "C" int gpb_profile_read(gpb_ctx* ctx, int64_t* launches, double* total_m
     *units = ctx->prof_units;
     ctx->prof_events.clear();
     ctx->prof_units = 0.0;
+    return 0;
+}
+
+// Debug hook: per-tile placement/timing records of k_predict (where the dispatcher put each tile, when it ran).
+// capacity > 0 arms the trace (and clears it), capacity == 0 disarms.  read copies up to max_records records of
+// 8 uint32 {HW_ID, XCC_ID, gp, row block, walker tile, t_start, t_end (100 MHz ticks), blockIdx} and re-arms.
+extern "C" int gpb_debug_tile_trace(gpb_ctx* ctx, int64_t capacity) {
+    if (!ctx || capacity < 0 || capacity > (1 << 22)) return GPB_E_ARG;
+    GPB_HIP(hipSetDevice(ctx->device));
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    dev_free(&ctx->tile_trace);
+    if (capacity == 0) return 0;
+    const size_t n = 8 + 8 * (size_t)capacity;
+    GPB_HIP(hipMalloc(&ctx->tile_trace, n * sizeof(unsigned)));
+    GPB_HIP(hipMemset(ctx->tile_trace, 0, n * sizeof(unsigned)));
+    const unsigned cap = (unsigned)capacity;
+    GPB_HIP(hipMemcpy(ctx->tile_trace + 1, &cap, sizeof(unsigned), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int gpb_debug_tile_trace_read(gpb_ctx* ctx, uint32_t* records_host, int64_t max_records, int64_t* n_out) {
+    if (!ctx || !records_host || !n_out || max_records < 0) return GPB_E_ARG;
+    if (!ctx->tile_trace) GPB_FAIL(GPB_E_STATE, "gpb_debug_tile_trace_read: trace not armed");
+    GPB_HIP(hipSetDevice(ctx->device));
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    unsigned head[2] = {0, 0};
+    GPB_HIP(hipMemcpy(head, ctx->tile_trace, sizeof(head), hipMemcpyDeviceToHost));
+    int64_t n = head[0] < head[1] ? head[0] : head[1];
+    if (n > max_records) n = max_records;
+    if (n > 0) GPB_HIP(hipMemcpy(records_host, ctx->tile_trace + 8, (size_t)n * 8 * sizeof(unsigned), hipMemcpyDeviceToHost));
+    GPB_HIP(hipMemset(ctx->tile_trace, 0, sizeof(unsigned)));      // count = 0: re-armed
+    *n_out = n;
     return 0;
 }
 

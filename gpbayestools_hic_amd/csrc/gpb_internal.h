@@ -87,7 +87,9 @@ struct gpb_ctx {
     int64_t chol_outer = 512;      // outer panel width of the two-level blocked Cholesky
     int chol_inner_tile = 64;       // tile of the K=64 trailing updates inside an outer panel (64 or 128)
     int resident_order = 2;         // k_predict with one workgroup per tile: 0 = ticket queues, 1-3 = static orders (2 = snake)
-    int force_tile = 0;            // test hook: 0 = auto, 64 / 128 / 32 (= 64x32) force the k_predict tile
+    unsigned* tile_trace = nullptr; // debug hook: [count, capacity, pad x6][capacity][8] records of k_predict tiles
+    int tile_priority = 1;         // k_predict: wave priority by K-loop length (s_setprio)
+    int force_tile = 0;           // test hook: 0 = auto, 64 / 128 / 32 (= 64x32) force the k_predict tile
     int force_xcd = -1;             // tuning hook: -1 auto, 0 / 1 = k_predict XCD affinity by walker tile / row block
     int64_t tile_switch = 1280;     // use 128x128 tiles when at least this many of them exist
     bool force_generic_mvn = false; // test hook: bypass the register-resident MVN fast path

@@ -106,14 +106,27 @@ __global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, i
 // L2.  The fused epilogue reduces V^2 over rows in a tree that depends only on the row index — 32-row
 // chains, lane groups, then the two halves of each 64-row block — so both tile sizes, and therefore any
 // sharding of the walkers, give bit-identical sums.  spart is indexed by 64-row block.
+__device__ __forceinline__ void set_wave_prio(int p) {      // s_setprio takes an immediate
+    if (p <= 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+
 template <int T, int NW, int TN>
 __device__ __forceinline__ void predict_tile(TileLds<T, TN>& lds, int p, int ib, int wt, const double* __restrict__ Linv,
                                              const double* __restrict__ KsT, double* __restrict__ spart, int64_t Np,
-                                             int64_t Wld, int P) {
+                                             int64_t Wld, int P, int prio_levels, unsigned* __restrict__ trace) {
+    // trace (debug hook, normally null): one record per tile — where and when it ran (tools/gpu_tile_trace.py)
+    const unsigned long long trace_t0 = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     constexpr int NI = T / 32, WN = NW / 2, TNW = TN / WN, NJ = TNW / 16;
     const int64_t mb = (int64_t)ib * T, nb = (int64_t)wt * TN;
     const int m_ext = (int)imin64(T, Np - mb);
     const int64_t k_end = imin64(mb + T, Np);
+    // Resident grids: longer K loops issue first (s_setprio), so that a CU's long tile does not share the matrix
+    // pipe equally until the short ones are done and then finish alone at one wave's issue rate.  The tile trace
+    // (tools/gpu_tile_trace.py) shows the order taking effect; worth 1-2 % at 128-256 walkers.  Scheduling only.
+    if (prio_levels > 0) set_wave_prio((4 * ib) / prio_levels);      // prio_levels = number of row blocks
     Acc<T, NW, TN> acc;
     acc_zero<T, NW, TN>(acc);
     gemm_tile_loop<T, false, false, NW, TN>(Linv + (int64_t)p * Np * Np, Np, KsT + (int64_t)p * Np * Wld, Wld, mb, nb,
@@ -153,6 +166,18 @@ __device__ __forceinline__ void predict_tile(TileLds<T, TN>& lds, int p, int ib,
     } else {                                    // the two wave rows are the halves of one 64-row block
         if (tid < TN) spart[((int64_t)ib * P + p) * Wld + nb + tid] = red[tid] + red[TN + tid];
     }
+    if (trace && tid == 0) {
+        const unsigned slot = atomicAdd(&trace[0], 1u);
+        if (slot < trace[1]) {                  // trace[1] = capacity in records
+            unsigned* r = trace + 8 + 8 * (size_t)slot;
+            r[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);      // HW_ID: CU / SE / SIMD ...
+            r[1] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);      // XCC_ID
+            r[2] = (unsigned)p; r[3] = (unsigned)ib; r[4] = (unsigned)wt;
+            r[5] = (unsigned)trace_t0;
+            r[6] = (unsigned)__builtin_amdgcn_s_memrealtime();
+            r[7] = blockIdx.x;
+        }
+    }
 }
 
 // ticket t of queue qx -> tile (GP p, row block ib, walker tile wt); false for the padding of xcd_mode 1
@@ -189,7 +214,8 @@ template <int T, int NW, int TN>
 __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : 4)) void k_predict(const double* __restrict__ Linv, const double* __restrict__ KsT,
                                                      double* __restrict__ spart, int64_t Np, int64_t Wld, int P,
                                                      int nI, int nW, int xcd_mode, unsigned* __restrict__ queue,
-                                                     unsigned nblocks, int resident, unsigned ncu_x) {
+                                                     unsigned nblocks, int resident, unsigned ncu_x,
+                                                     int prio_levels, unsigned* __restrict__ trace) {
     __shared__ TileLds<T, TN> lds;
     __shared__ unsigned s_ticket;
     if (resident) {
@@ -217,7 +243,7 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : 4)) void k_pred
         }
         int p, ib, wt;
         if (decode_tile(xcd_mode, t, qx, nI, nW, P, p, ib, wt))
-            predict_tile<T, NW, TN>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P);
+            predict_tile<T, NW, TN>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace);
         return;
     }
     // Eight ticket queues, one per XCD label (blockIdx % 8; workgroups with equal labels share an XCD's
@@ -243,7 +269,7 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : 4)) void k_pred
             if (t >= nq) break;                 // uniform: this queue is exhausted
             int p, ib, wt;
             if (!decode_tile(xcd_mode, t, qx, nI, nW, P, p, ib, wt)) continue;   // padding (uniform)
-            predict_tile<T, NW, TN>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P);
+            predict_tile<T, NW, TN>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace);
         }
     }
     // the last workgroup to finish re-arms the queues for the next launch (all others are past their draws)
@@ -361,7 +387,8 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var)
 #define GPB_PRED(TT, WW, NN)                                                                                     \
     hipLaunchKernelGGL((k_predict<TT, WW, NN>), dim3(grid), dim3(64 * WW), 0, ctx->stream, ctx->Linv, ctx->KsT,    \
                        ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW, xcd_rows, ctx->tile_counter,           \
-                       (unsigned)nblocks, resident, (unsigned)(ctx->num_cu / 8))
+                       (unsigned)nblocks, resident, (unsigned)(ctx->num_cu / 8), (ctx->tile_priority && resident) ? nI : 0,    \
+                       ctx->tile_trace)
         if (T == 128)      { if (nwv == 8) GPB_PRED(128, 8, 128); else GPB_PRED(128, 4, 128); }
         else if (TN == 32) GPB_PRED(64, 4, 32);
         else               { if (nwv == 8) GPB_PRED(64, 8, 64); else GPB_PRED(64, 4, 64); }

@@ -274,6 +274,18 @@ class GPEngine:
         return out
 
     # ------------------------------------------------------------------ diagnostics
+    def tile_trace(self, capacity):
+        """arm (capacity > 0) or disarm (0) the per-tile placement/timing trace of the predict kernel"""
+        self._ck(self.lib.gpb_debug_tile_trace(self.h, int(capacity)))
+        self._trace_cap = int(capacity)
+
+    def tile_trace_read(self):
+        """records[n, 8] uint32: HW_ID, XCC_ID, gp, row block, walker tile, start, end (100 MHz ticks), blockIdx"""
+        rec = np.zeros((self._trace_cap, 8), dtype=np.uint32)
+        n = C.c_int64(0)
+        self._ck(self.lib.gpb_debug_tile_trace_read(self.h, nat.ptr(rec), self._trace_cap, C.byref(n)))
+        return rec[:n.value]
+
     def test_gemm(self, A, B, mode=0, tile=128):
         A, B = nat.f64(A), nat.f64(B)
         if mode == 0:
@@ -293,7 +305,7 @@ class GPEngine:
 
     def tune(self, key, value):
         """launch-geometry hook of the predict kernel: 'xcd', 'wgs64', 'waves', 'wgs128w8'."""
-        k = {"xcd": 0, "wgs64": 1, "waves": 2, "wgs128w8": 3, "chol_outer": 4, "resident": 5, "wgs32": 6, "narrow_switch": 7, "mvn_wg_switch": 8, "chol_inner_tile": 9}[key]
+        k = {"xcd": 0, "wgs64": 1, "waves": 2, "wgs128w8": 3, "chol_outer": 4, "resident": 5, "wgs32": 6, "narrow_switch": 7, "mvn_wg_switch": 8, "chol_inner_tile": 9, "tile_priority": 10}[key]
         self._ck(self.lib.gpb_debug_tune(self.h, k, int(value)))
 
     def force_generic_mvn(self, on=True):

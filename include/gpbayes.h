@@ -209,8 +209,14 @@ int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
  * 6 = persistent 64x32-tile workgroups per CU;
  * 7 = largest padded walker batch that uses 64x32 tiles; 8 = largest batch whose block log-likelihood
  * (PCA mode, 32 < M <= 64) runs one workgroup per walker instead of one wave per walker;
- * 9 = tile (64 or 128) of the K=64 trailing updates inside an outer Cholesky panel. */
+ * 9 = tile (64 or 128) of the K=64 trailing updates inside an outer Cholesky panel;
+ * 10 = wave priority of predict tiles by K-loop length (0/1). */
 int gpb_debug_tune(gpb_ctx* ctx, int key, int value);
+/* debug hook: per-tile placement and timing of the predict kernel.  capacity > 0 arms (and clears) a trace of
+ * that many records, 0 disarms; read copies up to max_records records of 8 uint32 {HW_ID register, XCC_ID,
+ * GP, row block, walker tile, start, end (100 MHz ticks), blockIdx} to the host and re-arms. */
+int gpb_debug_tile_trace(gpb_ctx* ctx, int64_t capacity);
+int gpb_debug_tile_trace_read(gpb_ctx* ctx, uint32_t* records_host, int64_t max_records, int64_t* n_out);
 /* test hook: route gpb_loglike through the generic LDS/HBM Cholesky instead of the register-resident
  * fast path (PCA mode, M <= 64) so that both implementations can be checked against each other. */
 int gpb_debug_force_generic_mvn(gpb_ctx* ctx, int on);
