@@ -13,6 +13,8 @@ from gpbayestools_hic_amd import Emulator, synth  # noqa: E402
 
 
 def main():
+    import torch                                    # page the runtime in before anything is timed
+    torch.zeros(1, device="cuda"); torch.cuda.synchronize()
     for (N, d, M, npc) in ((1024, 15, 16, 4), (2048, 20, 64, 10)):
         wd = tempfile.mkdtemp()
         X = synth.lhs(N, d); Y = synth.observables(X, M)
