@@ -268,7 +268,8 @@ __global__ __launch_bounds__(256) void k_loglike_reg(const double* __restrict__ 
         for (int k = 0; k < MP; ++k) a[k] = fma(t, sA[p * 64 + k], a[k]);   // src/emulator.py:584-587
     }
     bool bad = false;
-    double q = 0.0, logdet = 0.0, prod = 1.0;
+    double q = 0.0, prod = 1.0;
+    double gprod = 1.0;                               // lane g keeps the product of pivot group g (4 pivots each)
 #pragma unroll
     for (int j = 0; j < MP; ++j) {
         const double ajj = readlane_f64(a[j], j);
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256) void k_loglike_reg(const double* __restrict__ 
         const double vj = readlane_f64(y, j) * rinv;  // forward solve: v_j
         q = fma(vj, vj, q);
         prod *= ajj;                                  // log det: sum log L_jj = 1/2 log prod a_jj, 4 pivots per log
-        if ((j & 3) == 3) { logdet += 0.5 * log(prod); prod = 1.0; }
+        if ((j & 3) == 3) { gprod = (lane == (j >> 2)) ? prod : gprod; prod = 1.0; }
         y = fma(-lj, vj, y);                          // meaningful for lanes i > j
 #pragma unroll
         for (int k = j + 1; k < MP; ++k) {
@@ -287,6 +288,10 @@ __global__ __launch_bounds__(256) void k_loglike_reg(const double* __restrict__ 
             if (((k - j) & 7) == 0) __builtin_amdgcn_sched_barrier(0);   // keep the SGPR broadcasts from piling up
         }
     }
+    const double glog = log(gprod);                   // the MP/4 logarithms in parallel, one per lane, off the chain
+    double logdet = 0.0;
+#pragma unroll
+    for (int g = 0; g < MP / 4; ++g) logdet = fma(0.5, readlane_f64(glog, g), logdet);   // fixed order
     bool inside = true;
     if (box.X) {                                      // strict box over the d parameters, one per lane
         bool ok = true;
@@ -388,7 +393,8 @@ __global__ __launch_bounds__(256) void k_loglike_wg(const double* __restrict__ m
         }
     }
     bool bad = false;
-    double q = 0.0, logdet = 0.0, prod = 1.0;
+    double q = 0.0, prod = 1.0;
+    double gprod = 1.0;                      // thread g keeps the product of pivot group g (4 pivots each)
     const int nblk = (M + 15) >> 4;          // identity-padded columns beyond M change nothing (pivot 1, v = 0)
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) {
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(256) void k_loglike_wg(const double* __restrict__ m
                 const double vj = buf[64] * rinv;                 // forward solve: v_j
                 q = fma(vj, vj, q);
                 prod *= ajj;                                      // sum log L_jj = 1/2 log prod a_jj, 4 pivots per log
-                if ((j & 3) == 3) { logdet += 0.5 * log(prod); prod = 1.0; }
+                if ((j & 3) == 3) { gprod = (tid == (j >> 2)) ? prod : gprod; prod = 1.0; }
                 double lk[4];
 #pragma unroll
                 for (int b = jb; b < 4; ++b) lk[b] = buf[tx + 16 * b] * rinv;
@@ -422,7 +428,12 @@ __global__ __launch_bounds__(256) void k_loglike_wg(const double* __restrict__ m
             }
         }
     }
+    __syncthreads();                         // the column lines are free: reuse them for the 16 group logarithms
+    if (tid < 16) col[tid] = log(gprod);     // in parallel, off the factorisation's dependency chain
+    __syncthreads();
     if (tid == 0) {
+        double logdet = 0.0;
+        for (int g = 0; g < 16; ++g) logdet = fma(0.5, col[g], logdet);      // fixed order (as k_loglike_reg)
         const bool inside = !s_outside;
         double r = -0.5 * q - logdet;
         if (bad && inside) {
