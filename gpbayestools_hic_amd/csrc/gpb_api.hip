@@ -433,13 +433,14 @@ extern "C" int gpb_loglike(gpb_ctx* ctx, const double* Xs, int64_t W, int on_dev
     int rc = stage_inputs(ctx, Xs, W, on_device, nullptr, &Xs_dev, nullptr);
     if (rc) return rc;
     if (n_notpd_host) GPB_HIP(hipMemsetAsync(ctx->notpd, 0, sizeof(int), ctx->stream));
-    if ((rc = launch_predict(ctx, Xs_dev, W, true))) return rc;
+    const bool fused = loglike_fuses_finalize(ctx);
+    if ((rc = launch_predict(ctx, Xs_dev, W, true, !fused))) return rc;
     if (on_device) {
-        if ((rc = launch_loglike(ctx, W, ll, accumulate != 0))) return rc;
+        if ((rc = launch_loglike(ctx, W, ll, accumulate != 0, fused))) return rc;
     } else {
         if ((rc = ensure_out(ctx, W))) return rc;
         if (accumulate) GPB_HIP(hipMemcpyAsync(ctx->out_stage, ll, sizeof(double) * W, hipMemcpyHostToDevice, ctx->stream));
-        if ((rc = launch_loglike(ctx, W, ctx->out_stage, accumulate != 0))) return rc;
+        if ((rc = launch_loglike(ctx, W, ctx->out_stage, accumulate != 0, fused))) return rc;
         GPB_HIP(hipMemcpyAsync(ll, ctx->out_stage, sizeof(double) * W, hipMemcpyDeviceToHost, ctx->stream));
     }
     if (n_notpd_host) {
@@ -459,8 +460,9 @@ extern "C" int gpb_logpost(gpb_ctx* ctx, const double* Xs_dev, int64_t W, double
     GPB_HIP(hipSetDevice(ctx->device));
     int rc = ensure_wcap(ctx, W);
     if (rc) return rc;
-    if ((rc = launch_predict(ctx, Xs_dev, W, true))) return rc;
-    return launch_loglike(ctx, W, ll_dev, accumulate != 0, Xs_dev, lo_dev, hi_dev, outside_value, inside_const);
+    const bool fused = loglike_fuses_finalize(ctx);
+    if ((rc = launch_predict(ctx, Xs_dev, W, true, !fused))) return rc;
+    return launch_loglike(ctx, W, ll_dev, accumulate != 0, fused, Xs_dev, lo_dev, hi_dev, outside_value, inside_const);
 }
 
 extern "C" int gpb_mvn_loglike(gpb_ctx* ctx, const double* dY, const double* cov, int64_t W, int64_t M,
@@ -592,6 +594,7 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 8: if (value < 0) return GPB_E_ARG; ctx->mvn_wg_switch = value; break;
         case 9: if (value != 64 && value != 128) return GPB_E_ARG; ctx->chol_inner_tile = value; break;
         case 10: if (value < 0 || value > 1) return GPB_E_ARG; ctx->tile_priority = value; break;
+        case 11: if (value < 0 || value > 1) return GPB_E_ARG; ctx->fuse_finalize = value; break;
         default: return GPB_E_ARG;
     }
     return 0;

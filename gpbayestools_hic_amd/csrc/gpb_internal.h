@@ -93,7 +93,8 @@ struct gpb_ctx {
     int force_xcd = -1;             // tuning hook: -1 auto, 0 / 1 = k_predict XCD affinity by walker tile / row block
     int64_t tile_switch = 1280;     // use 128x128 tiles when at least this many of them exist
     bool force_generic_mvn = false; // test hook: bypass the register-resident MVN fast path
-    int64_t mvn_wg_switch = 768;    // batches up to this size use one workgroup per walker (32 < M <= 64)
+    int fuse_finalize = 1;          // block log-likelihood kernels sum the predict partials themselves (P <= 32)
+    int64_t mvn_wg_switch = 768;   // batches up to this size use one workgroup per walker (32 < M <= 64)
 
     // ---- parameterTrafoPCA input map (gpb_pmap.hip) ------------------------------------
     int* pmap_int = nullptr;       // col_src[d_out] | group descriptors [G][6]
@@ -137,13 +138,16 @@ int launch_lml_value(gpb_ctx* ctx);
 int launch_lml_grad(gpb_ctx* ctx, double* grad_host);
 // predict side (gpb_predict.hip)
 int ensure_wcap(gpb_ctx* ctx, int64_t W);
-int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var);
+// finalize = false leaves the mean / variance as partials (mpart, spart) for a consumer that sums them itself
+int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var, bool finalize = true);
 int launch_predict_cov(gpb_ctx* ctx, const double* Xs_dev, int64_t W, double* cov_dev);
 // likelihood (gpb_like.hip)
 int launch_obs(gpb_ctx* ctx, int64_t W, const double* estd_dev, double* mean_dev, double* cov_dev);
-int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, const double* X_box = nullptr,
-                   const double* lo_dev = nullptr, const double* hi_dev = nullptr, double outside = 0.0,
-                   double inside_const = 0.0);
+// true when launch_loglike will take the block log-likelihood kernels that sum the partials themselves
+bool loglike_fuses_finalize(const gpb_ctx* ctx);
+int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, bool from_partials,
+                   const double* X_box = nullptr, const double* lo_dev = nullptr, const double* hi_dev = nullptr,
+                   double outside = 0.0, double inside_const = 0.0);
 int launch_mvn(gpb_ctx* ctx, const double* dY_dev, const double* cov_dev, int64_t W, int64_t M, double* ll_dev);
 // test hooks
 int launch_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K, const double* A, const double* B,

@@ -228,6 +228,17 @@ struct BoxArgs {
     double inside_const;  // 2 log(1e-16)
 };
 
+// Optional fused k_finalize: mpart != nullptr -> the kernel sums the per-chunk mean partials and the per-row-block
+// sum-of-squares partials of its walker itself, in k_finalize's order (same bits), instead of reading mean_pc / var_pc.
+// One launch and one dependent pass over HBM less per log-probability batch; needs P <= 32.
+struct PartArgs {
+    const double* mpart;  // [nchunk][P][Wld]
+    const double* spart;  // [nI64][P][Wld]
+    const double* amp;    // [P]
+    const double* noise;  // [P]
+    int nchunk, nI64;
+};
+
 template <int MP>
 __global__ __launch_bounds__(256) void k_loglike_reg(const double* __restrict__ mean_pc,
                                                      const double* __restrict__ var_pc, int64_t Wld, int64_t W, int P,
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(256) void k_loglike_reg(const double* __restrict__ 
                                                      const double* __restrict__ mu, const double* __restrict__ C0,
                                                      const double* __restrict__ yexp, const double* __restrict__ Cexp,
                                                      double* __restrict__ ll, int accumulate, int* __restrict__ notpd,
-                                                     BoxArgs box) {
+                                                     BoxArgs box, PartArgs part) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* sC = sm;                         // [64][MP+1]  C_trunc + C_exp, identity padded
     double* sA = sm + 64 * (MP + 1);         // [P][64]     A, zero padded
@@ -258,9 +269,27 @@ __global__ __launch_bounds__(256) void k_loglike_reg(const double* __restrict__ 
 #pragma unroll
     for (int k = 0; k < MP; ++k) a[k] = sC[lane * (MP + 1) + k];
     double y = (lane < M) ? (mu[lane] - yexp[lane]) : 0.0;
+    double zmv = 0.0;                        // fused finalize: lane p = mean of GP p, lane 32 + p = its variance
+    if (part.mpart) {
+        const int pl = lane & 31;
+        if (pl < P) {
+            if (lane < 32) {
+                double m = 0.0;
+#pragma unroll 8
+                for (int c = 0; c < part.nchunk; ++c) m += part.mpart[((int64_t)c * P + pl) * Wld + w];
+                zmv = m;
+            } else {
+                double s = 0.0;
+#pragma unroll 8
+                for (int i = 0; i < part.nI64; ++i) s += part.spart[((int64_t)i * P + pl) * Wld + w];
+                zmv = (part.amp[pl] + part.noise[pl]) - s;
+            }
+        }
+    }
     for (int p = 0; p < P; ++p) {
-        const double zm = mean_pc[(int64_t)p * Wld + w];        // wave-uniform
-        const double zv = var_pc[(int64_t)p * Wld + w];         // extra_std == 0 on this path
+        // wave-uniform; extra_std == 0 on this path
+        const double zm = part.mpart ? readlane_f64(zmv, p) : mean_pc[(int64_t)p * Wld + w];
+        const double zv = part.mpart ? readlane_f64(zmv, 32 + p) : var_pc[(int64_t)p * Wld + w];
         const double ai = sA[p * 64 + lane];
         y = fma(zm, ai, y);                                       // dY_i (src/emulator.py:559-561, src/mcmc.py:288)
         const double t = zv * ai;
@@ -317,11 +346,12 @@ __global__ __launch_bounds__(256) void k_loglike_reg(const double* __restrict__ 
 }
 
 template <int MP>
-static int launch_loglike_reg(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, const BoxArgs& box) {
+static int launch_loglike_reg(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, const BoxArgs& box,
+                              const PartArgs& part) {
     const size_t sh = (64 * (MP + 1) + (size_t)ctx->P * 64) * sizeof(double);
     hipLaunchKernelGGL(k_loglike_reg<MP>, dim3((unsigned)((W + 3) / 4)), dim3(256), sh, ctx->stream, ctx->mean_pc,
                        ctx->var_pc, ctx->Wcap, W, (int)ctx->P, (int)ctx->M, ctx->A, ctx->mu, ctx->C0, ctx->yexp,
-                       ctx->Cexp, ll_dev, accumulate ? 1 : 0, ctx->notpd, box);
+                       ctx->Cexp, ll_dev, accumulate ? 1 : 0, ctx->notpd, box, part);
     GPB_HIP(hipGetLastError());
     return 0;
 }
@@ -342,16 +372,31 @@ __global__ __launch_bounds__(256) void k_loglike_wg(const double* __restrict__ m
                                                     const double* __restrict__ mu, const double* __restrict__ C0,
                                                     const double* __restrict__ yexp, const double* __restrict__ Cexp,
                                                     double* __restrict__ ll, int accumulate, int* __restrict__ notpd,
-                                                    BoxArgs box) {
+                                                    BoxArgs box, PartArgs part) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* sA = sm;                         // [P][64]  A, zero padded
     double* col = sm + (size_t)P * 64;       // [2][66]  column j of the trailing matrix (unscaled), y_j at [64]
+    double* zl = col + 2 * 66;               // [2P]     fused finalize: mean, variance of GP p at [2p], [2p+1]
     __shared__ int s_outside;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     const int64_t w = blockIdx.x;
     for (int e = tid; e < P * 64; e += 256) {
         const int p = e >> 6, i = e & 63;
         sA[e] = (i < M) ? A[p * M + i] : 0.0;
+    }
+    if (part.mpart) {                        // k_finalize's sums for this walker, same order; means on wave 0, variances on wave 1
+        const int pl = tid & 63;
+        if (tid < 64 && pl < P) {
+            double m = 0.0;
+#pragma unroll 8
+            for (int c = 0; c < part.nchunk; ++c) m += part.mpart[((int64_t)c * P + pl) * Wld + w];
+            zl[2 * pl] = m;
+        } else if (tid >= 64 && tid < 128 && pl < P) {
+            double s = 0.0;
+#pragma unroll 8
+            for (int i = 0; i < part.nI64; ++i) s += part.spart[((int64_t)i * P + pl) * Wld + w];
+            zl[2 * pl + 1] = (part.amp[pl] + part.noise[pl]) - s;
+        }
     }
     if (tid == 0) s_outside = 0;
     __syncthreads();
@@ -378,8 +423,9 @@ __global__ __launch_bounds__(256) void k_loglike_wg(const double* __restrict__ m
         }
     }
     for (int p = 0; p < P; ++p) {
-        const double zm = mean_pc[(int64_t)p * Wld + w];        // uniform
-        const double zv = var_pc[(int64_t)p * Wld + w];         // extra_std == 0 on this path
+        // uniform; extra_std == 0 on this path
+        const double zm = part.mpart ? zl[2 * p] : mean_pc[(int64_t)p * Wld + w];
+        const double zv = part.mpart ? zl[2 * p + 1] : var_pc[(int64_t)p * Wld + w];
         double ak[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) ak[b] = sA[p * 64 + tx + 16 * b];
@@ -446,11 +492,12 @@ __global__ __launch_bounds__(256) void k_loglike_wg(const double* __restrict__ m
     }
 }
 
-static int launch_loglike_wg(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, const BoxArgs& box) {
-    const size_t sh = ((size_t)ctx->P * 64 + 2 * 66) * sizeof(double);
+static int launch_loglike_wg(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, const BoxArgs& box,
+                             const PartArgs& part) {
+    const size_t sh = ((size_t)ctx->P * 64 + 2 * 66 + 2 * (size_t)ctx->P) * sizeof(double);
     hipLaunchKernelGGL(k_loglike_wg, dim3((unsigned)W), dim3(256), sh, ctx->stream, ctx->mean_pc, ctx->var_pc,
                        ctx->Wcap, W, (int)ctx->P, (int)ctx->M, ctx->A, ctx->mu, ctx->C0, ctx->yexp, ctx->Cexp, ll_dev,
-                       accumulate ? 1 : 0, ctx->notpd, box);
+                       accumulate ? 1 : 0, ctx->notpd, box, part);
     GPB_HIP(hipGetLastError());
     return 0;
 }
@@ -460,16 +507,29 @@ __global__ void k_box(const double* __restrict__ X, int64_t W, int d, const doub
 
 // box_* optional (X_box == nullptr: no prior box).  The register-resident kernel applies the box itself;
 // the generic kernels are followed by k_box.
-int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, const double* X_box,
+static bool block_kernels_apply(const gpb_ctx* ctx) {
+    return ctx->mode == GPB_MODE_PCA && ctx->M <= 64 && ctx->P <= 96 && !ctx->force_generic_mvn;
+}
+
+bool loglike_fuses_finalize(const gpb_ctx* ctx) {
+    return block_kernels_apply(ctx) && ctx->P <= 32 && ctx->fuse_finalize;
+}
+
+int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, bool from_partials, const double* X_box,
                    const double* lo_dev, const double* hi_dev, double outside, double inside_const) {
     const int64_t M = ctx->M, P = ctx->P;
     const BoxArgs box{X_box, lo_dev, hi_dev, (int)ctx->d, outside, inside_const};
-    if (ctx->mode == GPB_MODE_PCA && M <= 64 && P <= 96 && !ctx->force_generic_mvn) {
-        if (M <= 8) return launch_loglike_reg<8>(ctx, W, ll_dev, accumulate, box);
-        if (M <= 16) return launch_loglike_reg<16>(ctx, W, ll_dev, accumulate, box);
-        if (M <= 32) return launch_loglike_reg<32>(ctx, W, ll_dev, accumulate, box);
-        if (W <= ctx->mvn_wg_switch) return launch_loglike_wg(ctx, W, ll_dev, accumulate, box);   // same bits, lower latency
-        return launch_loglike_reg<64>(ctx, W, ll_dev, accumulate, box);
+    if (from_partials && !loglike_fuses_finalize(ctx)) GPB_FAIL(GPB_E_STATE, "gpb: internal: partials without a fused consumer");
+    if (block_kernels_apply(ctx)) {
+        PartArgs part{nullptr, nullptr, nullptr, nullptr, 0, 0};
+        if (from_partials)
+            part = PartArgs{ctx->mpart, ctx->spart, ctx->amp, ctx->noise,
+                            (int)((ctx->Np + KX_CHUNK - 1) / KX_CHUNK), (int)(ctx->Np / 64)};
+        if (M <= 8) return launch_loglike_reg<8>(ctx, W, ll_dev, accumulate, box, part);
+        if (M <= 16) return launch_loglike_reg<16>(ctx, W, ll_dev, accumulate, box, part);
+        if (M <= 32) return launch_loglike_reg<32>(ctx, W, ll_dev, accumulate, box, part);
+        if (W <= ctx->mvn_wg_switch) return launch_loglike_wg(ctx, W, ll_dev, accumulate, box, part);   // same bits, lower latency
+        return launch_loglike_reg<64>(ctx, W, ll_dev, accumulate, box, part);
     }
     const size_t small = (2 * P + 2 * M) * sizeof(double);
     const size_t mat = (size_t)(M + 1) * (M + 1) * sizeof(double);

@@ -343,7 +343,7 @@ static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int
 }
 
 // Xs_dev: [W][d] on the device.  Results land in ctx->mean_pc / var_pc ([P][Wcap]).
-int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var) {
+int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var, bool finalize) {
     if (!ctx->factored) GPB_FAIL(GPB_E_STATE, "gpb: predict before gpb_gp_factor");
     if (W > ctx->Wcap) GPB_FAIL(GPB_E_STATE, "gpb: internal: W exceeds workspace");
     const int64_t Wuse = round_up(W, WPAD);
@@ -399,9 +399,10 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var)
             ctx->prof_units += (double)ctx->P * (double)W;
         }
     }
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((Wuse + 255) / 256), (unsigned)ctx->P), dim3(256), 0, ctx->stream,
-                       ctx->mpart, ctx->spart, ctx->amp, ctx->noise, ctx->mean_pc, ctx->var_pc, ctx->Wcap, Wuse,
-                       (int)ctx->P, nchunk, nI64, need_var ? 1 : 0);
+    if (finalize)
+        hipLaunchKernelGGL(k_finalize, dim3((unsigned)((Wuse + 255) / 256), (unsigned)ctx->P), dim3(256), 0,
+                           ctx->stream, ctx->mpart, ctx->spart, ctx->amp, ctx->noise, ctx->mean_pc, ctx->var_pc,
+                           ctx->Wcap, Wuse, (int)ctx->P, nchunk, nI64, need_var ? 1 : 0);
     GPB_HIP(hipGetLastError());
     return 0;
 }

@@ -195,6 +195,9 @@ def test_loglike_fast_and_generic_paths(eng, M, P):
     ref = np.array([O.mvn_loglike(a, c) for a, c in zip(mY - yexp, mC + cexp)])
     fast = eng.loglike(Xw).copy()
     assert eng.last_not_pd == 0
+    # the block kernels sum the predict partials themselves in k_finalize's order: same bits with and without the fusion
+    eng.tune("fuse_finalize", 0); unfused = eng.loglike(Xw).copy(); eng.tune("fuse_finalize", 1)
+    assert np.array_equal(unfused, fast)
     if 32 < M <= 64:
         # one wave per walker and one workgroup per walker apply the same operations to every element:
         # the batch-size switch between them never changes a bit
