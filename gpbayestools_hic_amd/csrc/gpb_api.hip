@@ -22,7 +22,7 @@ void dev_free(T** p) {
 }
 
 int pick_dpad(int64_t d) {
-    const int opts[] = {8, 16, 24, 32, 48, 64};
+    const int opts[] = {8, 16, 20, 24, 32, 48, 64};     // 20: the reference's analyses have 17-20 model parameters
     for (int o : opts) if (d <= o) return o;
     return -1;
 }

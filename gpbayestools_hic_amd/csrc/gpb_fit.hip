@@ -568,6 +568,7 @@ static int launch_grad_kind(gpb_ctx* ctx, int ntiles, double* gfinal) {
     switch (ctx->dpad) {
         case 8: GPB_GRAD(8); break;
         case 16: GPB_GRAD(16); break;
+        case 20: GPB_GRAD(20); break;
         case 24: GPB_GRAD(24); break;
         case 32: GPB_GRAD(32); break;
         case 48: GPB_GRAD(48); break;

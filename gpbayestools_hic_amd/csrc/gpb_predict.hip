@@ -333,6 +333,7 @@ static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int
     switch (ctx->dpad) {
         case 8: GPB_KX(8); break;
         case 16: GPB_KX(16); break;
+        case 20: GPB_KX(20); break;
         case 24: GPB_KX(24); break;
         case 32: GPB_KX(32); break;
         case 48: GPB_KX(48); break;
