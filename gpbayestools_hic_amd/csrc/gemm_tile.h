@@ -2,16 +2,18 @@
 //   predict (V = L^-1 K*^T, fused sum of squares), Cholesky trailing update (SYRK),
 //   triangular inverse (recursive block doubling) and K^-1 = L^-T L^-1 for the LML gradient.
 //
-// Block tile T x T (T = 128 or 64), K-step 16, 256 threads = 4 waves (2x2), wave tile T/2 x T/2 =
-// (T/32)^2 v_mfma_f64_16x16x4_f64 tiles (T=128: 16 accumulators of 4 f64 = 128 VGPRs).
-// Operand tiles are staged in LDS k-major ([k][m], [k][n]) with a 16-double row pad so that the
+// Block tile T x TN (128x128, 64x64, 64x32), K-step KB (16), 256 threads =
+// 4 waves (2x2), wave tile T/2 x TN/2 of v_mfma_f64_16x16x4_f64 tiles (T=128: 16 accumulators of 4 f64 = 128
+// VGPRs).  Operand tiles are staged in LDS k-major ([k][m], [k][n]) with a 16-double row pad so that the
 // per-lane fragment reads (lane l: row k=l>>4, 16 consecutive m) are bank-conflict free for
 // ds_read_b64; global loads are register-prefetched one K-step ahead.
-// Measured on MI355X (profiles/r01_mfma_f64_issue_rate.txt): v_mfma_f64_16x16x4_f64 issues about
-// once per 100 cycles per SIMD (~50 TFLOP/s chip-wide at 2.4 GHz), i.e. 2048 flop per 1 KiB of
-// fragments, so LDS and L2 traffic are far from their limits; the design goal is only to keep the
-// matrix pipe issuing back to back.  T = 64 exists for small walker batches (multi-GPU shards),
-// where 128-wide tiles leave CUs idle behind the heaviest triangular row block.
+// Measured on MI355X (profiles/r01_mfma_f64_issue_rate.txt): v_mfma_f64_16x16x4_f64 occupies the matrix pipe
+// for 64 cycles, but ONE wave can issue one only every ~138 cycles, i.e. 2048 flop per 1 KiB of fragments, so
+// LDS and L2 traffic are far from their limits; the design goal is only to keep the matrix pipe issuing back to
+// back.  T = 64 exists for small walker batches (multi-GPU shards), where 128-wide tiles leave CUs idle behind
+// the heaviest triangular row block; its waves have only 16 MFMAs between the two barriers of a 16-deep K-step
+// (~1300 cycles of synchronisation per ~2200 of issue, profiles/r01_tile_trace.txt).  KB is a template parameter;
+// 32-deep steps for the 64-row tiles were measured within 2.5 % of 16-deep either way and are not instantiated.
 //
 // v_mfma_f64_16x16x4_f64 lane maps (cdna_hip_programming.md §3):
 //   A: lane l holds A[i=l&15][k=l>>4];  B: lane l holds B[k=l>>4][j=l&15];
@@ -23,65 +25,66 @@
 namespace gpb {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
-constexpr int BK = 16;
+constexpr int BK = 16;                   // default K-step
 constexpr int GEMM_THREADS = 256;
 
 // T rows of A (the m extent) by TN columns of B (the n extent); TN = T except for the narrow predict tile.
-template <int T, int TN = T>
+template <int T, int TN = T, int KB = BK>
 struct __attribute__((aligned(16))) TileLds {
     static constexpr int LD = T + 16;   // row stride = 2*(T+16) dwords = 32 (mod 64) banks
-    double As[BK][T + 16];
-    double Bs[BK][TN + 16];
-};                                       // T=128: 36,864 B; T=64: 20,480 B; 64x32: 16,384 B
+    double As[KB][T + 16];
+    double Bs[KB][TN + 16];
+};                                       // KB=16: T=128: 36,864 B; T=64: 20,480 B; 64x32: 16,384 B
 
 // NW = waves per workgroup (4: 2x2 waves, wave tile T/2 x T/2;  8: 2x4 waves, wave tile T/2 x T/4).
-// More waves per tile shorten a tile's critical path: ONE wave can issue an f64 MFMA only every
-// ~138 cycles (profiles/r01_mfma_f64_issue_rate.txt), two waves per SIMD reach ~70.
-template <int T, int NW = 4>
-struct Frag { double2 r[(8 * T) / (64 * NW)]; };
+template <int T, int NW = 4, int KB = BK>
+struct Frag { d2 r[(KB * T / 2) / (64 * NW)]; };       // native vectors: HIP's double2 struct is copied with memcpy,
+                                                        // which kept some instantiations' prefetch registers in scratch
 template <int T, int NW = 4, int TN = T>
 struct Acc { d4 v[T / 32][(2 * TN / NW) / 16]; };
 
-// logical tile[k][x] = G[(k0+k)*ld + x0+x]   (k<16, x<T); rows are contiguous in x.
-template <int T, int NW>
+// logical tile[k][x] = G[(k0+k)*ld + x0+x]   (k<KB, x<T); rows are contiguous in x.
+// FULL = the caller guarantees x_ext == T (no edge): the loads are unconditional.
+template <int T, int NW, int KB, bool FULL = false>
 __device__ __forceinline__ void gload_direct(const double* __restrict__ G, int64_t ld, int64_t k0, int64_t x0,
-                                             int x_ext, Frag<T, NW>& f, int tid) {
+                                             int x_ext, Frag<T, NW, KB>& f, int tid) {
     constexpr int TPR = T / 2;                 // threads per row (2 doubles each)
     constexpr int RPP = (64 * NW) / TPR;       // rows per pass
     const int row = tid / TPR, col = (tid % TPR) * 2;
-    const bool ok = col < x_ext;
+    const bool ok = FULL || col < x_ext;
 #pragma unroll
-    for (int j = 0; j < (8 * T) / (64 * NW); ++j) {
-        if (ok) f.r[j] = *reinterpret_cast<const double2*>(G + (k0 + row + RPP * j) * ld + x0 + col);
-        else    f.r[j] = make_double2(0.0, 0.0);
+    for (int j = 0; j < (KB * T / 2) / (64 * NW); ++j) {
+        if (ok) f.r[j] = *reinterpret_cast<const d2*>(G + (k0 + row + RPP * j) * ld + x0 + col);
+        else    f.r[j] = d2{0.0, 0.0};
     }
 }
-template <int T, int NW>
-__device__ __forceinline__ void lstore_direct(double (*S)[T + 16], const Frag<T, NW>& f, int tid) {
+template <int T, int NW, int KB>
+__device__ __forceinline__ void lstore_direct(double (*S)[T + 16], const Frag<T, NW, KB>& f, int tid) {
     constexpr int TPR = T / 2, RPP = (64 * NW) / TPR;
     const int row = tid / TPR, col = (tid % TPR) * 2;
 #pragma unroll
-    for (int j = 0; j < (8 * T) / (64 * NW); ++j) *reinterpret_cast<double2*>(&S[row + RPP * j][col]) = f.r[j];
+    for (int j = 0; j < (KB * T / 2) / (64 * NW); ++j) *reinterpret_cast<d2*>(&S[row + RPP * j][col]) = f.r[j];
 }
 // logical tile[k][x] = G[(x0+x)*ld + k0+k]   (rows of G are contiguous in k): transpose on store.
-template <int T, int NW>
+template <int T, int NW, int KB, bool FULL = false>
 __device__ __forceinline__ void gload_trans(const double* __restrict__ G, int64_t ld, int64_t k0, int64_t x0,
-                                            int x_ext, Frag<T, NW>& f, int tid) {
+                                            int x_ext, Frag<T, NW, KB>& f, int tid) {
     constexpr int TPX = (64 * NW) / T;         // threads per x row
-    constexpr int KPT = BK / TPX;              // k's per thread
+    constexpr int KPT = KB / TPX;              // k's per thread
     const int x = tid / TPX, kh = (tid % TPX) * KPT;
-    const bool ok = x < x_ext;
+    const bool ok = FULL || x < x_ext;
     const double* p = G + (x0 + x) * ld + k0 + kh;
 #pragma unroll
     for (int j = 0; j < KPT / 2; ++j) {
-        if (ok) f.r[j] = *reinterpret_cast<const double2*>(p + 2 * j);
-        else    f.r[j] = make_double2(0.0, 0.0);
+        if (ok) f.r[j] = *reinterpret_cast<const d2*>(p + 2 * j);
+        else    f.r[j] = d2{0.0, 0.0};
     }
 }
-template <int T, int NW>
-__device__ __forceinline__ void lstore_trans(double (*S)[T + 16], const Frag<T, NW>& f, int tid) {
-    constexpr int TPX = (64 * NW) / T, KPT = BK / TPX;
+template <int T, int NW, int KB>
+__device__ __forceinline__ void lstore_trans(double (*S)[T + 16], const Frag<T, NW, KB>& f, int tid) {
+    constexpr int TPX = (64 * NW) / T, KPT = KB / TPX;
     const int x = tid / TPX, kh = (tid % TPX) * KPT;
 #pragma unroll
     for (int j = 0; j < KPT / 2; ++j) {
@@ -98,12 +101,13 @@ __device__ __forceinline__ void acc_zero(Acc<T, NW, TN>& acc) {
         for (int j = 0; j < (2 * TN / NW) / 16; ++j) acc.v[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 }
 
-template <int T, int NW, int TN>
-__device__ __forceinline__ void tile_mma(const TileLds<T, TN>& L, Acc<T, NW, TN>& acc, int lane, int m0, int n0) {
+template <int T, int NW, int TN, int KB>
+__device__ __forceinline__ void tile_mma(const TileLds<T, TN, KB>& L, Acc<T, NW, TN>& acc, int lane, int m0,
+                                         int n0) {
     constexpr int NI = T / 32, NJ = (2 * TN / NW) / 16;
     const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 4) {
+    for (int kk = 0; kk < KB; kk += 4) {
         double a[NI], b[NJ];
 #pragma unroll
         for (int i = 0; i < NI; ++i) a[i] = L.As[kk + lk][m0 + 16 * i + lr];
@@ -117,40 +121,41 @@ __device__ __forceinline__ void tile_mma(const TileLds<T, TN>& L, Acc<T, NW, TN>
     }
 }
 
-// acc += A[m_base.., k] * B[k, n_base..] for k in [k_begin, k_end), both multiples of BK.
+// acc += A[m_base.., k] * B[k, n_base..] for k in [k_begin, k_end), both multiples of KB.  The k order of the
+// accumulation (ascending, four at a time inside an MFMA) does not depend on KB: results are identical.
 //   A_TRANS=false: A[m][k] = Ag[(m_base+m)*lda + k]       A_TRANS=true: A[m][k] = Ag[k*lda + m_base+m]
 //   B_TRANS=false: B[k][n] = Bg[k*ldb + n_base+n]         B_TRANS=true: B[k][n] = Bg[(n_base+n)*ldb + k]
 // m_ext / n_ext (even, <= T) bound the valid rows / columns of this tile; the rest reads as 0.
-template <int T, bool A_TRANS, bool B_TRANS, int NW = 4, int TN = T>
+template <int T, bool A_TRANS, bool B_TRANS, int NW = 4, int TN = T, int KB = BK, bool FULL = false>
 __device__ __forceinline__ void gemm_tile_loop(const double* __restrict__ Ag, int64_t lda,
                                                const double* __restrict__ Bg, int64_t ldb, int64_t m_base,
                                                int64_t n_base, int m_ext, int n_ext, int64_t k_begin, int64_t k_end,
-                                               TileLds<T, TN>& L, Acc<T, NW, TN>& acc) {
+                                               TileLds<T, TN, KB>& L, Acc<T, NW, TN>& acc) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     constexpr int WN = NW / 2, TNW = TN / WN;   // waves along n, wave tile width
     const int m0 = (wave / WN) * (T / 2), n0 = (wave % WN) * TNW;
-    Frag<T, NW> fa;
-    Frag<TN, NW> fb;
+    Frag<T, NW, KB> fa;
+    Frag<TN, NW, KB> fb;
     if (k_begin < k_end) {
-        if (A_TRANS) gload_direct<T, NW>(Ag, lda, k_begin, m_base, m_ext, fa, tid);
-        else         gload_trans<T, NW>(Ag, lda, k_begin, m_base, m_ext, fa, tid);
-        if (B_TRANS) gload_trans<TN, NW>(Bg, ldb, k_begin, n_base, n_ext, fb, tid);
-        else         gload_direct<TN, NW>(Bg, ldb, k_begin, n_base, n_ext, fb, tid);
+        if (A_TRANS) gload_direct<T, NW, KB, FULL>(Ag, lda, k_begin, m_base, m_ext, fa, tid);
+        else         gload_trans<T, NW, KB, FULL>(Ag, lda, k_begin, m_base, m_ext, fa, tid);
+        if (B_TRANS) gload_trans<TN, NW, KB, FULL>(Bg, ldb, k_begin, n_base, n_ext, fb, tid);
+        else         gload_direct<TN, NW, KB, FULL>(Bg, ldb, k_begin, n_base, n_ext, fb, tid);
     }
-    for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += KB) {
         __syncthreads();
-        if (A_TRANS) lstore_direct<T, NW>(L.As, fa, tid); else lstore_trans<T, NW>(L.As, fa, tid);
-        if (B_TRANS) lstore_trans<TN, NW>(L.Bs, fb, tid); else lstore_direct<TN, NW>(L.Bs, fb, tid);
+        if (A_TRANS) lstore_direct<T, NW, KB>(L.As, fa, tid); else lstore_trans<T, NW, KB>(L.As, fa, tid);
+        if (B_TRANS) lstore_trans<TN, NW, KB>(L.Bs, fb, tid); else lstore_direct<TN, NW, KB>(L.Bs, fb, tid);
         __syncthreads();
-        const int64_t kn = k0 + BK;
+        const int64_t kn = k0 + KB;
         if (kn < k_end) {
-            if (A_TRANS) gload_direct<T, NW>(Ag, lda, kn, m_base, m_ext, fa, tid);
-            else         gload_trans<T, NW>(Ag, lda, kn, m_base, m_ext, fa, tid);
-            if (B_TRANS) gload_trans<TN, NW>(Bg, ldb, kn, n_base, n_ext, fb, tid);
-            else         gload_direct<TN, NW>(Bg, ldb, kn, n_base, n_ext, fb, tid);
+            if (A_TRANS) gload_direct<T, NW, KB, FULL>(Ag, lda, kn, m_base, m_ext, fa, tid);
+            else         gload_trans<T, NW, KB, FULL>(Ag, lda, kn, m_base, m_ext, fa, tid);
+            if (B_TRANS) gload_trans<TN, NW, KB, FULL>(Bg, ldb, kn, n_base, n_ext, fb, tid);
+            else         gload_direct<TN, NW, KB, FULL>(Bg, ldb, kn, n_base, n_ext, fb, tid);
         }
-        tile_mma<T, NW, TN>(L, acc, lane, m0, n0);
+        tile_mma<T, NW, TN, KB>(L, acc, lane, m0, n0);
     }
 }
 

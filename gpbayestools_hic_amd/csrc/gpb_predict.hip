@@ -113,8 +113,8 @@ __device__ __forceinline__ void set_wave_prio(int p) {      // s_setprio takes a
     else __builtin_amdgcn_s_setprio(3);
 }
 
-template <int T, int NW, int TN>
-__device__ __forceinline__ void predict_tile(TileLds<T, TN>& lds, int p, int ib, int wt, const double* __restrict__ Linv,
+template <int T, int NW, int TN, int KB>
+__device__ __forceinline__ void predict_tile(TileLds<T, TN, KB>& lds, int p, int ib, int wt, const double* __restrict__ Linv,
                                              const double* __restrict__ KsT, double* __restrict__ spart, int64_t Np,
                                              int64_t Wld, int P, int prio_levels, unsigned* __restrict__ trace) {
     // trace (debug hook, normally null): one record per tile — where and when it ran (tools/gpu_tile_trace.py)
@@ -129,7 +129,8 @@ __device__ __forceinline__ void predict_tile(TileLds<T, TN>& lds, int p, int ib,
     if (prio_levels > 0) set_wave_prio((4 * ib) / prio_levels);      // prio_levels = number of row blocks
     Acc<T, NW, TN> acc;
     acc_zero<T, NW, TN>(acc);
-    gemm_tile_loop<T, false, false, NW, TN>(Linv + (int64_t)p * Np * Np, Np, KsT + (int64_t)p * Np * Wld, Wld, mb, nb,
+    // Np is a multiple of 64 and the batch is padded to 128 walkers: 64-row tiles never have an edge
+    gemm_tile_loop<T, false, false, NW, TN, KB, T == 64>(Linv + (int64_t)p * Np * Np, Np, KsT + (int64_t)p * Np * Wld, Wld, mb, nb,
                                             m_ext, TN, 0, k_end, lds, acc);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -210,42 +211,17 @@ __device__ __forceinline__ bool decode_tile(int xcd_mode, unsigned t, unsigned q
 // queues in LPT order, so the triangular row blocks balance dynamically whatever the dispatcher does.
 // Exit condition: every workgroup walks all eight queues once and leaves each when its ticket is past
 // the queue's length; nothing spins.
-template <int T, int NW, int TN>
-__global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : 4)) void k_predict(const double* __restrict__ Linv, const double* __restrict__ KsT,
+template <int T, int NW, int TN, int KB>
+__global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (KB == 32 ? 3 : 4))) void k_predict(const double* __restrict__ Linv, const double* __restrict__ KsT,
                                                      double* __restrict__ spart, int64_t Np, int64_t Wld, int P,
                                                      int nI, int nW, int xcd_mode, unsigned* __restrict__ queue,
-                                                     unsigned nblocks, int resident, unsigned ncu_x,
-                                                     int prio_levels, unsigned* __restrict__ trace) {
-    __shared__ TileLds<T, TN> lds;
-    __shared__ unsigned s_ticket;
-    if (resident) {
-        // Every tile has its own workgroup and all of them are co-resident: nothing can be balanced
-        // dynamically, so the tile is a fixed function of blockIdx.  The dispatcher deals an XCD's workgroups
-        // round-robin over its ncu_x CUs (tools/micro/dispatch_probe.hip): workgroup j of an XCD runs on CU
-        // j % ncu_x.  resident: 1 = weight-sorted order as is, 2 = snake over the CUs (equal sums),
-        // 3 = snake of neighbouring PAIRS (equal sums, and the two heaviest tiles of a CU finish together).
-        const unsigned qx = blockIdx.x & 7u;
-        unsigned nq;
-        if (xcd_mode == 2) nq = ((unsigned)P > qx) ? (((unsigned)P - qx + 7u) / 8u) * (unsigned)(nI * nW) : 0u;
-        else               nq = (nblocks > qx) ? (nblocks - qx + 7u) / 8u : 0u;
-        unsigned t = blockIdx.x >> 3;
-        if (t >= nq) return;
-        const unsigned k = t / ncu_x, c = t - k * ncu_x;
-        if (resident == 2) {
-            if ((k & 1u) && (k + 1u) * ncu_x <= nq) t = k * ncu_x + (ncu_x - 1u - c);
-        } else if (resident == 3) {
-            const unsigned n2 = (nq / (2u * ncu_x)) * (2u * ncu_x);
-            if (t < n2) {
-                const unsigned kp = k >> 1;
-                const unsigned pi = kp * ncu_x + ((kp & 1u) ? (ncu_x - 1u - c) : c);
-                t = 2u * pi + (k & 1u);
-            }
-        }
-        int p, ib, wt;
-        if (decode_tile(xcd_mode, t, qx, nI, nW, P, p, ib, wt))
-            predict_tile<T, NW, TN>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace);
-        return;
-    }
+                                                     unsigned nblocks, unsigned* __restrict__ trace) {
+    constexpr int prio_levels = 0;
+    __shared__ TileLds<T, TN, KB> lds;
+    // The ticket lives in the padding of the last A row (never touched by the loaders, the MFMA fragment reads
+    // or the epilogue's scratch): the operand tiles alone are an exact fraction of the CU's 160 KB LDS, and a
+    // separate 4-byte variable would cost a whole workgroup of occupancy.
+    unsigned& s_ticket = *reinterpret_cast<unsigned*>(&lds.As[KB - 1][T + 8]);
     // Eight ticket queues, one per XCD label (blockIdx % 8; workgroups with equal labels share an XCD's
     // L2 under round-robin dispatch — speed only): queue x owns the tiles b = 8 t + x, i.e. a fixed set
     // of walker tiles (or row blocks) whose operand panels stay in that XCD's L2 while its workgroups
@@ -269,7 +245,7 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : 4)) void k_pred
             if (t >= nq) break;                 // uniform: this queue is exhausted
             int p, ib, wt;
             if (!decode_tile(xcd_mode, t, qx, nI, nW, P, p, ib, wt)) continue;   // padding (uniform)
-            predict_tile<T, NW, TN>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace);
+            predict_tile<T, NW, TN, KB>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace);
         }
     }
     // the last workgroup to finish re-arms the queues for the next launch (all others are past their draws)
@@ -279,6 +255,39 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : 4)) void k_pred
             queue[128] = 0u;
         }
     }
+}
+
+// Static launch for the case that every tile has its own workgroup and all of them are co-resident (a rank's
+// shard of a sharded ensemble): nothing can be balanced dynamically, so the tile is a fixed function of
+// blockIdx.  The dispatcher deals an XCD's workgroups round-robin over its ncu_x CUs (measured,
+// tools/micro/dispatch_probe.hip): workgroup j of an XCD runs on CU j % ncu_x.  order: 1 = weight-sorted as is,
+// 2 = snake over the CUs (equal sums per CU), 3 = snake of neighbouring PAIRS (equal sums, and the two heaviest
+// tiles of a CU finish together).  Same tile -> queue maps as above; a separate kernel so that each has ONE
+// inlined copy of the tile body (with two copies the compiler parked the prefetch registers in scratch memory).
+template <int T, int NW, int TN, int KB>
+__global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (KB == 32 ? 3 : 4))) void k_predict_static(
+    const double* __restrict__ Linv, const double* __restrict__ KsT, double* __restrict__ spart, int64_t Np, int64_t Wld,
+    int P, int nI, int nW, int xcd_mode, unsigned nblocks, int order, unsigned ncu_x, int prio_levels,
+    unsigned* __restrict__ trace) {
+    __shared__ TileLds<T, TN, KB> lds;
+    const unsigned qx = blockIdx.x & 7u;
+    const unsigned nq = (nblocks > qx) ? (nblocks - qx + 7u) / 8u : 0u;
+    unsigned t = blockIdx.x >> 3;
+    if (t >= nq) return;
+    const unsigned k = t / ncu_x, c = t - k * ncu_x;
+    if (order == 2) {
+        if ((k & 1u) && (k + 1u) * ncu_x <= nq) t = k * ncu_x + (ncu_x - 1u - c);
+    } else if (order == 3) {
+        const unsigned n2 = (nq / (2u * ncu_x)) * (2u * ncu_x);
+        if (t < n2) {
+            const unsigned kp = k >> 1;
+            const unsigned pi = kp * ncu_x + ((kp & 1u) ? (ncu_x - 1u - c) : c);
+            t = 2u * pi + (k & 1u);
+        }
+    }
+    int p, ib, wt;
+    if (decode_tile(xcd_mode, t, qx, nI, nW, P, p, ib, wt))
+        predict_tile<T, NW, TN, KB>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace);
 }
 
 __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ mpart, const double* __restrict__ spart,
@@ -379,20 +388,31 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
         const int per_cu = (T == 128) ? (nwv == 8 ? ctx->wgs_per_cu128w8 : 2)
                                       : (TN == 32 ? ctx->wgs_per_cu32 : ctx->wgs_per_cu64);
         const int64_t slots = (int64_t)ctx->num_cu * per_cu;
-        const unsigned grid = (unsigned)(nblocks < slots ? nblocks : slots);
-        // one workgroup per tile and all of them co-resident (registers allow 2 / 5 / 7 workgroups per CU):
-        // nothing is left to balance dynamically, so the kernel deals the tiles out statically instead
-        const int occ = (T == 128) ? 2 : (TN == 32 ? 7 : 5);
-        const int resident = (nblocks <= (int64_t)ctx->num_cu * occ && nblocks <= slots && nwv == 4 && xcd_rows != 2)
+        // one workgroup per tile and all of them co-resident: nothing is left to balance dynamically, so a static
+        // kernel deals the tiles out instead.  Co-residency per CU of k_predict_static (its VGPRs / LDS):
+        // 128x128: 2, 64x64: 7, 64x32: 8.
+        int occ = (T == 128) ? 2 : (TN == 32 ? 8 : 7);
+        if (ctx->resident_occ > 0) occ = ctx->resident_occ;
+        const int resident = (nblocks <= (int64_t)ctx->num_cu * occ && nwv == 4 && xcd_rows != 2)
                                  ? ctx->resident_order : 0;
-#define GPB_PRED(TT, WW, NN)                                                                                     \
-    hipLaunchKernelGGL((k_predict<TT, WW, NN>), dim3(grid), dim3(64 * WW), 0, ctx->stream, ctx->Linv, ctx->KsT,    \
-                       ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW, xcd_rows, ctx->tile_counter,           \
-                       (unsigned)nblocks, resident, (unsigned)(ctx->num_cu / 8), (ctx->tile_priority && resident) ? nI : 0,    \
-                       ctx->tile_trace)
-        if (T == 128)      { if (nwv == 8) GPB_PRED(128, 8, 128); else GPB_PRED(128, 4, 128); }
-        else if (TN == 32) GPB_PRED(64, 4, 32);
-        else               { if (nwv == 8) GPB_PRED(64, 8, 64); else GPB_PRED(64, 4, 64); }
+        const unsigned grid = (unsigned)((resident || nblocks < slots) ? nblocks : slots);
+#define GPB_PRED(TT, WW, NN, KK)                                                                                 \
+    do {                                                                                                         \
+        if (resident)                                                                                            \
+            hipLaunchKernelGGL((k_predict_static<TT, WW, NN, KK>), dim3(grid), dim3(64 * WW), 0, ctx->stream,     \
+                               ctx->Linv, ctx->KsT, ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW, xcd_rows, \
+                               (unsigned)nblocks, resident, (unsigned)(ctx->num_cu / 8),                          \
+                               ctx->tile_priority ? nI : 0, ctx->tile_trace);                                     \
+        else                                                                                                     \
+            hipLaunchKernelGGL((k_predict<TT, WW, NN, KK>), dim3(grid), dim3(64 * WW), 0, ctx->stream, ctx->Linv,  \
+                               ctx->KsT, ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW, xcd_rows,            \
+                               ctx->tile_counter, (unsigned)nblocks, ctx->tile_trace);                             \
+    } while (0)
+        // (32-deep K-steps for the 64-row tiles were measured: within 2.5 % either way, not kept)
+        if (T == 128)      { if (nwv == 8) GPB_PRED(128, 8, 128, 16); else GPB_PRED(128, 4, 128, 16); }
+        else if (TN == 32) GPB_PRED(64, 4, 32, 16);
+        else if (nwv == 8) GPB_PRED(64, 8, 64, 16);
+        else               GPB_PRED(64, 4, 64, 16);
 #undef GPB_PRED
         if (ctx->profile) {
             GPB_HIP(hipEventRecord(e1, ctx->stream));
