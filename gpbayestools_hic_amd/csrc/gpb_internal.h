@@ -78,7 +78,7 @@ struct gpb_ctx {
     int64_t mvn_ws_cap = 0;
     int* notpd = nullptr;          // device counter
     int num_cu = 256;               // multiprocessor count of the device
-    int wgs_per_cu64 = 6;           // persistent k_predict<64> workgroups per CU
+    int wgs_per_cu64 = 7;           // persistent k_predict<64> workgroups per CU (6 resident at 80 VGPRs; 7 measured 1-2 % better)
     int wgs_per_cu128w8 = 2;        // ... for the 128-tile, 8-wave variant
     int wgs_per_cu32 = 4;           // ... for the 64x32 tile
     int64_t narrow_switch = 128;    // padded walker batches up to this size use 64x32 tiles (0 = never)
@@ -92,7 +92,7 @@ struct gpb_ctx {
     int tile_priority = 1;         // k_predict: wave priority by K-loop length (s_setprio)
     int force_tile = 0;           // test hook: 0 = auto, 64 / 128 / 32 (= 64x32) force the k_predict tile
     int force_xcd = -1;             // tuning hook: -1 auto, 0 / 1 = k_predict XCD affinity by walker tile / row block
-    int64_t tile_switch = 1280;     // use 128x128 tiles when at least this many of them exist
+    int64_t tile_switch = 900;      // use 128x128 tiles when at least this many of them exist (measured crossover)
     bool force_generic_mvn = false; // test hook: bypass the register-resident MVN fast path
     int fuse_finalize = 1;          // block log-likelihood kernels sum the predict partials themselves (P <= 32)
     int64_t mvn_wg_switch = 768;   // batches up to this size use one workgroup per walker (32 < M <= 64)

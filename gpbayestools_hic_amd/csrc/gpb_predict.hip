@@ -212,7 +212,7 @@ __device__ __forceinline__ bool decode_tile(int xcd_mode, unsigned t, unsigned q
 // Exit condition: every workgroup walks all eight queues once and leaves each when its ticket is past
 // the queue's length; nothing spins.
 template <int T, int NW, int TN, int KB>
-__global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (KB == 32 ? 3 : 4))) void k_predict(const double* __restrict__ Linv, const double* __restrict__ KsT,
+__global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (T == 64 && TN == 64 && NW == 4 ? 6 : 4))) void k_predict(const double* __restrict__ Linv, const double* __restrict__ KsT,
                                                      double* __restrict__ spart, int64_t Np, int64_t Wld, int P,
                                                      int nI, int nW, int xcd_mode, unsigned* __restrict__ queue,
                                                      unsigned nblocks, unsigned* __restrict__ trace) {
