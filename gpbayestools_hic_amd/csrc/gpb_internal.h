@@ -88,7 +88,7 @@ struct gpb_ctx {
     int chol_inner_tile = 64;       // tile of the K=64 trailing updates inside an outer panel (64 or 128)
     int resident_order = 2;         // k_predict with one workgroup per tile: 0 = ticket queues, 1-3 = static orders (2 = snake)
     unsigned* tile_trace = nullptr; // debug hook: [count, capacity, pad x6][capacity][8] records of k_predict tiles
-    int resident_occ = 0;           // tuning hook: co-resident workgroups per CU assumed for the static launch (0 = table)
+    int resident_occ = 0;          // tuning hook: co-resident workgroups per CU assumed for the static launch (0 = table)
     int tile_priority = 1;         // k_predict: wave priority by K-loop length (s_setprio)
     int force_tile = 0;           // test hook: 0 = auto, 64 / 128 / 32 (= 64x32) force the k_predict tile
     int force_xcd = -1;             // tuning hook: -1 auto, 0 / 1 = k_predict XCD affinity by walker tile / row block

@@ -130,8 +130,9 @@ __device__ __forceinline__ void predict_tile(TileLds<T, TN, KB>& lds, int p, int
     Acc<T, NW, TN> acc;
     acc_zero<T, NW, TN>(acc);
     // Np is a multiple of 64 and the batch is padded to 128 walkers: 64-row tiles never have an edge
-    gemm_tile_loop<T, false, false, NW, TN, KB, T == 64>(Linv + (int64_t)p * Np * Np, Np, KsT + (int64_t)p * Np * Wld, Wld, mb, nb,
-                                            m_ext, TN, 0, k_end, lds, acc);
+    gemm_tile_loop<T, false, false, NW, TN, KB, T == 64>(Linv + (int64_t)p * Np * Np, Np,
+                                                         KsT + (int64_t)p * Np * Wld, Wld, mb, nb, m_ext, TN, 0, k_end,
+                                                         lds, acc);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     double s[NJ];
