@@ -433,7 +433,7 @@ extern "C" int gpb_loglike(gpb_ctx* ctx, const double* Xs, int64_t W, int on_dev
     int rc = stage_inputs(ctx, Xs, W, on_device, nullptr, &Xs_dev, nullptr);
     if (rc) return rc;
     if (n_notpd_host) GPB_HIP(hipMemsetAsync(ctx->notpd, 0, sizeof(int), ctx->stream));
-    const bool fused = loglike_fuses_finalize(ctx);
+    const bool fused = loglike_fuses_finalize(ctx, W);
     if ((rc = launch_predict(ctx, Xs_dev, W, true, !fused))) return rc;
     if (on_device) {
         if ((rc = launch_loglike(ctx, W, ll, accumulate != 0, fused))) return rc;
@@ -460,7 +460,7 @@ extern "C" int gpb_logpost(gpb_ctx* ctx, const double* Xs_dev, int64_t W, double
     GPB_HIP(hipSetDevice(ctx->device));
     int rc = ensure_wcap(ctx, W);
     if (rc) return rc;
-    const bool fused = loglike_fuses_finalize(ctx);
+    const bool fused = loglike_fuses_finalize(ctx, W);
     if ((rc = launch_predict(ctx, Xs_dev, W, true, !fused))) return rc;
     return launch_loglike(ctx, W, ll_dev, accumulate != 0, fused, Xs_dev, lo_dev, hi_dev, outside_value, inside_const);
 }

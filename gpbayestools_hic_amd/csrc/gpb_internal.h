@@ -145,7 +145,7 @@ int launch_predict_cov(gpb_ctx* ctx, const double* Xs_dev, int64_t W, double* co
 // likelihood (gpb_like.hip)
 int launch_obs(gpb_ctx* ctx, int64_t W, const double* estd_dev, double* mean_dev, double* cov_dev);
 // true when launch_loglike will take the block log-likelihood kernels that sum the partials themselves
-bool loglike_fuses_finalize(const gpb_ctx* ctx);
+bool loglike_fuses_finalize(const gpb_ctx* ctx, int64_t W);
 int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, bool from_partials,
                    const double* X_box = nullptr, const double* lo_dev = nullptr, const double* hi_dev = nullptr,
                    double outside = 0.0, double inside_const = 0.0);

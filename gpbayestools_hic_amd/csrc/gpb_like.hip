@@ -511,15 +511,18 @@ static bool block_kernels_apply(const gpb_ctx* ctx) {
     return ctx->mode == GPB_MODE_PCA && ctx->M <= 64 && ctx->P <= 96 && !ctx->force_generic_mvn;
 }
 
-bool loglike_fuses_finalize(const gpb_ctx* ctx) {
-    return block_kernels_apply(ctx) && ctx->P <= 32 && ctx->fuse_finalize;
+// Small batches only: there the saved launch and dependent pass matter (a rank's shard), while at thousands of
+// walkers the per-walker strided reads of the partials cost more than the coalesced k_finalize they replace
+// (measured: +25 us on k_loglike_reg<64> at 2048 walkers against a 6.6 us kernel).
+bool loglike_fuses_finalize(const gpb_ctx* ctx, int64_t W) {
+    return block_kernels_apply(ctx) && ctx->P <= 32 && ctx->fuse_finalize && W <= ctx->mvn_wg_switch;
 }
 
 int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, bool from_partials, const double* X_box,
                    const double* lo_dev, const double* hi_dev, double outside, double inside_const) {
     const int64_t M = ctx->M, P = ctx->P;
     const BoxArgs box{X_box, lo_dev, hi_dev, (int)ctx->d, outside, inside_const};
-    if (from_partials && !loglike_fuses_finalize(ctx)) GPB_FAIL(GPB_E_STATE, "gpb: internal: partials without a fused consumer");
+    if (from_partials && !loglike_fuses_finalize(ctx, W)) GPB_FAIL(GPB_E_STATE, "gpb: internal: partials without a fused consumer");
     if (block_kernels_apply(ctx)) {
         PartArgs part{nullptr, nullptr, nullptr, nullptr, 0, 0};
         if (from_partials)
