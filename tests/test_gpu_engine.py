@@ -251,3 +251,25 @@ def test_predict_tile_sizes_are_bit_identical(eng):
                     m2, v2 = eng.predict(Xs)
                     assert np.array_equal(m1, m2) and np.array_equal(v1, v2), (tile, xcd, order)
         eng.force_tile(0); eng.tune("xcd", -1); eng.tune("resident", 2)
+
+
+def test_predict_tile_trace_covers_every_tile_once(eng):
+    """debug hook: one record per (GP, row block, walker tile), for the static and the ticket-queue launch"""
+    from gpbayestools_hic_amd import synth
+    rng = np.random.default_rng(21)
+    N, d, P, W = 512, 5, 3, 256
+    eng.set_data(synth.lhs(N, d, seed=3), rng.standard_normal((P, N)), "RBF", 0.1)
+    eng.set_theta(synth.fixed_theta(d, P)); eng.factor()
+    Xs = rng.random((W, d))
+    eng.force_tile(64)
+    for order in (2, 0):                                   # static snake launch / persistent ticket queues
+        eng.tune("resident", order)
+        eng.tile_trace(4096)
+        eng.predict(Xs)
+        rec = eng.tile_trace_read()
+        eng.tile_trace(0)
+        tiles = {(int(r[2]), int(r[3]), int(r[4])) for r in rec}
+        assert len(rec) == P * (N // 64) * (W // 64) == len(tiles)
+        assert tiles == {(p, ib, wt) for p in range(P) for ib in range(N // 64) for wt in range(W // 64)}
+        assert np.all((rec[:, 6].astype(np.int64) - rec[:, 5].astype(np.int64)) % (1 << 32) < 10_000_000)   # < 0.1 s
+    eng.force_tile(0); eng.tune("resident", 2)
