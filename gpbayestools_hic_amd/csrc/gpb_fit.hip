@@ -316,8 +316,17 @@ int launch_potrf(gpb_ctx* ctx) {
                 hipLaunchKernelGGL(k_syrk<128>, grid, dim3(256), 0, ctx->stream, ctx->K, Np, c0, 64, r0, pe);
             }
         } else {                                        // panel finished: whole trailing matrix, K = panel width
-            dim3 grid((unsigned)((Np - r0 + 127) / 128), (unsigned)((Np - r0 + 127) / 128), (unsigned)ctx->P);
-            hipLaunchKernelGGL(k_syrk<128>, grid, dim3(256), 0, ctx->stream, ctx->K, Np, pb, (int)(pe - pb), r0, Np);
+            const int64_t nt = (Np - r0 + 127) / 128;
+            const bool small = ctx->syrk_tile == 64 ||
+                               (ctx->syrk_tile == 0 && nt * (nt + 1) / 2 * ctx->P < 16 * (int64_t)ctx->num_cu);
+            if (small) {                                // few 128-wide tiles: 64-wide ones fill the chip (same bits)
+                const unsigned n64 = (unsigned)((Np - r0 + 63) / 64);
+                hipLaunchKernelGGL(k_syrk<64>, dim3(n64, n64, (unsigned)ctx->P), dim3(256), 0, ctx->stream, ctx->K, Np,
+                                   pb, (int)(pe - pb), r0, Np);
+            } else {
+                hipLaunchKernelGGL(k_syrk<128>, dim3((unsigned)nt, (unsigned)nt, (unsigned)ctx->P), dim3(256), 0,
+                                   ctx->stream, ctx->K, Np, pb, (int)(pe - pb), r0, Np);
+            }
         }
     }
     GPB_HIP(hipGetLastError());
@@ -328,31 +337,31 @@ int launch_potrf(gpb_ctx* ctx) {
 // inv([[A,0],[C,B]]) = [[A^-1,0],[-B^-1 C A^-1, B^-1]].  Level hs: the hs-sized diagonal blocks
 // of Linv are complete; phase 1: T = C A^-1, phase 2: X21 = -B^-1 T.  Both are NN MFMA GEMMs
 // whose K range is clipped by the triangular operand.
-template <int PHASE>
+template <int PHASE, int T_>
 __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict__ L, double* __restrict__ Linv,
                                                         double* __restrict__ T, int64_t Np, int64_t hs,
                                                         int ngroups) {
-    __shared__ TileLds<128> lds;
+    __shared__ TileLds<T_> lds;
     const int p = blockIdx.z / ngroups, g = blockIdx.z % ngroups;
     const int64_t c0 = (int64_t)g * 2 * hs, r0 = c0 + hs;
     const int64_t n2 = imin64(hs, Np - r0);
-    const int64_t mb = (int64_t)blockIdx.y * 128, nb = (int64_t)blockIdx.x * 128;
+    const int64_t mb = (int64_t)blockIdx.y * T_, nb = (int64_t)blockIdx.x * T_;
     if (n2 <= 0 || mb >= n2 || nb >= hs) return;
-    const int m_ext = (int)imin64(128, n2 - mb), n_ext = (int)imin64(128, hs - nb);
+    const int m_ext = (int)imin64(T_, n2 - mb), n_ext = (int)imin64(T_, hs - nb);
     const int64_t off = (int64_t)p * Np * Np;
-    Acc<128> acc;
-    acc_zero<128>(acc);
+    Acc<T_> acc;
+    acc_zero<T_>(acc);
     if (PHASE == 1) {
         // T[r0+m][c0+n] = sum_{k>=n} L[r0+m][c0+k] * Linv[c0+k][c0+n]
-        gemm_tile_loop<128,false, false>(L + off + r0 * Np + c0, Np, Linv + off + c0 * Np + c0, Np, mb, nb, m_ext,
-                                     n_ext, nb, hs, lds, acc);
-        tile_store<128>(T + off + r0 * Np + c0, Np, mb, nb, m_ext, n_ext, 1.0, false, acc);
+        gemm_tile_loop<T_, false, false>(L + off + r0 * Np + c0, Np, Linv + off + c0 * Np + c0, Np, mb, nb, m_ext,
+                                         n_ext, nb, hs, lds, acc);
+        tile_store<T_>(T + off + r0 * Np + c0, Np, mb, nb, m_ext, n_ext, 1.0, false, acc);
     } else {
         // Linv[r0+m][c0+n] = -sum_{k<=m} Linv[r0+m][r0+k] * T[r0+k][c0+n]
-        const int64_t k_end = imin64(mb + 128, n2);
-        gemm_tile_loop<128,false, false>(Linv + off + r0 * Np + r0, Np, T + off + r0 * Np + c0, Np, mb, nb, m_ext,
-                                     n_ext, 0, k_end, lds, acc);
-        tile_store<128>(Linv + off + r0 * Np + c0, Np, mb, nb, m_ext, n_ext, -1.0, false, acc);
+        const int64_t k_end = imin64(mb + T_, n2);
+        gemm_tile_loop<T_, false, false>(Linv + off + r0 * Np + r0, Np, T + off + r0 * Np + c0, Np, mb, nb, m_ext,
+                                         n_ext, 0, k_end, lds, acc);
+        tile_store<T_>(Linv + off + r0 * Np + c0, Np, mb, nb, m_ext, n_ext, -1.0, false, acc);
     }
 }
 
@@ -360,12 +369,26 @@ int launch_trtri(gpb_ctx* ctx) {
     const int64_t Np = ctx->Np;
     for (int64_t hs = 64; hs < Np; hs *= 2) {
         const int ngroups = (int)((Np + 2 * hs - 1) / (2 * hs));
-        const unsigned tl = (unsigned)((hs + 127) / 128);
-        dim3 grid(tl, tl, (unsigned)(ngroups * ctx->P));
-        hipLaunchKernelGGL(k_trtri_level<1>, grid, dim3(256), 0, ctx->stream, ctx->K, ctx->Linv, ctx->T, Np, hs,
-                           ngroups);
-        hipLaunchKernelGGL(k_trtri_level<2>, grid, dim3(256), 0, ctx->stream, ctx->K, ctx->Linv, ctx->T, Np, hs,
-                           ngroups);
+        // 64-wide tiles while 128-wide ones would leave the chip underfilled or badly quantised (measured faster up
+        // to ~10 tiles of 128 per CU: N = 2048 4.58 -> 4.17 ms, N = 4096 17.96 -> 17.54 ms for the whole fit);
+        // the k order of every element's sum does not depend on the tile size: same bits either way
+        const int64_t tl128 = (hs + 127) / 128;
+        const int64_t tiles128 = tl128 * tl128 * ngroups * ctx->P;
+        const bool small = ctx->trtri_tile == 64 || (ctx->trtri_tile == 0 && tiles128 < 16 * (int64_t)ctx->num_cu);
+        if (small) {
+            const unsigned tl = (unsigned)((hs + 63) / 64);
+            dim3 grid(tl, tl, (unsigned)(ngroups * ctx->P));
+            hipLaunchKernelGGL((k_trtri_level<1, 64>), grid, dim3(256), 0, ctx->stream, ctx->K, ctx->Linv, ctx->T, Np,
+                               hs, ngroups);
+            hipLaunchKernelGGL((k_trtri_level<2, 64>), grid, dim3(256), 0, ctx->stream, ctx->K, ctx->Linv, ctx->T, Np,
+                               hs, ngroups);
+        } else {
+            dim3 grid((unsigned)tl128, (unsigned)tl128, (unsigned)(ngroups * ctx->P));
+            hipLaunchKernelGGL((k_trtri_level<1, 128>), grid, dim3(256), 0, ctx->stream, ctx->K, ctx->Linv, ctx->T,
+                               Np, hs, ngroups);
+            hipLaunchKernelGGL((k_trtri_level<2, 128>), grid, dim3(256), 0, ctx->stream, ctx->K, ctx->Linv, ctx->T,
+                               Np, hs, ngroups);
+        }
     }
     GPB_HIP(hipGetLastError());
     return 0;

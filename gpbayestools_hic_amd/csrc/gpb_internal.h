@@ -85,7 +85,9 @@ struct gpb_ctx {
     int predict_waves = 4;          // waves per k_predict tile (4 or 8)
     unsigned* tile_counter = nullptr;   // 8 ticket queues (stride 16) + done counter [128]; re-armed by the kernel
     int64_t chol_outer = 512;      // outer panel width of the two-level blocked Cholesky
-    int chol_inner_tile = 64;       // tile of the K=64 trailing updates inside an outer panel (64 or 128)
+    int syrk_tile = 0;              // tile of the end-of-panel trailing updates (0 = by fill, 64, 128)
+    int trtri_tile = 0;            // tile of the triangular-inverse levels (0 = by fill, 64, 128)
+    int chol_inner_tile = 64;      // tile of the K=64 trailing updates inside an outer panel (64 or 128)
     int resident_order = 2;         // k_predict with one workgroup per tile: 0 = ticket queues, 1-3 = static orders (2 = snake)
     unsigned* tile_trace = nullptr; // debug hook: [count, capacity, pad x6][capacity][8] records of k_predict tiles
     int resident_occ = 0;          // tuning hook: co-resident workgroups per CU assumed for the static launch (0 = table)
