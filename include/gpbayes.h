@@ -211,8 +211,9 @@ int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
  * (PCA mode, 32 < M <= 64) runs one workgroup per walker instead of one wave per walker;
  * 9 = tile (64 or 128) of the K=64 trailing updates inside an outer Cholesky panel;
  * 10 = wave priority of predict tiles by K-loop length (0/1); 11 = the block log-likelihood kernels sum the
- * predict partials themselves instead of a separate finalize launch (0/1); 13 = co-resident workgroups per
- * CU assumed when choosing the static predict launch (0 = built-in table). */
+ * predict partials themselves instead of a separate finalize launch (0/1); 12 / 14 = tile of the
+ * triangular-inverse levels / of the end-of-panel Cholesky updates (0 = by fill, 64, 128);
+ * 13 = co-resident workgroups per CU assumed when choosing the static predict launch (0 = built-in table). */
 int gpb_debug_tune(gpb_ctx* ctx, int key, int value);
 /* debug hook: per-tile placement and timing of the predict kernel.  capacity > 0 arms (and clears) a trace of
  * that many records, 0 disarms; read copies up to max_records records of 8 uint32 {HW_ID register, XCC_ID,
