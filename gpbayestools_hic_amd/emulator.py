@@ -120,6 +120,32 @@ class Emulator:
             self._ppca = ParameterPCA(self.design_points, self.design_min, self.design_max)
             self.PCA_new_design_points = self._ppca.new_design_points
             self.design_min, self.design_max = self._ppca.design_min, self._ppca.design_max
+            # the reference's attribute names for the three parameter groups (src/emulator.py:79-99)
+            from . import param_pca as _pp
+            self.targetVariance = _pp.TARGET_VARIANCE
+            bulk, shear, yloss = self._ppca.groups
+            self.indices_zeta_s_parameters = list(_pp.IDX_BULK)
+            self.indices_eta_s_parameters = list(_pp.IDX_SHEAR)
+            self.indices_yloss_parameters = list(_pp.IDX_YLOSS)
+            self.paramTrafoScaler_bulk, self.paramTrafoPCA_bulk = bulk.scaler, bulk.pca
+            self.paramTrafoScaler_shear, self.paramTrafoPCA_shear = shear.scaler, shear.pca
+            self.paramTrafoScaler_yloss, self.paramTrafoPCA_yloss = yloss.scaler, yloss.pca
+
+    # scalar forms of the parametrised functions behind parameterTrafoPCA (src/emulator.py:102-126)
+    def parametrization_zeta_over_s_vs_T(self, zeta_max, T_zeta0, sigma_plus, sigma_minus, T, mu_B):
+        from .param_pca import zeta_over_s
+        par = np.array([[zeta_max, T_zeta0, sigma_plus, sigma_minus]], dtype=np.float64)
+        return float(zeta_over_s(par, T=np.array([T], dtype=np.float64), mu_B=mu_B)[0, 0])
+
+    def parametrization_eta_over_s_vs_mu_B(self, eta_0, eta_2, eta_4, mu_B):
+        from .param_pca import eta_over_s
+        return float(eta_over_s(np.array([[eta_0, eta_2, eta_4]], dtype=np.float64),
+                                mu_B=np.array([mu_B], dtype=np.float64))[0, 0])
+
+    def parametrization_y_loss_vs_y_init(self, yloss_2, yloss_4, yloss_6, y_init):
+        from .param_pca import y_loss
+        return float(y_loss(np.array([[yloss_2, yloss_4, yloss_6]], dtype=np.float64),
+                            y_init=np.array([y_init], dtype=np.float64))[0, 0])
 
     # ------------------------------------------------------------------ data loading
     def _load_training_data_pickle(self, dataFile):
@@ -315,6 +341,12 @@ class Emulator:
             draws.append(rng.multivariate_normal(mean[:, i], cov[i], n_samples).T[:, :, np.newaxis])
         rest = np.random.standard_normal((X.shape[0], n_samples, self.pca.n_components_ - self.npc))
         Z = np.concatenate(draws + [rest], axis=2)
+        return self._inverse_transform(Z)
+
+    def _inverse_transform(self, Z):
+        """principal components Z[..., k] -> observables [..., nobs], using the first k rows of the PC ->
+        observable map (src/emulator.py:366-375)"""
+        Z = np.asarray(Z, dtype=np.float64)
         return np.dot(Z, self._trans_matrix[:Z.shape[-1]]) + self.scaler.mean_
 
     # ------------------------------------------------------------------ hold-out validation helpers

@@ -40,6 +40,9 @@ def test_g3_g4_emulator_at_reference_theta(tmp_path, name):
     assert maxrel(emu.scaler.scale_, g["scaler_scale"]) < 1e-14
     if "trans_matrix" in g.files:
         assert maxrel(emu._trans_matrix, g["trans_matrix"]) < 1e-11
+        Zpc = np.random.default_rng(4).standard_normal((3, 2, emu.npc))          # (..., npc) -> (..., nobs)
+        want = Zpc @ g["trans_matrix"][:emu.npc] + emu.scaler.mean_
+        assert maxrel(emu._inverse_transform(Zpc), want) < 1e-11                 # src/emulator.py:366-375
         assert maxrel(emu._cov_trunc, g["cov_trunc"]) < 1e-11
         assert maxrel(emu._var_trans, g["var_trans"]) < 1e-11
     assert relerr(emu.lml_, g["lml"]) < 1e-10

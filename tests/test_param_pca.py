@@ -38,6 +38,33 @@ def test_function_families_match_reference_branches():
     assert maxrel(pp.y_loss(par3), np.array([[yl(*p, y) for y in pp.YINIT_GRID] for p in par3])) < 1e-15
 
 
+def test_emulator_exposes_reference_parameter_pca_surface(tmp_path):
+    """attribute and method names notebooks use on a parameterTrafoPCA emulator (src/emulator.py:79-126);
+    construction needs no device"""
+    from gpbayestools_hic_amd import Emulator, synth
+    from gpbayestools_hic_amd import param_pca as pp
+    g = golden("g7_param_pca.npz")
+    tp, pf = str(tmp_path / "t.pkl"), str(tmp_path / "p.txt")
+    synth.write_training_pickle(tp, g["X"], g["Y"], 0.01)
+    synth.write_parameter_file(pf, g["lo"], g["hi"])
+    emu = Emulator(training_set_path=tp, parameter_file=pf, npc=int(g["npc"]), parameterTrafoPCA=True)
+    assert emu.targetVariance == 0.99
+    assert emu.indices_zeta_s_parameters == [15, 16, 17, 18] and emu.indices_eta_s_parameters == [12, 13, 14]
+    assert emu.indices_yloss_parameters == [2, 3, 4]
+    assert [emu.paramTrafoPCA_bulk.n_components_, emu.paramTrafoPCA_shear.n_components_,
+            emu.paramTrafoPCA_yloss.n_components_] == list(g["n_components"])
+    assert emu.paramTrafoScaler_bulk.mean_.shape == (100,)
+    # scalar parametrisations agree with the vectorised grid functions, branch by branch
+    z_lo = emu.parametrization_zeta_over_s_vs_T(0.1, 0.2, 0.05, 0.03, 0.15, 0.0)
+    assert z_lo == pp.zeta_over_s(np.array([[0.1, 0.2, 0.05, 0.03]]), T=np.array([0.15]))[0, 0]
+    z_hi = emu.parametrization_zeta_over_s_vs_T(0.1, 0.2, 0.05, 0.03, 0.25, 0.3)
+    assert abs(z_hi - 0.1 * np.exp(-(0.25 - (0.2 - 0.15 * 0.3 ** 2)) ** 2 / (2 * 0.05 ** 2))) < 1e-16
+    for m, want in ((0.1, 0.1 + (0.2 - 0.1) * 0.5), (0.3, 0.2 + (0.05 - 0.2) * ((0.3 - 0.2) / 0.2)), (0.5, 0.05), (0.0, 0.05)):
+        assert abs(emu.parametrization_eta_over_s_vs_mu_B(0.1, 0.2, 0.05, m) - want) < 1e-16
+    for y, want in ((1.0, 0.5), (3.0, 1.0 + (2.0 - 1.0) * 0.5), (5.0, 2.0 + (0.5 - 2.0) * 0.5)):
+        assert abs(emu.parametrization_y_loss_vs_y_init(1.0, 2.0, 0.5, y) - want) < 1e-15
+
+
 @pytest.mark.gpu
 def test_emulator_with_parameter_pca_gpu(tmp_path):
     from gpbayestools_hic_amd import Emulator, synth
