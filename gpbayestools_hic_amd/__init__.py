@@ -7,7 +7,8 @@ src/mcmc.py log-posterior loop): hand-written HIP kernels for gfx950 behind a C 
 """
 __version__ = "0.1.0"
 
-__all__ = ["Emulator", "Chain", "mvn_loglike", "GPEngine", "StretchSampler", "WalkerSharding"]
+__all__ = ["Emulator", "Chain", "mvn_loglike", "GPEngine", "StretchSampler", "LoggingEnsembleSampler",
+           "WalkerSharding"]
 
 
 def __getattr__(name):   # lazy: importing the package must not need torch / the built library
@@ -20,9 +21,9 @@ def __getattr__(name):   # lazy: importing the package must not need torch / the
     if name == "GPEngine":
         from .engine import GPEngine
         return GPEngine
-    if name == "StretchSampler":
-        from .sampler import StretchSampler
-        return StretchSampler
+    if name in ("StretchSampler", "LoggingEnsembleSampler"):
+        from . import sampler
+        return getattr(sampler, name)
     if name == "WalkerSharding":
         from .dist import WalkerSharding
         return WalkerSharding

@@ -19,6 +19,7 @@ import numpy as np
 from .emulator import Emulator
 from .engine import GPEngine
 from .preprocess import parse_model_parameter_file
+from .sampler import LoggingEnsembleSampler  # noqa: F401  (the reference defines it in this module)
 
 log = logging.getLogger(__name__)
 

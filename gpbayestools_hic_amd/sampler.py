@@ -142,3 +142,39 @@ class StretchSampler:
     @property
     def flatlnprobability(self):
         return self._lp_dev.reshape(-1).cpu().numpy()
+
+
+class _HostLogProb:
+    """minimal chain-like object around a host callable f(X[w, ndim]) -> lp[w]"""
+
+    def __init__(self, ndim, fn, device):
+        self.ndim, self.fn, self.device, self.emuList = int(ndim), fn, int(device), []
+
+    def log_prob_device(self, X_dev, out):
+        import torch
+        lp = np.asarray(self.fn(X_dev.cpu().numpy()), dtype=np.float64).reshape(-1)
+        out.copy_(torch.as_tensor(lp, device=out.device))
+        return out
+
+
+class LoggingEnsembleSampler(StretchSampler):
+    """The reference's sampler class by name and call signature (src/mcmc.py:68-92, 372-412):
+    `LoggingEnsembleSampler(nwalkers, ndim, log_prob_fn, pool=...)`, `run_mcmc(X0, nsteps, status=)`, then
+    `.chain`, `.flatchain`, `.lnprobability`, `.flatlnprobability`, `.acceptance_fraction`, `.reset()`.
+    When `log_prob_fn` is `Chain.log_posterior` of this package the whole loop stays on the device;
+    any other callable f(X[w, ndim]) -> lp[w] is called on the host once per half-ensemble (the stretch
+    move itself still runs on the device).  `pool` is accepted and ignored: batches are already whole."""
+
+    def __init__(self, nwalkers, ndim, log_prob_fn, pool=None, a=2.0, seed=None, device=0, **_ignored):
+        from .mcmc import Chain
+        owner = getattr(log_prob_fn, "__self__", None)
+        if isinstance(owner, Chain) and owner._native() and getattr(log_prob_fn, "__func__", None) is Chain.log_posterior:
+            if int(ndim) != owner.ndim:
+                raise ValueError("ndim does not match the chain's number of parameters")
+            super().__init__(owner, nwalkers, seed=seed, a=a)
+        else:
+            super().__init__(_HostLogProb(ndim, log_prob_fn, device), nwalkers, seed=seed, a=a)
+
+    def run_mcmc(self, X0, nsteps, status=None, **_kwargs):
+        log.info("running %d walkers for %d steps", self.nwalkers, nsteps)
+        return self.run(X0, nsteps, status=status)

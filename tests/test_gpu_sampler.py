@@ -82,6 +82,29 @@ def test_same_seed_reproduces_chain_and_shards_do_not_change_it():
     assert not np.array_equal(s2.chain, runs[0][0])
 
 
+def test_logging_ensemble_sampler_by_the_references_signature(tmp_path):
+    """LoggingEnsembleSampler(nwalkers, ndim, log_prob_fn, pool=...).run_mcmc(X0, nsteps, status=...) as the
+    reference drives it (src/mcmc.py:372-412): bound Chain.log_posterior stays on the device, any other callable is
+    evaluated on the host — both walk the same chain as StretchSampler with that seed."""
+    from gpbayestools_hic_amd import StretchSampler, synth
+    from gpbayestools_hic_amd.mcmc import LoggingEnsembleSampler
+    from gpbayestools_hic_amd.workload import build_chain
+    chain, emu, info = build_chain(1, workdir=str(tmp_path))
+    nw, d = 32, info["d"]
+    X0 = synth.walkers(nw, d, seed=9)
+    ref = StretchSampler(chain, nw, seed=77)
+    ref.run(X0, 12)
+    dev = LoggingEnsembleSampler(nw, d, chain.log_posterior, pool=chain, seed=77)
+    last = dev.run_mcmc(X0, 12, status=5)
+    assert np.array_equal(dev.chain, ref.chain) and np.array_equal(dev.lnprobability, ref.lnprobability)
+    assert last.shape == (nw, d) and dev.chain.shape == (nw, 12, d) and dev.flatchain.shape == (nw * 12, d)
+    host = LoggingEnsembleSampler(nw, d, lambda X: chain.log_posterior(X), seed=77)
+    host.run_mcmc(X0, 12)
+    assert np.array_equal(host.chain, ref.chain)          # same numbers through the host callback
+    host.reset()
+    assert host.iterations == 0 and np.all(host.acceptance_fraction == 0)
+
+
 def test_chain_run_mcmc_schema_and_resume(tmp_path):
     from test_gpu_dropin import _chain
     g = golden("g5_chain.npz")
