@@ -416,8 +416,18 @@ __global__ __launch_bounds__(256) void k_lower_matvec_t(const double* __restrict
     const int64_t j0 = (int64_t)blockIdx.x * 64, j = j0 + lane;
     const double* Lp = Linv + (int64_t)p * Np * Np;
     const double* yp = y + (int64_t)p * Np;
-    double s = 0.0;
-    for (int64_t i = j0 + wave; i < Np; i += 4) s = fma(Lp[i * Np + j], yp[i], s);
+    // four independent chains per wave (rows i = j0 + wave + 4t, chain t mod 4): the single dependent chain
+    // was pure load latency (~115 us at N = 2048); fixed order, so the result is reproducible
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int64_t i = j0 + wave;
+    for (; i + 12 < Np; i += 16) {
+        s0 = fma(Lp[i * Np + j], yp[i], s0);
+        s1 = fma(Lp[(i + 4) * Np + j], yp[i + 4], s1);
+        s2 = fma(Lp[(i + 8) * Np + j], yp[i + 8], s2);
+        s3 = fma(Lp[(i + 12) * Np + j], yp[i + 12], s3);
+    }
+    for (; i < Np; i += 4) s0 = fma(Lp[i * Np + j], yp[i], s0);
+    const double s = (s0 + s1) + (s2 + s3);
     red[wave][lane] = s;
     __syncthreads();
     if (wave == 0) out[(int64_t)p * Np + j] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
