@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void k_potf2_inv(double* __restrict__ K, doubl
     __shared__ double a[64][65];     // block -> L
     __shared__ double x[64][65];     // L^-1
     __shared__ double tm[64][65];    // scratch for the inverse assembly
+    __shared__ double rdg[64];       // reciprocals of the pivots
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t c0 = kb * 64;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void k_potf2_inv(double* __restrict__ K, doubl
         if (wave == 0) {
             // ---- 16x16 diagonal sub-block in registers: lane i (< 16) owns row i
             const int li = lane & 15;
-            double r[16], rd[16];                          // row of the block; reciprocals of the pivots
+            double r[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) r[k] = a[o + li][o + k];
             int badj = -1;
@@ -162,54 +163,34 @@ __global__ __launch_bounds__(256) void k_potf2_inv(double* __restrict__ K, doubl
                 if (!(ajj > 0.0) && badj < 0) badj = j;
                 const double rinv = rsqrt(ajj);                   // 1 / L_jj
                 const double lj = r[j] * rinv;                    // column j of L (rows >= j; row j: sqrt(a_jj))
-                rd[j] = rinv;
+                if (lane == 0) rdg[o + j] = rinv;
                 r[j] = lj;
 #pragma unroll
                 for (int k = j + 1; k < 16; ++k) r[k] = fma(-lj, rl64(lj, k), r[k]);
             }
             if (badj >= 0 && lane == 0 && info[p] == 0) info[p] = (int)(c0 + o + badj + 1);
-            // ---- inverse of the 16x16 factor: lane c (< 16) owns column c of X
-            double xc[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) xc[i] = 0.0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                double sacc = 0.0;
-#pragma unroll
-                for (int k = 0; k < i; ++k) sacc = fma(rl64(r[k], i), xc[k], sacc);   // l_ik from lane i's row
-                const double v = (i == li) ? rd[i] : -sacc * rd[i];
-                xc[i] = (i >= li) ? v : 0.0;
-            }
             if (lane < 16) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    a[o + li][o + k] = (k <= li) ? r[k] : 0.0;
-                    x[o + k][o + li] = xc[k];          // column li of the inverse
-                }
+                for (int k = 0; k < 16; ++k) a[o + li][o + k] = (k <= li) ? r[k] : 0.0;
             }
         }
         __syncthreads();
         const int nrem = 48 - o;                       // rows below this sub-block inside the 64-block
         if (nrem > 0) {
-            // ---- panel: L21 = A21 X11^T   (X11 lower: sum over k <= j)
-            double pv[3];
+            // ---- panel: L21 L11^T = A21 by forward substitution, one row per thread (the 16x16 inverses are
+            //      not needed here and are taken off this serial chain: all four are formed in parallel below)
+            if (tid < nrem) {
+                const int rr = o + 16 + tid;
+                double l[16];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int idx = tid + 256 * u;
-                pv[u] = 0.0;
-                if (idx < nrem * 16) {
-                    const int rr = o + 16 + (idx >> 4), j = idx & 15;
-                    double sacc = 0.0;
+                for (int j = 0; j < 16; ++j) {
+                    double sacc = a[rr][o + j];
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) sacc = fma(a[rr][o + k], x[o + j][o + k], sacc);   // X11 is 0 above its diagonal
-                    pv[u] = sacc;
+                    for (int k = 0; k < j; ++k) sacc = fma(-l[k], a[o + j][o + k], sacc);
+                    l[j] = sacc * rdg[o + j];
                 }
-            }
-            __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int idx = tid + 256 * u;
-                if (idx < nrem * 16) a[o + 16 + (idx >> 4)][o + (idx & 15)] = pv[u];
+                for (int j = 0; j < 16; ++j) a[rr][o + j] = l[j];
             }
             __syncthreads();
             // ---- trailing update of the lower triangle: A22 -= L21 L21^T
@@ -223,6 +204,30 @@ __global__ __launch_bounds__(256) void k_potf2_inv(double* __restrict__ K, doubl
             __syncthreads();
         }
     }
+    {
+        // ---- inverses of the four 16x16 diagonal factors, one per wave: lane c (< 16) owns column c of X
+        const int o = 16 * wave, li = lane & 15;
+        double r[16], xc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            r[k] = a[o + li][o + k];                   // row li of L11 (zeros above the diagonal)
+            xc[k] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const double rdi = rdg[o + i];
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < i; ++k) sacc = fma(rl64(r[k], i), xc[k], sacc);   // l_ik from lane i's row
+            const double v = (i == li) ? rdi : -sacc * rdi;
+            xc[i] = (i >= li) ? v : 0.0;
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x[o + k][o + li] = xc[k];          // column li of the inverse
+        }
+    }
+    __syncthreads();
     // ---- assemble L^-1 from its 16x16 diagonal blocks by block doubling (hs = 16, then 32):
     //      X21 = -X22 (L21 X11)
     for (int hs = 16; hs <= 32; hs *= 2) {
