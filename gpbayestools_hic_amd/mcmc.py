@@ -188,8 +188,18 @@ class Chain:
         if self._native():
             import torch
             dev = torch.device("cuda", self.device)
-            Xd = torch.as_tensor(np.ascontiguousarray(X), device=dev)
-            return self.log_prob_device(Xd, outside=outside).cpu().numpy()
+            # long inputs (a stored chain, src/mcmc.py:729-749) go through in slabs: the K*^T workspace is
+            # P x N x rows doubles per emulator; a row's result does not depend on how the batch is cut
+            per_row = max(8 * e._ngp * e._X_train.shape[0] for e in self.emuList)
+            slab = int(min(max((8 << 30) // per_row, 1024), 1 << 17)) // 128 * 128
+            if X.shape[0] <= slab:
+                Xd = torch.as_tensor(np.ascontiguousarray(X), device=dev)
+                return self.log_prob_device(Xd, outside=outside).cpu().numpy()
+            out = np.empty(X.shape[0])
+            for i0 in range(0, X.shape[0], slab):
+                Xd = torch.as_tensor(np.ascontiguousarray(X[i0:i0 + slab]), device=dev)
+                out[i0:i0 + slab] = self.log_prob_device(Xd, outside=outside).cpu().numpy()
+            return out
         # generic path: foreign emulators predict on the host, the MVN runs on the device
         lp = np.zeros(X.shape[0])
         inside = np.all((X > self.min) & (X < self.max), axis=1)

@@ -74,3 +74,18 @@ def test_two_walker_ensemble_runs():
     s = StretchSampler(fake, 2, seed=1, logprob_device=lambda X, out: out.copy_(-0.5 * (X * X).sum(1)))
     s.run(np.array([[0.1], [-0.2]]), 50)
     assert s.chain.shape == (2, 50, 1) and np.all(np.isfinite(s.chain))
+
+
+def test_long_host_batches_go_through_in_slabs(tmp_path):
+    """a stored chain handed to log_likelihood_point_by_point (src/mcmc.py:225-258, 729-749) is longer than the
+    slab the K*^T workspace is sized for: same numbers as row-by-row pieces, outside rows included"""
+    from gpbayestools_hic_amd import synth
+    from gpbayestools_hic_amd.workload import build_chain
+    chain, emu, info = build_chain(1, workdir=str(tmp_path))
+    W = (1 << 17) + 37                                     # one row more than a slab, and a ragged tail
+    X = synth.walkers(W, info["d"], seed=11)
+    X[::1001, 0] = 1.5
+    lp = chain.log_likelihood_point_by_point(X)
+    assert lp.shape == (W,) and np.all(np.isneginf(lp[::1001])) and np.all(np.isfinite(np.delete(lp, np.s_[::1001])))
+    for sl in (slice(0, 300), slice((1 << 17) - 50, (1 << 17) + 37)):
+        assert np.array_equal(chain.log_posterior(X[sl]), lp[sl])
