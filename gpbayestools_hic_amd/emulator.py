@@ -319,10 +319,27 @@ class Emulator:
         X = np.atleast_2d(np.asarray(X, dtype=np.float64))
         Xg = np.ascontiguousarray(self._map_parameters(X))
         eng = self._engine_ready()
-        if not return_cov:
-            return eng.emu_predict(Xg, return_cov=False)
-        es = np.broadcast_to(np.asarray(extra_std, dtype=np.float64).reshape(-1), (Xg.shape[0],))
-        return eng.emu_predict(Xg, return_cov=True, extra_std=np.ascontiguousarray(es))
+        W = Xg.shape[0]
+        es = None
+        if return_cov:
+            es = np.ascontiguousarray(np.broadcast_to(np.asarray(extra_std, dtype=np.float64).reshape(-1), (W,)))
+        # very long inputs go through in slabs sized for the device workspaces (K*^T: P x N doubles per row,
+        # staged covariances: nobs^2 per row); a row's numbers do not depend on how the batch is cut
+        per_row = 8 * (self._ngp * self._X_train.shape[0] + (self.nobs ** 2 if return_cov else 0))
+        slab = int(min(max((8 << 30) // per_row, 1024), 1 << 17)) // 128 * 128
+        if W <= slab:
+            return eng.emu_predict(Xg, return_cov=return_cov, extra_std=es)
+        mean = np.empty((W, self.nobs))
+        cov = np.empty((W, self.nobs, self.nobs)) if return_cov else None
+        for i0 in range(0, W, slab):
+            sl = slice(i0, min(i0 + slab, W))
+            part = eng.emu_predict(np.ascontiguousarray(Xg[sl]), return_cov=return_cov,
+                                   extra_std=None if es is None else np.ascontiguousarray(es[sl]))
+            if return_cov:
+                mean[sl], cov[sl] = part
+            else:
+                mean[sl] = part
+        return (mean, cov) if return_cov else mean
 
     def sample_y(self, X, n_samples=1, random_state=None):
         """Sample model output at X -> [n_samples_X, n_samples, nobs] (src/emulator.py:608-633): one

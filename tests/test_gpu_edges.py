@@ -89,3 +89,9 @@ def test_long_host_batches_go_through_in_slabs(tmp_path):
     assert lp.shape == (W,) and np.all(np.isneginf(lp[::1001])) and np.all(np.isfinite(np.delete(lp, np.s_[::1001])))
     for sl in (slice(0, 300), slice((1 << 17) - 50, (1 << 17) + 37)):
         assert np.array_equal(chain.log_posterior(X[sl]), lp[sl])
+    Xin = np.clip(X, 0.0, 1.0)
+    mean = emu.predict(Xin, return_cov=False)              # Emulator.predict slabs the same way
+    assert mean.shape == (W, emu.nobs)
+    assert np.array_equal(mean[-60:], emu.predict(Xin[-60:], return_cov=False))
+    m2, c2 = emu.predict(Xin[:40], return_cov=True, extra_std=0.0)
+    assert np.array_equal(m2, mean[:40]) and c2.shape == (40, emu.nobs, emu.nobs)
