@@ -576,10 +576,8 @@ extern "C" int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles
     return 0;
 }
 
-// key: 0 = XCD affinity (-1 auto, 0 by walker tile, 1 by row block); 1 = persistent 64-tile workgroups per CU;
-//      2 = waves per predict tile (4 or 8); 3 = persistent workgroups per CU of the 128-tile 8-wave variant;
-//      4 = outer Cholesky panel width;
-//      6 = persistent 64x32-tile workgroups per CU; 7 = largest padded batch that uses 64x32 tiles
+// Launch-geometry knobs (never change a result); the key list is documented with the declaration in
+// include/gpbayes.h and mirrored by GPEngine.tune() in engine.py.
 extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
     if (!ctx) return GPB_E_ARG;
     switch (key) {
