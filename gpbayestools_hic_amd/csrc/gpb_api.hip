@@ -581,7 +581,7 @@ extern "C" int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles
 extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
     if (!ctx) return GPB_E_ARG;
     switch (key) {
-        case 0: if (value < -1 || value > 2) return GPB_E_ARG; ctx->force_xcd = value; break;
+        case 0: if (value < -1 || value > 3) return GPB_E_ARG; ctx->force_xcd = value; break;
         case 1: if (value < 1 || value > 8) return GPB_E_ARG; ctx->wgs_per_cu64 = value; break;
         case 2: if (value != 4 && value != 8) return GPB_E_ARG; ctx->predict_waves = value; break;
         case 3: if (value < 1 || value > 4) return GPB_E_ARG; ctx->wgs_per_cu128w8 = value; break;

@@ -182,9 +182,42 @@ __device__ __forceinline__ void predict_tile(TileLds<T, TN, KB>& lds, int p, int
     }
 }
 
+// xcd_mode 3: "super-blocks" = (GP, group of 4 consecutive row blocks) x all walker tiles, heaviest groups first,
+// dealt round-robin to the eight queues.  With 2 x 32 resident 128x128 workgroups an XCD has about one
+// super-block in flight: its tiles share 4 L^-1 row panels and nW K*^T column panels through that XCD's L2.
+__device__ __forceinline__ unsigned superblock_queue_len(unsigned qx, int nI, int nW, int P) {
+    const int nG = (nI + 3) / 4;
+    unsigned n = 0;
+    for (int r = 0; 8 * r < nG * P; ++r) {
+        const int s = 8 * r + ((r & 1) ? 7 - (int)qx : (int)qx);     // snake deal: balanced queue totals
+        if (s >= nG * P) continue;
+        const int c = s / P, rows = (nI - 4 * c < 4) ? nI - 4 * c : 4;
+        n += (unsigned)(rows * nW);
+    }
+    return n;
+}
+
 // ticket t of queue qx -> tile (GP p, row block ib, walker tile wt); false for the padding of xcd_mode 1
 __device__ __forceinline__ bool decode_tile(int xcd_mode, unsigned t, unsigned qx, int nI, int nW, int P, int& p,
                                             int& ib, int& wt) {
+    if (xcd_mode == 3) {
+        const int nG = (nI + 3) / 4;
+        unsigned u = t;
+        for (int r = 0; 8 * r < nG * P; ++r) {
+            const int s = 8 * r + ((r & 1) ? 7 - (int)qx : (int)qx);
+            if (s >= nG * P) continue;
+            const int c = s / P, rows = (nI - 4 * c < 4) ? nI - 4 * c : 4;
+            const unsigned cnt = (unsigned)(rows * nW);
+            if (u < cnt) {
+                p = s - c * P;
+                ib = nI - 1 - 4 * c - (int)(u / (unsigned)nW);
+                wt = (int)(u % (unsigned)nW);
+                return true;
+            }
+            u -= cnt;
+        }
+        return false;
+    }
     if (xcd_mode == 2) {
         const int j = (int)t / (nI * nW), rem = (int)t - j * (nI * nW);
         p = (int)qx + 8 * j;
@@ -232,12 +265,15 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (T == 64 && TN 
     //   1: queue = (row block, GP) group % 8   (small W: each L^-1 row block is fetched by one XCD)
     //   2: queue = GP % 8: an XCD works through ONE GP at a time, so the ~64 tiles it has in flight share
     //      4 L^-1 row panels and 16 K*^T column panels instead of ~32 + ~20 (L2 hit rate, fabric traffic)
+    //   3: queue = super-block % 8 (GP x group of 4 row blocks, heaviest groups first): the same sharing, dealt
+    //      out at a quarter of a GP so that the queues stay balanced
     const int x = blockIdx.x & 7;
     for (int s = 0; s < 8; ++s) {
         const unsigned qx = (unsigned)((x + s) & 7);
         unsigned nq;
-        if (xcd_mode == 2) nq = ((unsigned)P > qx) ? (((unsigned)P - qx + 7u) / 8u) * (unsigned)(nI * nW) : 0u;
-        else               nq = (nblocks > qx) ? (nblocks - qx + 7u) / 8u : 0u;
+        if (xcd_mode == 3)      nq = superblock_queue_len(qx, nI, nW, P);
+        else if (xcd_mode == 2) nq = ((unsigned)P > qx) ? (((unsigned)P - qx + 7u) / 8u) * (unsigned)(nI * nW) : 0u;
+        else                    nq = (nblocks > qx) ? (nblocks - qx + 7u) / 8u : 0u;
         for (;;) {
             if (threadIdx.x == 0) s_ticket = atomicAdd(&queue[qx * 16], 1u);
             __syncthreads();
@@ -394,7 +430,7 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
         // 128x128: 2, 64x64: 7, 64x32: 8.
         int occ = (T == 128) ? 2 : (TN == 32 ? 8 : 7);
         if (ctx->resident_occ > 0) occ = ctx->resident_occ;
-        const int resident = (nblocks <= (int64_t)ctx->num_cu * occ && nwv == 4 && xcd_rows != 2)
+        const int resident = (nblocks <= (int64_t)ctx->num_cu * occ && nwv == 4 && xcd_rows < 2)
                                  ? ctx->resident_order : 0;
         const unsigned grid = (unsigned)((resident || nblocks < slots) ? nblocks : slots);
 #define GPB_PRED(TT, WW, NN, KK)                                                                                 \

@@ -202,7 +202,8 @@ int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K,
  * uses them. */
 int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
 /* tuning hook for launch geometry (never changes results): key 0 = XCD affinity of the predict kernel
- * (-1 auto, 0 by walker tile, 1 by row block, 2 by GP); 1 = persistent 64-tile workgroups per CU;
+ * (-1 auto, 0 by walker tile, 1 by row block, 2 by GP, 3 by (GP, four row blocks) super-block: least
+ * fabric traffic); 1 = persistent 64-tile workgroups per CU;
  * 2 = waves per tile (4 or 8); 3 = persistent workgroups per CU of the 128-tile 8-wave variant;
  * 4 = outer panel width of the blocked Cholesky; 5 = tile order when every predict tile has its own
  * co-resident workgroup (0 ticket queues, 1 sorted, 2 snake over the CUs, 3 snake of pairs);

@@ -242,7 +242,7 @@ def test_predict_tile_sizes_are_bit_identical(eng):
             m2, v2 = eng.predict(Xs)
             assert np.array_equal(m1, m2) and np.array_equal(v1, v2), (tile, waves)
         eng.tune("waves", 4)
-        for xcd in (0, 1, 2):                             # tile -> XCD queue maps only reorder the work
+        for xcd in (0, 1, 2, 3):                          # tile -> XCD queue maps only reorder the work
             eng.tune("xcd", xcd)
             for tile in (64, 128, 32):                    # 32 = 64 rows x 32 walkers
                 eng.force_tile(tile)
