@@ -570,7 +570,7 @@ extern "C" int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K, cons
 }
 
 extern "C" int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles) {
-    if (!ctx || (tile != 0 && tile != 32 && tile != 64 && tile != 128)) return GPB_E_ARG;   // 32 = 64 rows x 32 walkers
+    if (!ctx || (tile != 0 && tile != 32 && tile != 64 && tile != 65 && tile != 128)) return GPB_E_ARG;   // 32 = 64 rows x 32 walkers, 65 = 64 x 128
     ctx->force_tile = tile;
     if (switch_tiles > 0) ctx->tile_switch = switch_tiles;
     return 0;
@@ -595,6 +595,7 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 11: if (value < 0 || value > 1) return GPB_E_ARG; ctx->fuse_finalize = value; break;
         case 12: if (value != 0 && value != 64 && value != 128) return GPB_E_ARG; ctx->trtri_tile = value; break;
         case 14: if (value != 0 && value != 64 && value != 128) return GPB_E_ARG; ctx->syrk_tile = value; break;
+        case 16: if (value < 1 || value > 8) return GPB_E_ARG; ctx->wgs_per_cu64x128 = value; break;
         case 13: if (value < 0 || value > 16) return GPB_E_ARG; ctx->resident_occ = value; break;
         default: return GPB_E_ARG;
     }

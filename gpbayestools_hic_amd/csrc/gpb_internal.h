@@ -81,6 +81,7 @@ struct gpb_ctx {
     int wgs_per_cu64 = 7;           // persistent k_predict<64> workgroups per CU (6 resident at 80 VGPRs; 7 measured 1-2 % better)
     int wgs_per_cu128w8 = 2;        // ... for the 128-tile, 8-wave variant
     int wgs_per_cu32 = 4;           // ... for the 64x32 tile
+    int wgs_per_cu64x128 = 5;       // ... for the 64x128 tile (4 resident at 128 VGPRs)
     int64_t narrow_switch = 128;    // padded walker batches up to this size use 64x32 tiles (0 = never)
     int predict_waves = 4;          // waves per k_predict tile (4 or 8)
     unsigned* tile_counter = nullptr;   // 8 ticket queues (stride 16) + done counter [128]; re-armed by the kernel
@@ -94,7 +95,8 @@ struct gpb_ctx {
     int tile_priority = 1;         // k_predict: wave priority by K-loop length (s_setprio)
     int force_tile = 0;           // test hook: 0 = auto, 64 / 128 / 32 (= 64x32) force the k_predict tile
     int force_xcd = -1;             // tuning hook: -1 auto, 0 / 1 = k_predict XCD affinity by walker tile / row block
-    int64_t tile_switch = 900;      // use 128x128 tiles when at least this many of them exist (measured crossover)
+    int64_t tile_switch = 2560;     // use 128x128 tiles when at least this many of them exist (measured crossover)
+    int64_t mid_switch = 900;       // else 64x128 tiles when at least this many of THEM exist, else 64x64
     bool force_generic_mvn = false; // test hook: bypass the register-resident MVN fast path
     int fuse_finalize = 1;          // block log-likelihood kernels sum the predict partials themselves (P <= 32)
     int64_t mvn_wg_switch = 768;   // batches up to this size use one workgroup per walker (32 < M <= 64)

@@ -402,13 +402,18 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
     if (need_var) {
         // 128-wide tiles when they fill the chip several times over, 64-wide for small walker batches
         const int64_t tiles128 = ctx->P * ((ctx->Np + 127) / 128) * (Wuse / 128);
-        // T rows x TN walkers per tile: 128x128, 64x64, or 64x32 ("32") for the smallest batches, where the
-        // heaviest tile's serial K loop (one wave issues an f64 MFMA every ~138 cycles) is the critical path
-        int T = (tiles128 >= ctx->tile_switch) ? 128 : 64;
-        int TN = T;
-        if (T == 64 && Wuse <= ctx->narrow_switch) TN = 32;
+        // T rows x TN walkers per tile, by how many tiles there are to fill the chip with (measured crossovers,
+        // cfg 3 and cfg 4 sweeps): 128x128 (2 per CU, 64 MFMAs per wave between barriers) for the big batches;
+        // 64x128 (4-5 per CU, 32 MFMAs) in between; 64x64 (6-7 per CU, 16 MFMAs) for a rank's small shard, where
+        // the heaviest tile's serial K loop is the critical path; 64x32 ("32") below 128 walkers.
+        const int64_t tiles64x128 = ctx->P * nI64 * (Wuse / 128);
+        int T = 64, TN = 64;
+        if (tiles128 >= ctx->tile_switch) T = TN = 128;
+        else if (tiles64x128 >= ctx->mid_switch) TN = 128;
+        else if (Wuse <= ctx->narrow_switch) TN = 32;
         if (ctx->force_tile == 64 || ctx->force_tile == 128) T = TN = ctx->force_tile;
         if (ctx->force_tile == 32) { T = 64; TN = 32; }
+        if (ctx->force_tile == 65) { T = 64; TN = 128; }        // 64 rows x 128 walkers
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (ctx->profile) {                    // live HIP-event timing of the dominant kernel (bench.py)
             GPB_HIP(hipEventCreate(&e0));
@@ -423,12 +428,12 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
         const int64_t nblocks = (xcd_rows == 1) ? ((ngroups + 7) / 8) * 8 * nW : ngroups * nW;
         const int nwv = ctx->predict_waves;             // 4 or 8 waves per tile
         const int per_cu = (T == 128) ? (nwv == 8 ? ctx->wgs_per_cu128w8 : 2)
-                                      : (TN == 32 ? ctx->wgs_per_cu32 : ctx->wgs_per_cu64);
+                                      : (TN == 32 ? ctx->wgs_per_cu32 : (TN == 128 ? ctx->wgs_per_cu64x128 : ctx->wgs_per_cu64));
         const int64_t slots = (int64_t)ctx->num_cu * per_cu;
         // one workgroup per tile and all of them co-resident: nothing is left to balance dynamically, so a static
         // kernel deals the tiles out instead.  Co-residency per CU of k_predict_static (its VGPRs / LDS):
         // 128x128: 2, 64x64: 7, 64x32: 8.
-        int occ = (T == 128) ? 2 : (TN == 32 ? 8 : 7);
+        int occ = (T == 128) ? 2 : (TN == 32 ? 8 : (TN == 128 ? 4 : 7));
         if (ctx->resident_occ > 0) occ = ctx->resident_occ;
         const int resident = (nblocks <= (int64_t)ctx->num_cu * occ && nwv == 4 && xcd_rows < 2)
                                  ? ctx->resident_order : 0;
@@ -448,6 +453,7 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
         // (32-deep K-steps for the 64-row tiles were measured: within 2.5 % either way, not kept)
         if (T == 128)      { if (nwv == 8) GPB_PRED(128, 8, 128, 16); else GPB_PRED(128, 4, 128, 16); }
         else if (TN == 32) GPB_PRED(64, 4, 32, 16);
+        else if (TN == 128) GPB_PRED(64, 4, 128, 16);
         else if (nwv == 8) GPB_PRED(64, 8, 64, 16);
         else               GPB_PRED(64, 4, 64, 16);
 #undef GPB_PRED

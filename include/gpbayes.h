@@ -198,8 +198,8 @@ int gpb_dist_finalize(gpb_ctx* ctx);
 int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K,
                   const double* A_host, const double* B_host, double* C_host, int b_trans);
 /* test/tuning hook: force the tile of the predict kernel (0 = automatic, 64, 128, 32 = 64 rows x 32
- * walkers) and, when switch_tiles > 0, the number of 128x128 tiles from which the automatic choice
- * uses them. */
+ * walkers, 65 = 64 rows x 128 walkers) and, when switch_tiles > 0, the number of 128x128 tiles from
+ * which the automatic choice uses them. */
 int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
 /* tuning hook for launch geometry (never changes results): key 0 = XCD affinity of the predict kernel
  * (-1 auto, 0 by walker tile, 1 by row block, 2 by GP, 3 by (GP, four row blocks) super-block: least

@@ -244,7 +244,7 @@ def test_predict_tile_sizes_are_bit_identical(eng):
         eng.tune("waves", 4)
         for xcd in (0, 1, 2, 3):                          # tile -> XCD queue maps only reorder the work
             eng.tune("xcd", xcd)
-            for tile in (64, 128, 32):                    # 32 = 64 rows x 32 walkers
+            for tile in (64, 128, 32, 65):                # 32 = 64 rows x 32 walkers, 65 = 64 x 128
                 eng.force_tile(tile)
                 for order in (0, 1, 2, 3):                # ticket queues / static orders of a resident grid
                     eng.tune("resident", order)
