@@ -51,6 +51,38 @@ def test_tiny_and_ragged_shapes(N, d, P, M, W, kind):
     eng.close()
 
 
+@pytest.mark.parametrize("kind", ["RBF", "Matern15", "Matern25"])
+@pytest.mark.parametrize("c,ell,noise", [
+    (1.0, 0.05, 1e-2),      # length scale far below the design spacing: K ~ diagonal
+    (1.0, 20.0, 1e-2),      # nearly constant kernel: K close to rank one, variance by heavy cancellation
+    (1e2, 1.0, 1e-6),       # sklearn's lower noise bound region, large amplitude
+    (1e-3, 0.5, 1.0),       # noise dominated
+    (1.0, 0.3, 1e-8),
+])
+def test_hyperparameters_at_the_edges_of_the_search_box(kind, c, ell, noise):
+    """The optimiser of fit() visits the corners of the bounds (src/emulator.py:254-262); parity has to
+    hold there as well, including where the predictive variance is a small difference of large terms."""
+    from gpbayestools_hic_amd import GPEngine, synth
+    from oracle import gp_oracle as O
+    N, d, W = 300, 6, 200
+    rng = np.random.default_rng(0)
+    X = synth.lhs(N, d, seed=2); Xs = rng.random((W, d))
+    z = np.sin(X @ rng.standard_normal(d))
+    th = np.concatenate([[np.log(c)], np.log(np.full(d, ell)), [np.log(noise)]])
+    eng = GPEngine(0)
+    eng.set_data(X, z[None, :], kind, 0.1); eng.set_theta(th[None, :]); eng.factor()
+    m, v = eng.predict(Xs)
+    L, a = O.gp_factor(X, z, th, O.KIND_NAMES[kind], 0.1)
+    mo, vo = O.gp_predict(Xs, X, th, L, a, O.KIND_NAMES[kind])
+    assert np.max(np.abs(m[:, 0] - mo)) <= 1e-11 * np.max(np.abs(mo))
+    assert np.max(np.abs(v[:, 0] - vo) / np.abs(vo)) < 1e-10      # element-wise, not norm-wise
+    val, grad = eng.lml(th[None, :])
+    vo_, go_ = O.lml(th, X, z, O.KIND_NAMES[kind], 0.1, eval_gradient=True)
+    assert abs(val[0] - vo_) <= 1e-10 * abs(vo_)
+    assert np.max(np.abs(grad[0] - go_)) <= 1e-9 * max(np.max(np.abs(go_)), 1.0)
+    eng.close()
+
+
 def test_argument_errors_are_reported_not_crashes():
     from gpbayestools_hic_amd import GPEngine
     from gpbayestools_hic_amd._native import GPBError
