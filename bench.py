@@ -38,16 +38,20 @@ def cpu_baseline(info, emu, nrows):
     Xw = synth.walkers(nrows, d, seed=synth.SEED + 7)
     yexp = info["yexp"]
     cexp = np.diag((0.05 * np.abs(yexp)) ** 2)
-    t0 = time.time()
-    lp = O.log_prob(Xw, info["lo"], info["hi"], lambda x, e: oe.predict(x, True, e, faithful=True), yexp, cexp,
-                    batched=False)
-    dt = time.time() - t0
+    calls, t0 = 0, time.time()
+    while True:            # whole half-ensemble calls until ~10 s of host work have been timed (at most 8 calls)
+        lp = O.log_prob(Xw, info["lo"], info["hi"], lambda x, e: oe.predict(x, True, e, faithful=True), yexp, cexp,
+                        batched=False)
+        calls += 1
+        dt = time.time() - t0
+        if dt >= 10.0 or calls >= 8:
+            break
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         cores = os.cpu_count()
-    return {"value": nrows / dt, "unit": "walker-evals/s", "cores": cores, "kind": "port",
-            "sample": f"one half-ensemble log_posterior call of {nrows} rows (faithful W x W covariance "
+    return {"value": nrows * calls / dt, "unit": "walker-evals/s", "cores": cores, "kind": "port",
+            "sample": f"{calls} half-ensemble log_posterior call(s) of {nrows} rows each (faithful W x W covariance "
                       f"per GP + per-row LAPACK MVN), {dt:.1f} s, numpy/scipy threaded BLAS"}, lp, Xw
 
 

@@ -87,3 +87,37 @@ class WalkerSharding:
         self.dist.all_gather_into_tensor(gathered, local, group=self.group)
         out.copy_(gathered[:W])
         return out
+
+
+class GPSharding:
+    """Fit-side sharding: the npc GPs of an emulator are independent until prediction, so their
+    hyper-parameter searches — the wall-time of trainEmulator, src/emulator.py:309-315 — are dealt round-robin
+    to the ranks (GP p -> rank p % world).  One object all-gather of (indices, theta, LML) afterwards; every rank
+    then factorises all GPs at the gathered theta (3.7 ms at cfg 4, cheaper than broadcasting L and L^-1).
+    Collective: every rank of the group must call Emulator.trainEmulator."""
+
+    def __init__(self, rank=None, world=None, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+
+    def mine(self, P):
+        import numpy as np
+        return np.arange(self.rank, P, self.world)
+
+    def gather(self, P, idx, theta, val):
+        """theta[P,k], val[P] on every rank from each rank's (idx, theta[len(idx),k], val[len(idx)])."""
+        import numpy as np
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, (np.asarray(idx), np.asarray(theta), np.asarray(val)), group=self.group)
+        k = next(t.shape[1] for _, t, _ in parts if t.ndim == 2 and t.shape[0])
+        theta_all, val_all = np.empty((P, k)), np.empty(P)
+        seen = np.zeros(P, dtype=bool)
+        for i, t, v in parts:
+            theta_all[i], val_all[i] = t.reshape(-1, k), v
+            seen[i] = True
+        if not seen.all():
+            raise RuntimeError("GPSharding.gather: GPs %s were not searched by any rank" % np.flatnonzero(~seen))
+        return theta_all, val_all

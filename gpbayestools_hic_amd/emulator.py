@@ -115,6 +115,7 @@ class Emulator:
         self.alpha = 0.1                      # GPR(alpha=0.1), src/emulator.py:310
         self._engine = None
         self._trained = False
+        self.fit_sharding = None              # dist.GPSharding: deal the npc hyper-parameter searches to the ranks
         if self.parameterTrafoPCA_:
             from .param_pca import ParameterPCA
             self._ppca = ParameterPCA(self.design_points, self.design_min, self.design_max)
@@ -239,19 +240,16 @@ class Emulator:
         """argmax LML per GP with scipy L-BFGS-B (sk:_gpr.py:296-337,654-670).  The P searches
         are independent; they run in lock-step threads so that every objective call is ONE
         batched device evaluation of all P log-marginal likelihoods and gradients."""
-        P = self._ngp
         theta0, bounds = self._theta0_bounds(kernel_type)
-        starts = [np.tile(theta0, (P, 1))]
-        rng = np.random.default_rng()
-        for _ in range(int(self.nrestarts)):
-            starts.append(rng.uniform(bounds[:, 0], bounds[:, 1], size=(P, theta0.size)))
-        best_theta = np.tile(theta0, (P, 1))
-        best_val = np.full(P, np.inf)
-        for start in starts:
-            th, val = _batched_lbfgsb(eng, start, bounds)
-            better = val < best_val
-            best_theta[better], best_val[better] = th[better], val[better]
-        return best_theta, -best_val
+        sh = self.fit_sharding
+        if sh is None or sh.world == 1:
+            return search_hyperparameters(lambda idx: eng, self._ngp, theta0, bounds, self.nrestarts)
+
+        def sub_engine(idx):            # this rank's GPs only: same design, a subset of the target rows
+            sub = GPEngine(self.device)
+            sub.set_data(self._X_train, self._Z_train[idx], _KERNELS[kernel_type][0], self.alpha)
+            return sub
+        return search_hyperparameters(sub_engine, self._ngp, theta0, bounds, self.nrestarts, sh, close=True)
 
     def _build_transform(self):
         if self.perform_no_PCA_:
@@ -301,11 +299,13 @@ class Emulator:
         st = dict(self.__dict__)
         st["_engine"] = None
         st["_like_key"] = None
+        st["fit_sharding"] = None
         st.pop("gps", None)
         return st
 
     def __setstate__(self, st):
         self.__dict__.update(st)
+        self.__dict__.setdefault("fit_sharding", None)
         if self._trained:
             self.gps = [FittedGP(self, i) for i in range(self._ngp)]
 
@@ -391,6 +391,35 @@ class Emulator:
     def testEmulatorErrorsWithTrainingPoints(self, nTestPoints=1):
         """Same split, but predict the training points themselves (src/emulator.py:682-726)."""
         return self._holdout(nTestPoints, on_training=True)
+
+
+def search_hyperparameters(make_engine, P, theta0, bounds, nrestarts=0, sharding=None, close=False, rng=None):
+    """theta*[P, d+2] and LML*[P]: L-BFGS-B from `theta0` plus `nrestarts` log-uniform starts per GP
+    (sk:_gpr.py:296-337).  `make_engine(idx)` returns an object whose `.lml(theta[len(idx), d+2],
+    eval_gradient=True)` serves the GPs `idx`.  With `sharding` (dist.GPSharding, SURVEY §8e "fit-side") the
+    P searches are dealt round-robin to the ranks and ONE all-gather puts every result on every rank; a GP's
+    search does not depend on which other GPs share its batch, so the result is the unsharded one."""
+    idx = np.arange(P) if sharding is None else sharding.mine(P)
+    k = theta0.size
+    best_theta = np.tile(theta0, (idx.size, 1))
+    best_val = np.full(idx.size, np.inf)
+    if idx.size:
+        eng = make_engine(idx)
+        try:
+            starts = [np.tile(theta0, (idx.size, 1))]
+            rng = rng if rng is not None else np.random.default_rng()
+            for _ in range(int(nrestarts)):
+                starts.append(rng.uniform(bounds[:, 0], bounds[:, 1], size=(idx.size, k)))
+            for start in starts:
+                th, val = _batched_lbfgsb(eng, start, bounds)
+                better = val < best_val
+                best_theta[better], best_val[better] = th[better], val[better]
+        finally:
+            if close:
+                eng.close()
+    if sharding is None:
+        return best_theta, -best_val
+    return sharding.gather(P, idx, best_theta, -best_val)
 
 
 def _batched_lbfgsb(eng, start, bounds):

@@ -86,3 +86,69 @@ def test_rows_partition():
                 assert 0 <= r0 <= r1 <= W and r1 - r0 <= chunk
                 seen += list(range(r0, r1))
             assert seen == list(range(W))
+
+
+# ---------------------------------------------------------------- fit-side sharding (dist.GPSharding)
+class _OracleLMLEngine:
+    """Stands in for GPEngine.lml on the CPU tier: batched LML and gradient from the oracle."""
+
+    def __init__(self, X, Z):
+        self.X, self.Z = X, Z
+
+    def lml(self, theta, eval_gradient=True):
+        from oracle import gp_oracle as O
+        out = [O.lml(theta[p], self.X, self.Z[p], O.KIND_RBF, 0.1, eval_gradient=True) for p in range(len(self.Z))]
+        return np.array([o[0] for o in out]), np.array([o[1] for o in out])
+
+    def close(self):
+        pass
+
+
+def _fit_problem(P):
+    from oracle import gp_oracle as O
+    rng = np.random.default_rng(11)
+    N, d = 40, 3
+    X = rng.random((N, d))
+    Z = np.array([np.sin(X @ rng.standard_normal(d)) + 0.05 * rng.standard_normal(N) for _ in range(P)])
+    theta0, bounds = O.default_theta0_bounds(np.zeros(d), np.ones(d), O.KIND_RBF)
+    return X, Z, np.asarray(theta0), np.asarray(bounds)
+
+
+def _fit_worker(rank, world, port, q):
+    sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from gpbayestools_hic_amd.dist import GPSharding, init_from_env
+    from gpbayestools_hic_amd.emulator import search_hyperparameters
+    init_from_env(backend="gloo")
+    res = {}
+    for P in (3, 1):                            # 3 GPs over 2 ranks; 1 GP: rank 1 has nothing to search
+        X, Z, theta0, bounds = _fit_problem(P)
+        sh = GPSharding()
+        served = []
+        th, val = search_hyperparameters(lambda idx: (served.append(list(idx)), _OracleLMLEngine(X, Z[idx]))[1],
+                                         P, theta0, bounds, 0, sh, close=True)
+        res[P] = (th, val, served)
+    dist.barrier()
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_fit_sharding_world2_matches_unsharded():
+    from gpbayestools_hic_amd.emulator import search_hyperparameters
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fit_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for P in (3, 1):
+        X, Z, theta0, bounds = _fit_problem(P)
+        th, val = search_hyperparameters(lambda idx: _OracleLMLEngine(X, Z[idx]), P, theta0, bounds, 0)
+        assert np.all(np.isfinite(val)) and not np.allclose(th, theta0)          # the search moved
+        for rank in range(world):
+            assert np.array_equal(got[rank][P][0], th) and np.array_equal(got[rank][P][1], val), (rank, P)
+        assert got[0][P][2] == [list(range(0, P, 2))]
+        assert got[1][P][2] == ([[1]] if P == 3 else [])
