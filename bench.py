@@ -128,6 +128,11 @@ def main():
     sampler = StretchSampler(chain, nwalkers, seed=12345, sharding=sharding, device=local)
     X0 = synth.walkers(nwalkers, d)
     eng = emu._engine_ready()
+    direct_why = None
+    if sharding is not None and dist.get_backend() == "nccl" and os.environ.get("GPB_DIST_DIRECT", "1") != "0":
+        # ncclAllGather from the C ABI on the kernels' own stream (8 us less per collective than the hop through
+        # torch's communicator stream); self-checked against torch.distributed, which stays the exchange if not.
+        direct_why = sharding.try_direct(eng)
 
     def barrier():
         torch.cuda.synchronize()
@@ -169,7 +174,11 @@ def main():
             "config": {"workload": f"BASELINE config {args.config}: {N} design pts x {d} params x {M} observables, "
                                    f"{P} GPs ({info['kernel']}), {nwalkers} walkers, stretch move, "
                                    f"fixed hyper-parameters", "walkers": nwalkers,
-                       "parallelism": f"walker-shard x{world}" if world > 1 else "single GPU"},
+                       "parallelism": f"walker-shard x{world}" if world > 1 else "single GPU",
+                       "allgather": None if world == 1 else (
+                           "gpb_dist_allgather (ncclAllGather on the kernel stream)" if sharding.direct is not None
+                           else "torch.distributed " + dist.get_backend()
+                                + (" (direct path not used: %s)" % direct_why if direct_why else ""))},
             "acceptance_fraction": acc, "ranks_hold_identical_ensemble": consistent,
             "gflop_per_step_algorithmic": flops_per_walker(N, d, P, M, info["kernel"]) * nwalkers / 1e9,
             "roofline": {"bound": "mfma", "kernel": "k_predict (V = L^-1 K*^T, fused sum of squares)",

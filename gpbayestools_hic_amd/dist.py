@@ -5,9 +5,10 @@ rows [r*chunk, (r+1)*chunk) of each log-probability batch and ONE all-gather of 
 per rank puts the complete log-probability vector on every rank.  There is no other exchange:
 proposals and accept draws are regenerated identically everywhere (sampler.py).
 
-The collective goes through torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo"
-on CPU for tests), enqueued on the same stream as the kernels — no host synchronisation.  The
-payload is 2-16 KB, so the step is latency-bound, not link-bound.
+The collective is RCCL over xGMI: either torch.distributed's (backend "nccl"; "gloo" on CPU for tests) or,
+after WalkerSharding.try_direct, the C ABI's own communicator (gpb_dist_allgather: ncclAllGather enqueued on
+the very stream the kernels run on — measured 8 us less per collective than the hop through torch's
+communicator stream).  No host synchronisation either way.  The payload is 2-16 KB: latency-bound.
 """
 import os
 
@@ -45,6 +46,49 @@ class WalkerSharding:
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self._buf = {}
+        self.direct = None
+
+    def enable_direct(self, engine):
+        """Route the all-gather through the C ABI's own RCCL communicator (gpb_dist_*: ncclAllGather enqueued
+        directly on the kernels' stream, no second stream and no event hops).  Collective: rank 0 creates the
+        ncclUniqueId, torch.distributed carries it to the others.  bench.py goes through try_direct (below)."""
+        box = [engine.dist_uid() if self.rank == 0 else None]
+        self.dist.broadcast_object_list(box, src=0, group=self.group)
+        engine.dist_init(self.rank, self.world, box[0])
+        self.direct = engine
+        return self
+
+    def try_direct(self, engine):
+        """enable_direct + a self-check against torch.distributed's all-gather on a test vector; every rank
+        keeps the direct path only if it worked on ALL ranks.  Returns None when direct is on, else the reason
+        (the exchange then stays on torch.distributed — both are RCCL, nothing leaves the GPUs)."""
+        import torch
+        why = None
+        try:
+            self.enable_direct(engine)
+            n, dev = 64, torch.device("cuda", torch.cuda.current_device())
+            mine = torch.arange(n, dtype=torch.float64, device=dev) + 1000.0 * self.rank
+            ref = torch.empty(n * self.world, dtype=torch.float64, device=dev)
+            self.dist.all_gather_into_tensor(ref, mine, group=self.group)
+            got = torch.full_like(ref, -1.0)
+            got[self.rank * n:(self.rank + 1) * n] = mine
+            engine.dist_allgather(got[self.rank * n:(self.rank + 1) * n], got)
+            torch.cuda.synchronize()
+            if not torch.equal(ref, got):
+                why = "direct all-gather disagrees with torch.distributed"
+        except Exception as e:      # missing librccl, ncclCommInitRank refused, ...
+            why = "%s: %s" % (type(e).__name__, e)
+        ok = torch.tensor([0 if why else 1], dtype=torch.int32, device="cuda")
+        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 0:
+            if self.direct is not None:
+                try:
+                    self.direct.dist_finalize()
+                except Exception:
+                    pass
+            self.direct = None
+            return why or "direct path failed on another rank"
+        return None
 
     def rows(self, W):
         """(r0, r1, chunk): this rank's row range of a W-row batch; chunk = ceil(W / world)."""
@@ -67,12 +111,15 @@ class WalkerSharding:
             self.dist.all_gather_into_tensor(gathered, local.cpu(), group=self.group)
             out.copy_(gathered[:W])
             return out
-        if self.world > 1 and W == chunk * self.world and out.is_contiguous():
+        if (self.world > 1 or self.direct is not None) and W == chunk * self.world and out.is_contiguous():
             # even split: every rank writes its slice of `out` and the all-gather runs in place
             # (send buffer = receive buffer + rank*chunk) — no staging copies on the step's critical path
             mine = out[r0:r1]
             fn(X[r0:r1], mine)
-            self.dist.all_gather_into_tensor(out, mine, group=self.group)
+            if self.direct is not None and out.is_cuda:
+                self.direct.dist_allgather(mine, out)
+            else:
+                self.dist.all_gather_into_tensor(out, mine, group=self.group)
             return out
         key = (chunk, X.device, out.dtype)
         if key not in self._buf:
@@ -84,7 +131,10 @@ class WalkerSharding:
         if self.world == 1:
             out.copy_(local[:W])
             return out
-        self.dist.all_gather_into_tensor(gathered, local, group=self.group)
+        if self.direct is not None and X.is_cuda:
+            self.direct.dist_allgather(local, gathered)
+        else:
+            self.dist.all_gather_into_tensor(gathered, local, group=self.group)
         out.copy_(gathered[:W])
         return out
 

@@ -286,6 +286,35 @@ class GPEngine:
         self._ck(self.lib.gpb_debug_tile_trace_read(self.h, nat.ptr(rec), self._trace_cap, C.byref(n)))
         return rec[:n.value]
 
+    # ------------------------------------------------------------------ RCCL without torch.distributed
+    def dist_uid(self):
+        """128-byte ncclUniqueId (rank 0 creates it and hands it to the other ranks out of band)."""
+        uid = np.zeros(128, dtype=np.uint8)
+        self._ck(self.lib.gpb_dist_uid(nat.ptr(uid)))
+        return uid.tobytes()
+
+    def dist_init(self, rank, nranks, uid):
+        buf = np.frombuffer(bytes(uid), dtype=np.uint8).copy()
+        if buf.size != 128:
+            raise ValueError("uid must be the 128 bytes of dist_uid()")
+        self._ck(self.lib.gpb_dist_init(self.h, int(rank), int(nranks), nat.ptr(buf)))
+        self._dist_world = int(nranks)
+
+    def dist_allgather(self, send, recv):
+        """In-stream ncclAllGather of float64 device tensors: recv[r*n:(r+1)*n] = rank r's send[:n]
+        (in place when send is recv[rank*n:(rank+1)*n])."""
+        n = send.numel()
+        if (not send.is_cuda or not recv.is_cuda or send.dtype != recv.dtype or str(send.dtype) != "torch.float64"
+                or not send.is_contiguous() or not recv.is_contiguous()
+                or recv.numel() != n * getattr(self, "_dist_world", 0)):
+            raise ValueError("dist_allgather: contiguous float64 device tensors, recv.numel() == world * send.numel()")
+        self._ck(self.lib.gpb_dist_allgather(self.h, nat.VP(send.data_ptr()), nat.VP(recv.data_ptr()), n))
+        return recv
+
+    def dist_finalize(self):
+        self._ck(self.lib.gpb_dist_finalize(self.h))
+        self._dist_world = 0
+
     def test_gemm(self, A, B, mode=0, tile=128):
         A, B = nat.f64(A), nat.f64(B)
         if mode == 0:

@@ -70,3 +70,71 @@ def test_two_ranks_search_disjoint_gps_and_agree_with_one_rank(tmp_path):
         assert np.array_equal(rth, th), rank
         assert np.array_equal(rlml, lml), rank
         assert np.array_equal(rmean, mean) and np.array_equal(rcov, cov), rank
+
+
+def test_c_abi_rccl_binding_single_rank():
+    """gpb_dist_* (lazy dlopen of librccl, communicator per context, in-stream ncclAllGather) with a one-rank
+    communicator: the only size a one-GPU box can form; more ranks run the same calls."""
+    import torch
+    from gpbayestools_hic_amd import GPEngine
+    eng = GPEngine(0)
+    uid = eng.dist_uid()
+    assert len(uid) == 128 and any(uid)
+    eng.dist_init(0, 1, uid)
+    out = torch.zeros(1000, dtype=torch.float64, device="cuda")
+    src = torch.arange(1000, dtype=torch.float64, device="cuda") * 0.5
+    eng.dist_allgather(src, out)                       # separate buffers
+    torch.cuda.synchronize()
+    assert torch.equal(out, src)
+    out.mul_(3.0)
+    eng.dist_allgather(out[0:1000], out)               # in place (send = recv + rank * count)
+    torch.cuda.synchronize()
+    assert torch.equal(out, src * 3.0)
+    with pytest.raises(ValueError):
+        eng.dist_allgather(src[:10], out)              # recv must hold world * count
+    eng.dist_finalize()
+    eng.close()
+
+
+def _direct_worker(port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch
+    import torch.distributed as dist
+    from gpbayestools_hic_amd import synth
+    from gpbayestools_hic_amd.dist import WalkerSharding
+    from gpbayestools_hic_amd.sampler import StretchSampler
+    from gpbayestools_hic_amd.workload import build_chain
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    chain, emu, info = build_chain(1)
+    X0 = synth.walkers(64, info["d"])
+    plain = StretchSampler(chain, 64, seed=7)
+    plain.run(X0, 20, status=10 ** 9, store=False)
+    sh = WalkerSharding()
+    why = sh.try_direct(emu._engine_ready())
+    sharded = StretchSampler(chain, 64, seed=7, sharding=sh)
+    sharded.run(X0, 20, status=10 ** 9, store=False)
+    # ragged batch (staging buffers) through the same communicator
+    X = torch.as_tensor(synth.walkers(37, info["d"]), device="cuda")
+    a = torch.empty(37, dtype=torch.float64, device="cuda"); b = torch.empty_like(a)
+    fn = lambda Xr, o: chain.log_prob_device(Xr, out=o)
+    fn(X, a); sh.logprob(fn, X, b)
+    torch.cuda.synchronize()
+    q.put((why, sh.direct is not None, bool(torch.equal(plain.pos, sharded.pos)), bool(torch.equal(plain.lp, sharded.lp)),
+           bool(torch.equal(a, b))))
+    dist.destroy_process_group()
+
+
+def test_sampler_over_the_direct_rccl_allgather_one_rank():
+    """bench.py's N>1 exchange (WalkerSharding.try_direct -> gpb_dist_allgather in place on the kernel stream),
+    formed with the one rank a one-GPU box has: self-check passes, the chain equals the unsharded one."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_direct_worker, args=(_free_port(), q))
+    p.start()
+    why, direct_on, same_pos, same_lp, ragged_ok = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert why is None and direct_on
+    assert same_pos and same_lp and ragged_ok
