@@ -14,6 +14,9 @@
 // the heaviest triangular row block; its waves have only 16 MFMAs between the two barriers of a 16-deep K-step
 // (~1300 cycles of synchronisation per ~2200 of issue, profiles/r01_tile_trace.txt).  KB is a template parameter;
 // 32-deep steps for the 64-row tiles were measured within 2.5 % of 16-deep either way and are not instantiated.
+// Triangular operands (L^-1 in predict): gemm_tile_loop<..., TRI> leaves out the 16-row m-tiles of the diagonal
+// block that are all zeros, the same share for every wave (see there) — with two waves per SIMD an MFMA saved in
+// only one of them is an issue slot the other cannot use.
 //
 // v_mfma_f64_16x16x4_f64 lane maps (cdna_hip_programming.md §3):
 //   A: lane l holds A[i=l&15][k=l>>4];  B: lane l holds B[k=l>>4][j=l&15];
@@ -101,7 +104,10 @@ __device__ __forceinline__ void acc_zero(Acc<T, NW, TN>& acc) {
         for (int j = 0; j < (2 * TN / NW) / 16; ++j) acc.v[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 }
 
-template <int T, int NW, int TN, int KB>
+// One K-step of MFMAs from the staged tiles.  The wave's m-tile i (16 rows) starts at row m0 + MS*i of the block
+// tile: MS = 16, m0 = wave row * T/2 for the usual contiguous halves; MS = 32, m0 = wave row * 16 when the two wave
+// rows own the 16-row m-tiles alternately (TRI below).  IMIN > 0 leaves out m-tiles 0..IMIN-1.
+template <int T, int NW, int TN, int KB, int MS = 16, int IMIN = 0>
 __device__ __forceinline__ void tile_mma(const TileLds<T, TN, KB>& L, Acc<T, NW, TN>& acc, int lane, int m0,
                                          int n0) {
     constexpr int NI = T / 32, NJ = (2 * TN / NW) / 16;
@@ -110,11 +116,11 @@ __device__ __forceinline__ void tile_mma(const TileLds<T, TN, KB>& L, Acc<T, NW,
     for (int kk = 0; kk < KB; kk += 4) {
         double a[NI], b[NJ];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) a[i] = L.As[kk + lk][m0 + 16 * i + lr];
+        for (int i = IMIN; i < NI; ++i) a[i] = L.As[kk + lk][m0 + MS * i + lr];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) b[j] = L.Bs[kk + lk][n0 + 16 * j + lr];
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+        for (int i = IMIN; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
                 acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc.v[i][j], 0, 0, 0);
@@ -126,15 +132,25 @@ __device__ __forceinline__ void tile_mma(const TileLds<T, TN, KB>& L, Acc<T, NW,
 //   A_TRANS=false: A[m][k] = Ag[(m_base+m)*lda + k]       A_TRANS=true: A[m][k] = Ag[k*lda + m_base+m]
 //   B_TRANS=false: B[k][n] = Bg[k*ldb + n_base+n]         B_TRANS=true: B[k][n] = Bg[(n_base+n)*ldb + k]
 // m_ext / n_ext (even, <= T) bound the valid rows / columns of this tile; the rest reads as 0.
-template <int T, bool A_TRANS, bool B_TRANS, int NW = 4, int TN = T, int KB = BK, bool FULL = false>
+//
+// TRI: A is lower triangular and k_end - T (= tri_begin) .. k_end is the tile's diagonal block, where the 16-row
+// m-tile g is all zeros from K-step g + 1 of the block on.  To let EVERY wave drop the same share of that work
+// the two wave rows own the m-tiles alternately (wave row r: m-tiles r, r+2, ...; acc.v[i] = m-tile 2i + r): in the
+// q-th pair of diagonal K-steps all of a wave's m-tiles i < q are zero, whichever its row, so the pattern is a
+// compile-time constant per pair and the main loop stays free of control flow.  37.5 % of the diagonal block's
+// MFMAs go (T = 128), the skipped products are exact zeros, the sums are unchanged.  Callers must read acc with
+// the same interleaved map.
+template <int T, bool A_TRANS, bool B_TRANS, int NW = 4, int TN = T, int KB = BK, bool FULL = false, bool TRI = false>
 __device__ __forceinline__ void gemm_tile_loop(const double* __restrict__ Ag, int64_t lda,
                                                const double* __restrict__ Bg, int64_t ldb, int64_t m_base,
                                                int64_t n_base, int m_ext, int n_ext, int64_t k_begin, int64_t k_end,
-                                               TileLds<T, TN, KB>& L, Acc<T, NW, TN>& acc) {
+                                               TileLds<T, TN, KB>& L, Acc<T, NW, TN>& acc, int64_t tri_begin = 0) {
+    static_assert(!TRI || KB == 16, "TRI pairs K-steps of 16 with 16-row m-tiles");
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     constexpr int WN = NW / 2, TNW = TN / WN;   // waves along n, wave tile width
-    const int m0 = (wave / WN) * (T / 2), n0 = (wave % WN) * TNW;
+    constexpr int MS = TRI ? 32 : 16;
+    const int m0 = (wave / WN) * (TRI ? 16 : T / 2), n0 = (wave % WN) * TNW;
     Frag<T, NW, KB> fa;
     Frag<TN, NW, KB> fb;
     if (k_begin < k_end) {
@@ -143,7 +159,8 @@ __device__ __forceinline__ void gemm_tile_loop(const double* __restrict__ Ag, in
         if (B_TRANS) gload_trans<TN, NW, KB, FULL>(Bg, ldb, k_begin, n_base, n_ext, fb, tid);
         else         gload_direct<TN, NW, KB, FULL>(Bg, ldb, k_begin, n_base, n_ext, fb, tid);
     }
-    for (int64_t k0 = k_begin; k0 < k_end; k0 += KB) {
+    // one K-step of the pipeline: publish the prefetched operands in LDS, start the next prefetch
+    auto stage = [&](int64_t k0) {
         __syncthreads();
         if (A_TRANS) lstore_direct<T, NW, KB>(L.As, fa, tid); else lstore_trans<T, NW, KB>(L.As, fa, tid);
         if (B_TRANS) lstore_trans<TN, NW, KB>(L.Bs, fb, tid); else lstore_direct<TN, NW, KB>(L.Bs, fb, tid);
@@ -155,7 +172,25 @@ __device__ __forceinline__ void gemm_tile_loop(const double* __restrict__ Ag, in
             if (B_TRANS) gload_trans<TN, NW, KB, FULL>(Bg, ldb, kn, n_base, n_ext, fb, tid);
             else         gload_direct<TN, NW, KB, FULL>(Bg, ldb, kn, n_base, n_ext, fb, tid);
         }
-        tile_mma<T, NW, TN, KB>(L, acc, lane, m0, n0);
+    };
+    const int64_t k_main = TRI ? (tri_begin < k_end ? tri_begin : k_end) : k_end;
+    int64_t k0 = k_begin;
+    for (; k0 < k_main; k0 += KB) {
+        stage(k0);
+        tile_mma<T, NW, TN, KB, MS>(L, acc, lane, m0, n0);
+    }
+    if constexpr (TRI) {
+        // the diagonal block, two K-steps at a time (its extent is a multiple of 32: Np is one of 64)
+#define GPB_TRI_PAIR(Q)                                                                  \
+        if (Q < T / 32 && k0 < k_end) {                                                  \
+            stage(k0);                                                                   \
+            tile_mma<T, NW, TN, KB, MS, (Q < T / 32 ? Q : 0)>(L, acc, lane, m0, n0);     \
+            stage(k0 + KB);                                                              \
+            tile_mma<T, NW, TN, KB, MS, (Q < T / 32 ? Q : 0)>(L, acc, lane, m0, n0);     \
+            k0 += 2 * KB;                                                                \
+        }
+        GPB_TRI_PAIR(0) GPB_TRI_PAIR(1) GPB_TRI_PAIR(2) GPB_TRI_PAIR(3)
+#undef GPB_TRI_PAIR
     }
 }
 

@@ -592,6 +592,7 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 8: if (value < 0) return GPB_E_ARG; ctx->mvn_wg_switch = value; break;
         case 9: if (value != 64 && value != 128) return GPB_E_ARG; ctx->chol_inner_tile = value; break;
         case 10: if (value < 0 || value > 1) return GPB_E_ARG; ctx->tile_priority = value; break;
+        case 17: if (value < 0 || value > 1) return GPB_E_ARG; ctx->tri_skip = value; break;
         case 11: if (value < 0 || value > 1) return GPB_E_ARG; ctx->fuse_finalize = value; break;
         case 12: if (value != 0 && value != 64 && value != 128) return GPB_E_ARG; ctx->trtri_tile = value; break;
         case 14: if (value != 0 && value != 64 && value != 128) return GPB_E_ARG; ctx->syrk_tile = value; break;

@@ -93,6 +93,7 @@ struct gpb_ctx {
     unsigned* tile_trace = nullptr; // debug hook: [count, capacity, pad x6][capacity][8] records of k_predict tiles
     int resident_occ = 0;          // tuning hook: co-resident workgroups per CU assumed for the static launch (0 = table)
     int tile_priority = 1;         // k_predict: wave priority by K-loop length (s_setprio)
+    int tri_skip = 1;              // k_predict: skip the all-zero half of the diagonal block's second half
     int force_tile = 0;           // test hook: 0 = auto, 64 / 128 / 32 (= 64x32) force the k_predict tile
     int force_xcd = -1;             // tuning hook: -1 auto, 0 / 1 = k_predict XCD affinity by walker tile / row block
     int64_t tile_switch = 2560;     // use 128x128 tiles when at least this many of them exist (measured crossover)

@@ -116,7 +116,8 @@ __device__ __forceinline__ void set_wave_prio(int p) {      // s_setprio takes a
 template <int T, int NW, int TN, int KB>
 __device__ __forceinline__ void predict_tile(TileLds<T, TN, KB>& lds, int p, int ib, int wt, const double* __restrict__ Linv,
                                              const double* __restrict__ KsT, double* __restrict__ spart, int64_t Np,
-                                             int64_t Wld, int P, int prio_levels, unsigned* __restrict__ trace) {
+                                             int64_t Wld, int P, int prio_levels, unsigned* __restrict__ trace,
+                                             int tri_skip = 1) {
     // trace (debug hook, normally null): one record per tile — where and when it ran (tools/gpu_tile_trace.py)
     const unsigned long long trace_t0 = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     constexpr int NI = T / 32, WN = NW / 2, TNW = TN / WN, NJ = TNW / 16;
@@ -130,41 +131,86 @@ __device__ __forceinline__ void predict_tile(TileLds<T, TN, KB>& lds, int p, int
     Acc<T, NW, TN> acc;
     acc_zero<T, NW, TN>(acc);
     // Np is a multiple of 64 and the batch is padded to 128 walkers: 64-row tiles never have an edge
-    gemm_tile_loop<T, false, false, NW, TN, KB, T == 64>(Linv + (int64_t)p * Np * Np, Np,
-                                                         KsT + (int64_t)p * Np * Wld, Wld, mb, nb, m_ext, TN, 0, k_end,
-                                                         lds, acc);
+    // L^-1 is lower triangular: the 128x128 kernel skips the all-zero 16-row m-tiles of the diagonal block
+    // (gemm_tile_loop TRI: the wave rows own the m-tiles alternately, acc.v[i] = m-tile 2i + wave row).
+    constexpr bool TRI = (NW == 4);
+    gemm_tile_loop<T, false, false, NW, TN, KB, T == 64, TRI>(Linv + (int64_t)p * Np * Np, Np,
+                                                              KsT + (int64_t)p * Np * Wld, Wld, mb, nb, m_ext, TN, 0,
+                                                              k_end, lds, acc, tri_skip ? mb : k_end);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    double s[NJ];
+    double* red = &lds.Bs[0][0];                // [2 x 64-row blocks or wave rows][TN columns]
+    if constexpr (TRI) {
+        // Same reduction tree as below (32-row chains over m-tiles (2c, 2c+1), lane groups, two chains per 64-row
+        // block), but a chain's two m-tiles now sit in different wave rows: wave row 0 starts every chain and
+        // hands its per-lane partial to wave row 1 through LDS.
+        double* part = &lds.As[0][0];           // [chain c][j][wn][lane]: 4*4*2*64 doubles = 16 KB of the A tile
+        __syncthreads();                        // all waves are done reading the operand tiles
+        if (wm == 0) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        double h[NI / 2];                       // one chain per 32 rows: m-tiles (2g, 2g+1)
+            for (int c = 0; c < NI; ++c)
 #pragma unroll
-        for (int g = 0; g < NI / 2; ++g) {
-            double v = 0.0;
+                for (int j = 0; j < NJ; ++j) {
+                    double v = 0.0;
 #pragma unroll
-            for (int i = 2 * g; i < 2 * g + 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v = fma(acc.v[i][j][r], acc.v[i][j][r], v);
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            h[g] = v;
+                    for (int r = 0; r < 4; ++r) v = fma(acc.v[c][j][r], acc.v[c][j][r], v);
+                    part[((c * NJ + j) * WN + wn) * 64 + lane] = v;
+                }
         }
-        s[j] = (NI == 4) ? (h[0] + h[NI / 2 - 1]) : h[0];     // T=128: rows 0-31 + rows 32-63 of the wave's block
-    }
-    __syncthreads();                            // all waves are done reading the operand tiles
-    double* red = &lds.As[0][0];                // [2 wave rows][TN columns]
-    if (lane < 16) {
+        __syncthreads();
+        if (wm == 1) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) red[wm * TN + wn * TNW + 16 * j + lane] = s[j];
+            for (int j = 0; j < NJ; ++j) {
+                double h[NI];
+#pragma unroll
+                for (int c = 0; c < NI; ++c) {
+                    double v = part[((c * NJ + j) * WN + wn) * 64 + lane];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v = fma(acc.v[c][j][r], acc.v[c][j][r], v);
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    h[c] = v;
+                }
+                if (lane < 16) {
+                    red[0 * TN + wn * TNW + 16 * j + lane] = h[0] + h[1];            // rows 0-63 of the tile
+                    if (NI == 4) red[1 * TN + wn * TNW + 16 * j + lane] = h[NI - 2] + h[NI - 1];  // rows 64-127
+                }
+            }
+        }
+        __syncthreads();
+    } else {
+        double s[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            double h[NI / 2];                       // one chain per 32 rows: m-tiles (2g, 2g+1)
+#pragma unroll
+            for (int g = 0; g < NI / 2; ++g) {
+                double v = 0.0;
+#pragma unroll
+                for (int i = 2 * g; i < 2 * g + 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v = fma(acc.v[i][j][r], acc.v[i][j][r], v);
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                h[g] = v;
+            }
+            s[j] = (NI == 4) ? (h[0] + h[NI / 2 - 1]) : h[0];     // T=128: rows 0-31 + rows 32-63 of the wave's block
+        }
+        __syncthreads();                            // all waves are done reading the operand tiles
+        if (lane < 16) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) red[wm * TN + wn * TNW + 16 * j + lane] = s[j];
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (T == 128) {                             // each wave row is one 64-row block
+    if (T == 128) {                             // each half of red is one 64-row block
         if (tid < 256) {
             const int half = tid >> 7, col = tid & 127;
             const int64_t blk = 2 * (int64_t)ib + half;
             if (blk * 64 < Np) spart[(blk * P + p) * Wld + nb + col] = red[half * TN + col];
         }
+    } else if (TRI) {                           // one 64-row block, summed by wave row 1 above
+        if (tid < TN) spart[((int64_t)ib * P + p) * Wld + nb + tid] = red[tid];
     } else {                                    // the two wave rows are the halves of one 64-row block
         if (tid < TN) spart[((int64_t)ib * P + p) * Wld + nb + tid] = red[tid] + red[TN + tid];
     }
@@ -249,7 +295,7 @@ template <int T, int NW, int TN, int KB>
 __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (T == 64 && TN == 64 && NW == 4 ? 6 : 4))) void k_predict(const double* __restrict__ Linv, const double* __restrict__ KsT,
                                                      double* __restrict__ spart, int64_t Np, int64_t Wld, int P,
                                                      int nI, int nW, int xcd_mode, unsigned* __restrict__ queue,
-                                                     unsigned nblocks, unsigned* __restrict__ trace) {
+                                                     unsigned nblocks, unsigned* __restrict__ trace, int tri_skip) {
     constexpr int prio_levels = 0;
     __shared__ TileLds<T, TN, KB> lds;
     // The ticket lives in the padding of the last A row (never touched by the loaders, the MFMA fragment reads
@@ -282,7 +328,7 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (T == 64 && TN 
             if (t >= nq) break;                 // uniform: this queue is exhausted
             int p, ib, wt;
             if (!decode_tile(xcd_mode, t, qx, nI, nW, P, p, ib, wt)) continue;   // padding (uniform)
-            predict_tile<T, NW, TN, KB>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace);
+            predict_tile<T, NW, TN, KB>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace, tri_skip);
         }
     }
     // the last workgroup to finish re-arms the queues for the next launch (all others are past their draws)
@@ -305,7 +351,7 @@ template <int T, int NW, int TN, int KB>
 __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (KB == 32 ? 3 : 4))) void k_predict_static(
     const double* __restrict__ Linv, const double* __restrict__ KsT, double* __restrict__ spart, int64_t Np, int64_t Wld,
     int P, int nI, int nW, int xcd_mode, unsigned nblocks, int order, unsigned ncu_x, int prio_levels,
-    unsigned* __restrict__ trace) {
+    unsigned* __restrict__ trace, int tri_skip) {
     __shared__ TileLds<T, TN, KB> lds;
     const unsigned qx = blockIdx.x & 7u;
     const unsigned nq = (nblocks > qx) ? (nblocks - qx + 7u) / 8u : 0u;
@@ -324,7 +370,7 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (KB == 32 ? 3 :
     }
     int p, ib, wt;
     if (decode_tile(xcd_mode, t, qx, nI, nW, P, p, ib, wt))
-        predict_tile<T, NW, TN, KB>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace);
+        predict_tile<T, NW, TN, KB>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace, tri_skip);
 }
 
 __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ mpart, const double* __restrict__ spart,
@@ -432,8 +478,8 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
         const int64_t slots = (int64_t)ctx->num_cu * per_cu;
         // one workgroup per tile and all of them co-resident: nothing is left to balance dynamically, so a static
         // kernel deals the tiles out instead.  Co-residency per CU of k_predict_static (its VGPRs / LDS):
-        // 128x128: 2, 64x64: 7, 64x32: 8.
-        int occ = (T == 128) ? 2 : (TN == 32 ? 8 : (TN == 128 ? 4 : 7));
+        // 128x128: 2, 64x128: 4, 64x64: 6 (80 VGPRs), 64x32: 8.
+        int occ = (T == 128) ? 2 : (TN == 32 ? 8 : (TN == 128 ? 4 : 6));
         if (ctx->resident_occ > 0) occ = ctx->resident_occ;
         const int resident = (nblocks <= (int64_t)ctx->num_cu * occ && nwv == 4 && xcd_rows < 2)
                                  ? ctx->resident_order : 0;
@@ -444,11 +490,11 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
             hipLaunchKernelGGL((k_predict_static<TT, WW, NN, KK>), dim3(grid), dim3(64 * WW), 0, ctx->stream,     \
                                ctx->Linv, ctx->KsT, ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW, xcd_rows, \
                                (unsigned)nblocks, resident, (unsigned)(ctx->num_cu / 8),                          \
-                               ctx->tile_priority ? nI : 0, ctx->tile_trace);                                     \
+                               ctx->tile_priority ? nI : 0, ctx->tile_trace, ctx->tri_skip);                      \
         else                                                                                                     \
             hipLaunchKernelGGL((k_predict<TT, WW, NN, KK>), dim3(grid), dim3(64 * WW), 0, ctx->stream, ctx->Linv,  \
                                ctx->KsT, ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW, xcd_rows,            \
-                               ctx->tile_counter, (unsigned)nblocks, ctx->tile_trace);                             \
+                               ctx->tile_counter, (unsigned)nblocks, ctx->tile_trace, ctx->tri_skip);              \
     } while (0)
         // (32-deep K-steps for the 64-row tiles were measured: within 2.5 % either way, not kept)
         if (T == 128)      { if (nwv == 8) GPB_PRED(128, 8, 128, 16); else GPB_PRED(128, 4, 128, 16); }
