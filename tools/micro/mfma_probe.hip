@@ -26,7 +26,31 @@ __global__ __launch_bounds__(256) void k(double* out, int iters) {
     if (s == 12345.678) out[2] = s;
 }
 
+// the same loop with the accumulators pinned to AccVGPRs (inline asm "a" constraint)
 template <int NA, int NB>
+__global__ __launch_bounds__(256) void k_agpr(double* out, int iters) {
+    d4 acc[NA][NB];
+    double a[NA], b[NB];
+    for (int i = 0; i < NA; ++i) a[i] = 1.0 + 1e-9 * (threadIdx.x + i);
+    for (int j = 0; j < NB; ++j) b[j] = 1.0 - 1e-9 * (threadIdx.x + j);
+    for (int i = 0; i < NA; ++i) for (int j = 0; j < NB; ++j) acc[i][j] = d4{0, 0, 0, 0};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(a[i]), "v"(b[j]));
+    }
+    double s = 0;
+    for (int i = 0; i < NA; ++i) for (int j = 0; j < NB; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    asm volatile("" ::"v"(s));
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = (double)(t1 - t0); out[1] = (double)(r1 - r0); }
+    if (s == 12345.678) out[2] = s;
+}
+
+template <int NA, int NB, bool AGPR = false>
 void run(const char* name, int blocks) {
     double* d; hipMalloc(&d, 64);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -34,7 +58,8 @@ void run(const char* name, int blocks) {
     float ms = 0;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k<NA, NB>), dim3(blocks), dim3(256), 0, 0, d, iters);
+        if (AGPR) hipLaunchKernelGGL((k_agpr<NA, NB>), dim3(blocks), dim3(256), 0, 0, d, iters);
+        else      hipLaunchKernelGGL((k<NA, NB>), dim3(blocks), dim3(256), 0, 0, d, iters);
         hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
     }
@@ -52,6 +77,9 @@ int main() {
         run<2, 2>("acc4", blocks);
         run<2, 4>("acc8", blocks);
         run<4, 4>("acc16", blocks);
+        run<2, 2, true>("acc4/agpr", blocks);
+        run<2, 4, true>("acc8/agpr", blocks);
+        run<4, 4, true>("acc16/agpr", blocks);
     }
     return 0;
 }
