@@ -115,6 +115,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     gpb_dist_finalize(ctx);
     free(ctx->h_theta);
+    dev_free(&ctx->xmean); dev_free(&ctx->muS); dev_free(&ctx->Xc); dev_free(&ctx->dnorm);
     dev_free(&ctx->X); dev_free(&ctx->Xsc); dev_free(&ctx->ls); dev_free(&ctx->amp); dev_free(&ctx->noise);
     dev_free(&ctx->Z); dev_free(&ctx->K); dev_free(&ctx->Linv); dev_free(&ctx->T); dev_free(&ctx->yv);
     dev_free(&ctx->alpha); dev_free(&ctx->apart); dev_free(&ctx->info); dev_free(&ctx->lmlbuf);
@@ -169,6 +170,10 @@ extern "C" int gpb_gp_set(gpb_ctx* ctx, int64_t N, int64_t d, int64_t P, const d
     if ((rc = dev_alloc(ctx, &ctx->X, Np * dpad))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->Xsc, P * Np * dpad))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->ls, P * dpad))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->xmean, dpad))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->muS, P * dpad))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->Xc, P * Np * dpad))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->dnorm, P * Np))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->amp, P))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->noise, P))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->Z, P * Np))) return rc;
@@ -186,6 +191,13 @@ extern "C" int gpb_gp_set(gpb_ctx* ctx, int64_t N, int64_t d, int64_t P, const d
         for (int64_t k = 0; k < d; ++k) xp[i * dpad + k] = X_host[i * d + k];
     for (int64_t p = 0; p < P; ++p)
         for (int64_t i = 0; i < N; ++i) zp[p * Np + i] = Z_host[p * N + i];
+    std::vector<double> xm((size_t)dpad, 0.0);        // column means: the centre of k_kcross's dot-product form
+    for (int64_t k = 0; k < d; ++k) {
+        double sum = 0.0;
+        for (int64_t i = 0; i < N; ++i) sum += X_host[i * d + k];
+        xm[k] = sum / (double)N;
+    }
+    GPB_HIP(hipMemcpy(ctx->xmean, xm.data(), sizeof(double) * xm.size(), hipMemcpyHostToDevice));
     GPB_HIP(hipMemcpy(ctx->X, xp.data(), sizeof(double) * xp.size(), hipMemcpyHostToDevice));
     GPB_HIP(hipMemcpy(ctx->Z, zp.data(), sizeof(double) * zp.size(), hipMemcpyHostToDevice));
     return 0;
@@ -593,6 +605,9 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 9: if (value != 64 && value != 128) return GPB_E_ARG; ctx->chol_inner_tile = value; break;
         case 10: if (value < 0 || value > 1) return GPB_E_ARG; ctx->tile_priority = value; break;
         case 17: if (value < 0 || value > 1) return GPB_E_ARG; ctx->tri_skip = value; break;
+        case 18: if (value < 0 || value > 1) return GPB_E_ARG; ctx->kcross_dot = value; break;
+        case 19: if (value < 0 || value > 64) return GPB_E_ARG; ctx->kcross_chunks = value; break;
+        case 20: if (value < 1 || value > 2) return GPB_E_ARG; ctx->kcross_wpl = value; break;
         case 11: if (value < 0 || value > 1) return GPB_E_ARG; ctx->fuse_finalize = value; break;
         case 12: if (value != 0 && value != 64 && value != 128) return GPB_E_ARG; ctx->trtri_tile = value; break;
         case 14: if (value != 0 && value != 64 && value != 128) return GPB_E_ARG; ctx->syrk_tile = value; break;

@@ -37,11 +37,35 @@ __global__ void k_scale_design(const double* __restrict__ X, const double* __res
     Xsc[(int64_t)p * Np * dpad + idx] = X[idx] / ls[p * dpad + k];
 }
 
+// Centred copy for the dot-product form of the cross kernel (k_kcross): Xc = X/l - mean/l row by row, and the
+// rows' squared norms.  The walkers are shifted by the same muS, so the distances are those of the scaled design.
+__global__ void k_center_design(const double* __restrict__ Xsc, const double* __restrict__ xmean,
+                                const double* __restrict__ ls, double* __restrict__ muS, double* __restrict__ Xc,
+                                double* __restrict__ dnorm, int64_t Np, int dpad) {
+    const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int p = blockIdx.y;
+    if (n >= Np) return;
+    const double* src = Xsc + ((int64_t)p * Np + n) * dpad;
+    double* dst = Xc + ((int64_t)p * Np + n) * dpad;
+    double s = 0.0;
+    for (int k = 0; k < dpad; ++k) {
+        const double m = xmean[k] / ls[p * dpad + k];
+        if (n == 0) muS[p * dpad + k] = m;
+        const double v = src[k] - m;
+        dst[k] = v;
+        s = fma(v, v, s);
+    }
+    dnorm[(int64_t)p * Np + n] = s;
+}
+
 int launch_scale_design(gpb_ctx* ctx) {
     const int64_t tot = ctx->Np * ctx->dpad;
     dim3 grid((unsigned)((tot + 255) / 256), (unsigned)ctx->P);
     hipLaunchKernelGGL(k_scale_design, grid, dim3(256), 0, ctx->stream, ctx->X, ctx->ls, ctx->Xsc,
                        ctx->Np, (int)ctx->dpad);
+    dim3 grid2((unsigned)((ctx->Np + 255) / 256), (unsigned)ctx->P);
+    hipLaunchKernelGGL(k_center_design, grid2, dim3(256), 0, ctx->stream, ctx->Xsc, ctx->xmean, ctx->ls, ctx->muS,
+                       ctx->Xc, ctx->dnorm, ctx->Np, (int)ctx->dpad);
     GPB_HIP(hipGetLastError());
     return 0;
 }

@@ -33,6 +33,10 @@ struct gpb_ctx {
     double* h_theta = nullptr;     // host [P][d+2]
     double* X = nullptr;           // [Np][dpad]   raw design (pad rows/cols zero)
     double* Xsc = nullptr;         // [P][Np][dpad] design / length_scale_p
+    double* xmean = nullptr;       // [dpad] column means of the design (0 in the padding)
+    double* muS = nullptr;         // [P][dpad] xmean / length_scale_p
+    double* Xc = nullptr;          // [P][Np][dpad] Xsc - muS: centred scaled design (dot-product form of k_kcross)
+    double* dnorm = nullptr;       // [P][Np] squared norms of the rows of Xc
     double* ls = nullptr;          // [P][dpad]    length scales (1 in pad columns)
     double* amp = nullptr;         // [P] c
     double* noise = nullptr;       // [P] sigma_n^2
@@ -93,6 +97,9 @@ struct gpb_ctx {
     unsigned* tile_trace = nullptr; // debug hook: [count, capacity, pad x6][capacity][8] records of k_predict tiles
     int resident_occ = 0;          // tuning hook: co-resident workgroups per CU assumed for the static launch (0 = table)
     int tile_priority = 1;         // k_predict: wave priority by K-loop length (s_setprio)
+    int kcross_chunks = 0;         // 64-row chunks of the design per k_kcross workgroup (0 = by grid size)
+    int kcross_wpl = 2;            // walkers per lane of k_kcross (1 or 2)
+    int kcross_dot = 1;            // k_kcross: r^2 = |a|^2 + |b|^2 - 2 a.b (d fma) instead of d differences (2d ops)
     int tri_skip = 1;              // k_predict: skip the all-zero half of the diagonal block's second half
     int force_tile = 0;           // test hook: 0 = auto, 64 / 128 / 32 (= 64x32) force the k_predict tile
     int force_xcd = -1;             // tuning hook: -1 auto, 0 / 1 = k_predict XCD affinity by walker tile / row block

@@ -31,74 +31,147 @@ __device__ __forceinline__ double shape_fn_p(double r2) {
 
 // grid (Wpad/64, Np/64, P), 256 threads: lane = walker, the 4 waves stride the 64-point chunk's
 // design points; the design row is wave-uniform (scalar loads), the walker row lives in VGPRs.
-template <int KIND, int DPAD>
+// DOT: r^2 = |a|^2 + |b|^2 - 2 a.b with a = design row / l - mu / l (Xc, its norms in dnorm) and b = walker / l -
+// mu / l: d multiply-adds per pair instead of d subtractions + d multiply-adds (the kernel is bound by the fp64
+// VALU; 78 -> 58 instructions per design row).  Centring at the design's column means keeps |a|, |b| small: the
+// cancellation costs ~1e-16 (|a|^2 + |b|^2) absolute in r^2, <= 1e-15 relative in K* for length scales down to a
+// tenth of the design's extent (2e-13 at sklearn's lower search bound); measured against the oracle the two forms
+// are indistinguishable (1e-13 between them).  One form for every batch size, so a walker's result still does not
+// depend on how the ensemble is split.
+template <int KIND, int DPAD, bool DOT, int WPL>
 __global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, int64_t W, int d,
                                                 const double* __restrict__ Xsc, const double* __restrict__ ls,
                                                 const double* __restrict__ amp, const double* __restrict__ alpha,
                                                 double* __restrict__ KsT, double* __restrict__ mpart,
-                                                int64_t N, int64_t Np, int64_t Wld, int P) {
-    __shared__ double red[4][64];
-    __shared__ __attribute__((aligned(16))) double sbuf[64 * (DPAD + 1)];  // walker tile, then the design rows
+                                                int64_t N, int64_t Np, int64_t Wld, int P,
+                                                const double* __restrict__ dnorm, const double* __restrict__ muS,
+                                                int chunks_per_wg) {
+    constexpr int WT = 64 * WPL;                        // walkers per workgroup: lane l holds walkers l, l + 64, ...
+    __shared__ double red[4][WT];
+    __shared__ double sdn[KX_CHUNK];
+    __shared__ __attribute__((aligned(16))) double sbuf[WT * (DPAD + 1)];  // walker tile, then the design rows
     __shared__ double sal[KX_CHUNK];
     double (*sx)[DPAD + 1] = reinterpret_cast<double (*)[DPAD + 1]>(sbuf);
     double* sxr = sbuf;                                 // [KX_CHUNK][DPAD] design rows / length scale
-    const int p = blockIdx.z, chunk = blockIdx.y;
+    const int p = blockIdx.z;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t w = (int64_t)blockIdx.x * 64 + lane;
-    const int64_t nbeg = (int64_t)chunk * KX_CHUNK;     // Np is a multiple of KX_CHUNK: the chunk is always whole
-    const double* Xp = Xsc + ((int64_t)p * Np + nbeg) * DPAD;
-    // walker tile / length scale, loaded coalesced and divided once per element, then one row per lane;
+    const int64_t w0 = (int64_t)blockIdx.x * WT;
+    const int64_t nchunk = Np / KX_CHUNK;               // Np is a multiple of KX_CHUNK: chunks are always whole
+    const int64_t chunk0 = (int64_t)blockIdx.y * chunks_per_wg;
+    const int64_t chunk1 = imin64(chunk0 + chunks_per_wg, nchunk);
+    // walker tile / length scale, loaded coalesced and divided once per element, then WPL rows per lane;
     // the design rows are one contiguous block: coalesced into LDS, read back as broadcasts (scalar loads
-    // of 64 x DPAD doubles per workgroup miss the scalar cache and serialise on L2 latency)
+    // of 64 x DPAD doubles per workgroup miss the scalar cache and serialise on L2 latency).  Every broadcast
+    // feeds WPL multiply-adds (the LDS reads, not the VALU, bound the one-walker form).  A workgroup
+    // walks `chunks_per_wg` chunks with its walker tile in registers (the set-up — fp64 divisions, three
+    // barriers, two round trips to L2 — is as long as one chunk's arithmetic), the next chunk's rows in
+    // flight meanwhile.
     constexpr int NPRE = (KX_CHUNK * DPAD + 255) / 256;
-    double pre[NPRE];                                   // design rows in flight while the walker tile is set up
+    double pre[NPRE], pal = 0.0, pdn = 0.0;             // the next chunk's rows / alpha / row norms in flight
+    auto fetch = [&](int64_t chunk) {
+        const double* Xp = Xsc + ((int64_t)p * Np + chunk * KX_CHUNK) * DPAD;
 #pragma unroll
-    for (int j = 0; j < NPRE; ++j) {
-        const int e = threadIdx.x + 256 * j;
-        pre[j] = (e < KX_CHUNK * DPAD) ? Xp[e] : 0.0;
-    }
-    for (int e = threadIdx.x; e < 64 * DPAD; e += 256) {
+        for (int j = 0; j < NPRE; ++j) {
+            const int e = threadIdx.x + 256 * j;
+            pre[j] = (e < KX_CHUNK * DPAD) ? Xp[e] : 0.0;
+        }
+        if (threadIdx.x < KX_CHUNK) {
+            pal = alpha[(int64_t)p * Np + chunk * KX_CHUNK + threadIdx.x];
+            if (DOT) pdn = dnorm[(int64_t)p * Np + chunk * KX_CHUNK + threadIdx.x];
+        }
+    };
+    fetch(chunk0);
+    for (int e = threadIdx.x; e < WT * DPAD; e += 256) {
         const int r = e / DPAD, k = e - r * DPAD;
-        const int64_t ww = (int64_t)blockIdx.x * 64 + r;
-        sx[r][k] = (k < d && ww < W) ? Xs[ww * d + k] / ls[p * DPAD + k] : 0.0;
-    }
-    if (threadIdx.x < KX_CHUNK) sal[threadIdx.x] = alpha[(int64_t)p * Np + nbeg + threadIdx.x];
-    __syncthreads();
-    double xs[DPAD];
-#pragma unroll
-    for (int k = 0; k < DPAD; ++k) xs[k] = sx[lane][k];
-    __syncthreads();                                    // the walker tile is in registers: reuse its LDS
-#pragma unroll
-    for (int j = 0; j < NPRE; ++j) {
-        const int e = threadIdx.x + 256 * j;
-        if (e < KX_CHUNK * DPAD) sxr[e] = pre[j];
+        const int64_t ww = w0 + r;
+        double v = (k < d && ww < W) ? Xs[ww * d + k] / ls[p * DPAD + k] : 0.0;
+        if (DOT && k < d && ww < W) v -= muS[p * DPAD + k];
+        sx[r][k] = v;
     }
     __syncthreads();
+    double xs[WPL][DPAD];
+    double nb[WPL];                                     // |b|^2 of this lane's walkers (DOT)
+#pragma unroll
+    for (int u = 0; u < WPL; ++u) {
+        nb[u] = 0.0;
+#pragma unroll
+        for (int k = 0; k < DPAD; ++k) {
+            xs[u][k] = sx[lane + 64 * u][k];
+            if (DOT) nb[u] = fma(xs[u][k], xs[u][k], nb[u]);
+        }
+    }
     const double c = amp[p];
     double* Kp = KsT + (int64_t)p * Np * Wld;
-    double msum = 0.0;
-    for (int t = 0; t < KX_CHUNK / 4; ++t) {
-        const int pt = wave + 4 * t;                    // wave-uniform
-        const int64_t n = nbeg + pt;
-        double kv = 0.0;
-        if (n < N) {
-            const double* xr = sxr + pt * DPAD;
-            double r2 = 0.0;
+    for (int64_t chunk = chunk0; chunk < chunk1; ++chunk) {
+        const int64_t nbeg = chunk * KX_CHUNK;
+        __syncthreads();                                // the walker tile / the previous chunk's rows are done with
 #pragma unroll
-            for (int k = 0; k < DPAD; ++k) {
-                const double df = xs[k] - xr[k];
-                r2 = fma(df, df, r2);
-            }
-            kv = c * shape_fn_p<KIND>(r2);
-            msum = fma(sal[pt], kv, msum);
+        for (int j = 0; j < NPRE; ++j) {
+            const int e = threadIdx.x + 256 * j;
+            if (e < KX_CHUNK * DPAD) sxr[e] = pre[j];
         }
-        Kp[n * Wld + w] = kv;
+        if (threadIdx.x < KX_CHUNK) {
+            sal[threadIdx.x] = pal;
+            if (DOT) sdn[threadIdx.x] = pdn;
+        }
+        __syncthreads();
+        if (chunk + 1 < chunk1) fetch(chunk + 1);
+        double msum[WPL];
+#pragma unroll
+        for (int u = 0; u < WPL; ++u) msum[u] = 0.0;
+        for (int t = 0; t < KX_CHUNK / 4; ++t) {
+            const int pt = wave + 4 * t;                // wave-uniform
+            const int64_t n = nbeg + pt;
+            double kv[WPL];
+#pragma unroll
+            for (int u = 0; u < WPL; ++u) kv[u] = 0.0;
+            if (n < N) {
+                const double* xr = sxr + pt * DPAD;
+                double r2[WPL];
+#pragma unroll
+                for (int u = 0; u < WPL; ++u) r2[u] = 0.0;
+                if (DOT) {
+#pragma unroll
+                    for (int k = 0; k < DPAD; ++k) {
+                        const double a = xr[k];
+#pragma unroll
+                        for (int u = 0; u < WPL; ++u) r2[u] = fma(xs[u][k], a, r2[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < WPL; ++u) r2[u] = fmax(fma(-2.0, r2[u], sdn[pt] + nb[u]), 0.0);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < DPAD; ++k) {
+                        const double a = xr[k];
+#pragma unroll
+                        for (int u = 0; u < WPL; ++u) {
+                            const double df = xs[u][k] - a;
+                            r2[u] = fma(df, df, r2[u]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < WPL; ++u) {
+                    kv[u] = c * shape_fn_p<KIND>(r2[u]);
+                    msum[u] = fma(sal[pt], kv[u], msum[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < WPL; ++u) Kp[n * Wld + w0 + lane + 64 * u] = kv[u];
+        }
+        // red: written here, read by wave 0 below; the next write is behind the two barriers at the top of the loop
+#pragma unroll
+        for (int u = 0; u < WPL; ++u) red[wave][lane + 64 * u] = msum[u];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int u = 0; u < WPL; ++u) {
+                const int l = lane + 64 * u;
+                mpart[(chunk * P + p) * Wld + w0 + l] = ((red[0][l] + red[1][l]) + red[2][l]) + red[3][l];
+            }
+        }
     }
-    red[wave][lane] = msum;
-    __syncthreads();
-    if (wave == 0)
-        mpart[((int64_t)chunk * P + p) * Wld + w] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 // 1-D grid of P * nI * nW tiles (T x T, T = 128 or 64), heaviest row blocks first; consecutive blocks
@@ -417,11 +490,33 @@ int ensure_wcap(gpb_ctx* ctx, int64_t W) {
 template <int KIND>
 static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int64_t Wuse) {
     const int nchunk = (int)((ctx->Np + KX_CHUNK - 1) / KX_CHUNK);
-    dim3 grid((unsigned)(Wuse / 64), (unsigned)nchunk, (unsigned)ctx->P);
-#define GPB_KX(DP)                                                                                         \
-    hipLaunchKernelGGL((k_kcross<KIND, DP>), grid, dim3(256), 0, ctx->stream, Xs_dev, W, (int)ctx->d, ctx->Xsc, \
-                       ctx->ls, ctx->amp, ctx->alpha, ctx->KsT, ctx->mpart, ctx->N, ctx->Np, ctx->Wcap,     \
-                       (int)ctx->P)
+    // chunks per workgroup: as many as still leave >= 4 workgroups per CU (a geometry choice: the per-chunk
+    // partials and their order do not depend on it; measured, cfg 4: 1 / 2 / 4 chunks at 512 / 1024 / 2048+ walkers)
+    // two walkers per lane (every LDS broadcast feeds two multiply-adds) for d <= 32 and batches that are a whole
+    // number of 128-walker tiles (always: WPAD = 128)
+    const int wpl = (ctx->kcross_dot && ctx->kcross_wpl == 2 && ctx->dpad <= 32 && Wuse >= 256 && Wuse % 128 == 0) ? 2 : 1;
+    int cpw = ctx->kcross_chunks;
+    if (cpw <= 0) {
+        const int64_t wgs1 = (Wuse / (64 * wpl)) * nchunk * ctx->P;
+        cpw = 1;
+        while (cpw < 8 && wgs1 / (2 * cpw) >= 4 * (int64_t)ctx->num_cu) cpw *= 2;
+    }
+    dim3 grid((unsigned)(Wuse / (64 * wpl)), (unsigned)((nchunk + cpw - 1) / cpw), (unsigned)ctx->P);
+#define GPB_KX(DP)                                                                                               \
+    do {                                                                                                         \
+        if (ctx->kcross_dot && wpl == 2)                                                                         \
+            hipLaunchKernelGGL((k_kcross<KIND, DP, true, (DP <= 32 ? 2 : 1)>), grid, dim3(256), 0, ctx->stream,  \
+                               Xs_dev, W, (int)ctx->d, ctx->Xc, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT,         \
+                               ctx->mpart, ctx->N, ctx->Np, ctx->Wcap, (int)ctx->P, ctx->dnorm, ctx->muS, cpw);  \
+        else if (ctx->kcross_dot)                                                                                \
+            hipLaunchKernelGGL((k_kcross<KIND, DP, true, 1>), grid, dim3(256), 0, ctx->stream, Xs_dev, W,        \
+                               (int)ctx->d, ctx->Xc, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT, ctx->mpart,        \
+                               ctx->N, ctx->Np, ctx->Wcap, (int)ctx->P, ctx->dnorm, ctx->muS, cpw);              \
+        else                                                                                                     \
+            hipLaunchKernelGGL((k_kcross<KIND, DP, false, 1>), grid, dim3(256), 0, ctx->stream, Xs_dev, W,       \
+                               (int)ctx->d, ctx->Xsc, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT, ctx->mpart,       \
+                               ctx->N, ctx->Np, ctx->Wcap, (int)ctx->P, ctx->dnorm, ctx->muS, cpw);              \
+    } while (0)
     switch (ctx->dpad) {
         case 8: GPB_KX(8); break;
         case 16: GPB_KX(16); break;

@@ -216,7 +216,9 @@ int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
  * triangular-inverse levels / of the end-of-panel Cholesky updates (0 = by fill, 64, 128);
  * 13 = co-resident workgroups per CU assumed when choosing the static predict launch (0 = built-in table);
  * 16 = persistent 64x128-tile workgroups per CU; 17 = leave out the all-zero m-tiles of the predict kernel's
- * diagonal blocks (1, default) or multiply them like any other (0: A/B measurements). */
+ * diagonal blocks (1, default) or multiply them like any other (0: A/B measurements);
+ * 18 = cross-kernel distances as |a|^2 + |b|^2 - 2 a.b on centred coordinates (1, default) or as d differences (0);
+ * 19 = 64-row chunks of the design per cross-kernel workgroup (0 = by grid size); 20 = walkers per lane there (1, 2). */
 int gpb_debug_tune(gpb_ctx* ctx, int key, int value);
 /* debug hook: per-tile placement and timing of the predict kernel.  capacity > 0 arms (and clears) a trace of
  * that many records, 0 disarms; read copies up to max_records records of 8 uint32 {HW_ID register, XCC_ID,
