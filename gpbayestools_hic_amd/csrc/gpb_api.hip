@@ -608,11 +608,13 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 18: if (value < 0 || value > 1) return GPB_E_ARG; ctx->kcross_dot = value; break;
         case 19: if (value < 0 || value > 64) return GPB_E_ARG; ctx->kcross_chunks = value; break;
         case 20: if (value < 1 || value > 2) return GPB_E_ARG; ctx->kcross_wpl = value; break;
+        case 21: if (value < 0 || value > 1) return GPB_E_ARG; ctx->static64 = value; break;
+        case 22: if (value < 0) return GPB_E_ARG; ctx->mid_switch = value; break;
         case 11: if (value < 0 || value > 1) return GPB_E_ARG; ctx->fuse_finalize = value; break;
         case 12: if (value != 0 && value != 64 && value != 128) return GPB_E_ARG; ctx->trtri_tile = value; break;
         case 14: if (value != 0 && value != 64 && value != 128) return GPB_E_ARG; ctx->syrk_tile = value; break;
         case 16: if (value < 1 || value > 8) return GPB_E_ARG; ctx->wgs_per_cu64x128 = value; break;
-        case 13: if (value < 0 || value > 16) return GPB_E_ARG; ctx->resident_occ = value; break;
+        case 13: if (value < 0 || value > 1024) return GPB_E_ARG; ctx->resident_occ = value; break;
         default: return GPB_E_ARG;
     }
     return 0;

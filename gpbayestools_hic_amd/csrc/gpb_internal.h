@@ -86,7 +86,8 @@ struct gpb_ctx {
     int wgs_per_cu128w8 = 2;        // ... for the 128-tile, 8-wave variant
     int wgs_per_cu32 = 4;           // ... for the 64x32 tile
     int wgs_per_cu64x128 = 5;       // ... for the 64x128 tile (4 resident at 128 VGPRs)
-    int64_t narrow_switch = 128;    // padded walker batches up to this size use 64x32 tiles (0 = never)
+    int64_t narrow_switch = 1280;   // 64x64 tiles when at least this many of them exist per 256 CUs, else 64x32
+    int static64 = 1;               // 64-row predict tiles always launch as k_predict_static
     int predict_waves = 4;          // waves per k_predict tile (4 or 8)
     unsigned* tile_counter = nullptr;   // 8 ticket queues (stride 16) + done counter [128]; re-armed by the kernel
     int64_t chol_outer = 512;      // outer panel width of the two-level blocked Cholesky
@@ -103,8 +104,8 @@ struct gpb_ctx {
     int tri_skip = 1;              // k_predict: skip the all-zero half of the diagonal block's second half
     int force_tile = 0;           // test hook: 0 = auto, 64 / 128 / 32 (= 64x32) force the k_predict tile
     int force_xcd = -1;             // tuning hook: -1 auto, 0 / 1 = k_predict XCD affinity by walker tile / row block
-    int64_t tile_switch = 2560;     // use 128x128 tiles when at least this many of them exist (measured crossover)
-    int64_t mid_switch = 900;       // else 64x128 tiles when at least this many of THEM exist, else 64x64
+    int64_t tile_switch = 960;      // use 128x128 tiles when at least this many of them exist per 256 CUs (measured)
+    int64_t mid_switch = 1280;      // else 64x128 tiles when at least this many of THEM exist, else 64x64 / 64x32
     bool force_generic_mvn = false; // test hook: bypass the register-resident MVN fast path
     int fuse_finalize = 1;          // block log-likelihood kernels sum the predict partials themselves (P <= 32)
     int64_t mvn_wg_switch = 768;   // batches up to this size use one workgroup per walker (32 < M <= 64)

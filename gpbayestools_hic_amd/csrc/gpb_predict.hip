@@ -541,17 +541,17 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
     const int nchunk = (int)((ctx->Np + KX_CHUNK - 1) / KX_CHUNK);
     const int nI64 = (int)(ctx->Np / 64);
     if (need_var) {
-        // 128-wide tiles when they fill the chip several times over, 64-wide for small walker batches
+        // T rows x TN walkers per tile: the LARGEST shape of which enough tiles exist to fill the chip (measured,
+        // cfg 3 and cfg 4 sweeps at 128..2048 walkers, profiles/r01_tile_shape_sweep.txt): 128x128 (2 per CU, 64
+        // MFMAs per wave between barriers) from 3.75 tiles per CU on, 64x128 (32 MFMAs) and 64x64 (16) from 5 per
+        // CU, else 64x32.  Fewer, larger tiles leave CUs idle behind the heaviest triangular row block; more,
+        // smaller ones pay more barriers and operand traffic per MFMA.
         const int64_t tiles128 = ctx->P * ((ctx->Np + 127) / 128) * (Wuse / 128);
-        // T rows x TN walkers per tile, by how many tiles there are to fill the chip with (measured crossovers,
-        // cfg 3 and cfg 4 sweeps): 128x128 (2 per CU, 64 MFMAs per wave between barriers) for the big batches;
-        // 64x128 (4-5 per CU, 32 MFMAs) in between; 64x64 (6-7 per CU, 16 MFMAs) for a rank's small shard, where
-        // the heaviest tile's serial K loop is the critical path; 64x32 ("32") below 128 walkers.
-        const int64_t tiles64x128 = ctx->P * nI64 * (Wuse / 128);
-        int T = 64, TN = 64;
-        if (tiles128 >= ctx->tile_switch) T = TN = 128;
-        else if (tiles64x128 >= ctx->mid_switch) TN = 128;
-        else if (Wuse <= ctx->narrow_switch) TN = 32;
+        const int64_t tiles64x128 = ctx->P * nI64 * (Wuse / 128), tiles64 = ctx->P * nI64 * (Wuse / 64);
+        int T = 64, TN = 32;
+        if (tiles128 * 256 >= ctx->tile_switch * ctx->num_cu) T = TN = 128;
+        else if (tiles64x128 * 256 >= ctx->mid_switch * ctx->num_cu) TN = 128;
+        else if (tiles64 * 256 >= ctx->narrow_switch * ctx->num_cu) TN = 64;
         if (ctx->force_tile == 64 || ctx->force_tile == 128) T = TN = ctx->force_tile;
         if (ctx->force_tile == 32) { T = 64; TN = 32; }
         if (ctx->force_tile == 65) { T = 64; TN = 128; }        // 64 rows x 128 walkers
@@ -576,8 +576,13 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
         // 128x128: 2, 64x128: 4, 64x64: 6 (80 VGPRs), 64x32: 8.
         int occ = (T == 128) ? 2 : (TN == 32 ? 8 : (TN == 128 ? 4 : 6));
         if (ctx->resident_occ > 0) occ = ctx->resident_occ;
-        const int resident = (nblocks <= (int64_t)ctx->num_cu * occ && nwv == 4 && xcd_rows < 2)
-                                 ? ctx->resident_order : 0;
+        // The 64-row shapes always launch static, co-resident or not: beyond co-residency the hardware dispatcher
+        // hands the next workgroup (= next tile in weight order) to whichever CU frees a slot, which balances as
+        // well as the ticket queues do, and the static kernel is the lighter one (7-12 % faster at 384-768
+        // walkers than the persistent form of the same tile shape).
+        const bool all_resident = nblocks <= (int64_t)ctx->num_cu * occ;
+        const int resident = (nwv == 4 && xcd_rows < 2 && (all_resident || (T == 64 && ctx->static64)))
+                                 ? ctx->resident_order : 0;      // order 0 = ticket queues on request
         const unsigned grid = (unsigned)((resident || nblocks < slots) ? nblocks : slots);
 #define GPB_PRED(TT, WW, NN, KK)                                                                                 \
     do {                                                                                                         \

@@ -198,8 +198,8 @@ int gpb_dist_finalize(gpb_ctx* ctx);
 int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K,
                   const double* A_host, const double* B_host, double* C_host, int b_trans);
 /* test/tuning hook: force the tile of the predict kernel (0 = automatic, 64, 128, 32 = 64 rows x 32
- * walkers, 65 = 64 rows x 128 walkers) and, when switch_tiles > 0, the number of 128x128 tiles from
- * which the automatic choice uses them. */
+ * walkers, 65 = 64 rows x 128 walkers) and, when switch_tiles > 0, the number of 128x128 tiles per 256 CUs
+ * from which the automatic choice uses them. */
 int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
 /* tuning hook for launch geometry (never changes results): key 0 = XCD affinity of the predict kernel
  * (-1 auto, 0 by walker tile, 1 by row block, 2 by GP, 3 by (GP, four row blocks) super-block: least
@@ -208,7 +208,7 @@ int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
  * 4 = outer panel width of the blocked Cholesky; 5 = tile order when every predict tile has its own
  * co-resident workgroup (0 ticket queues, 1 sorted, 2 snake over the CUs, 3 snake of pairs);
  * 6 = persistent 64x32-tile workgroups per CU;
- * 7 = largest padded walker batch that uses 64x32 tiles; 8 = largest batch whose block log-likelihood
+ * 7 = 64x64 predict tiles when at least this many of them exist per 256 CUs, else 64x32; 8 = largest batch whose block log-likelihood
  * (PCA mode, 32 < M <= 64) runs one workgroup per walker instead of one wave per walker;
  * 9 = tile (64 or 128) of the K=64 trailing updates inside an outer Cholesky panel;
  * 10 = wave priority of predict tiles by K-loop length (0/1); 11 = the block log-likelihood kernels sum the
@@ -218,7 +218,9 @@ int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
  * 16 = persistent 64x128-tile workgroups per CU; 17 = leave out the all-zero m-tiles of the predict kernel's
  * diagonal blocks (1, default) or multiply them like any other (0: A/B measurements);
  * 18 = cross-kernel distances as |a|^2 + |b|^2 - 2 a.b on centred coordinates (1, default) or as d differences (0);
- * 19 = 64-row chunks of the design per cross-kernel workgroup (0 = by grid size); 20 = walkers per lane there (1, 2). */
+ * 19 = 64-row chunks of the design per cross-kernel workgroup (0 = by grid size); 20 = walkers per lane there (1, 2);
+ * 21 = 64-row predict tiles always launch static (1, default) or only when co-resident (0);
+ * 22 = 64x128 predict tiles when at least this many of them exist per 256 CUs. */
 int gpb_debug_tune(gpb_ctx* ctx, int key, int value);
 /* debug hook: per-tile placement and timing of the predict kernel.  capacity > 0 arms (and clears) a trace of
  * that many records, 0 disarms; read copies up to max_records records of 8 uint32 {HW_ID register, XCC_ID,
