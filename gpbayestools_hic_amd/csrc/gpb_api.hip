@@ -115,6 +115,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     gpb_dist_finalize(ctx);
     free(ctx->h_theta);
+    dev_free(&ctx->lr_R); dev_free(&ctx->lr_v0);
     dev_free(&ctx->xmean); dev_free(&ctx->muS); dev_free(&ctx->Xc); dev_free(&ctx->dnorm);
     dev_free(&ctx->X); dev_free(&ctx->Xsc); dev_free(&ctx->ls); dev_free(&ctx->amp); dev_free(&ctx->noise);
     dev_free(&ctx->Z); dev_free(&ctx->K); dev_free(&ctx->Linv); dev_free(&ctx->T); dev_free(&ctx->yv);
@@ -392,7 +393,101 @@ extern "C" int gpb_emu_set_transform(gpb_ctx* ctx, int mode, int64_t M, const do
     GPB_HIP(hipMemcpy(ctx->scale, scale_host ? scale_host : ones.data(), sizeof(double) * M, hipMemcpyHostToDevice));
     GPB_HIP(hipMemcpy(ctx->C0, cov_trunc_host ? cov_trunc_host : zeros.data(), sizeof(double) * M * M, hipMemcpyHostToDevice));
     ctx->mode = mode; ctx->M = M; ctx->have_transform = true; ctx->have_like = false;
+    ctx->lr_ok = false;
+    ctx->h_A.assign(A_host ? A_host : zeros.data(), (A_host ? A_host : zeros.data()) + P * M);
+    ctx->h_mu.assign(mu_host, mu_host + M);
+    ctx->h_C0.assign(cov_trunc_host ? cov_trunc_host : zeros.data(), (cov_trunc_host ? cov_trunc_host : zeros.data()) + M * M);
     return 0;
+}
+
+// Low-rank form of the block likelihood (PCA mode, src/emulator.py:584-587 + src/mcmc.py:23-65): the covariance of
+// every walker is C = C0 + A^T D A with the SAME C0 = C_trunc + C_exp and a walker-dependent D = diag(var_p) of
+// rank P << M.  With C0 = L0 L0^T and the thin QR factorisation L0^-1 A^T = Q R (M x P, P x P):
+//     L0^-1 C L0^-T = I + Q (R D R^T) Q^T
+//     log det C = log det C0 + log det S,                 S = I_P + R D R^T
+//     y^T C^-1 y = |(I - Q Q^T) L0^-1 y|^2 + v^T S^-1 v,  v = Q^T L0^-1 y = R m + v0
+// because y = A^T m + (mu - yexp) and L0^-1 A^T m = Q R m lies in the span of Q: the first term is a constant of
+// the emulator.  No difference of large numbers anywhere (unlike the Woodbury identity); against 40-digit
+// arithmetic the form is as accurate as the dense Cholesky (1e-15 relative).  Per walker this is a P x P Cholesky
+// instead of an M x M one.  Returns false (dense kernels stay in charge) when C0 is not positive definite or A is
+// rank deficient.
+static bool lowrank_setup(gpb_ctx* ctx, const double* yexp, const double* cexp) {
+    const int64_t M = ctx->M, P = ctx->P;
+    if (ctx->mode != GPB_MODE_PCA || P > 16 || P > M) return false;
+    std::vector<long double> L((size_t)(M * M), 0.0L);
+    for (int64_t i = 0; i < M; ++i)
+        for (int64_t j = 0; j <= i; ++j) {                         // symmetrised lower triangle of C0
+            const double a = ctx->h_C0[i * M + j] + cexp[i * M + j], b = ctx->h_C0[j * M + i] + cexp[j * M + i];
+            L[i * M + j] = 0.5L * ((long double)a + (long double)b);
+        }
+    long double logdet = 0.0L;
+    for (int64_t j = 0; j < M; ++j) {                              // Cholesky, column by column
+        long double dsum = L[j * M + j];
+        for (int64_t k = 0; k < j; ++k) dsum -= L[j * M + k] * L[j * M + k];
+        if (!(dsum > 0.0L)) return false;
+        const long double ljj = sqrtl(dsum);
+        L[j * M + j] = ljj;
+        logdet += 2.0L * logl(ljj);
+        for (int64_t i = j + 1; i < M; ++i) {
+            long double v = L[i * M + j];
+            for (int64_t k = 0; k < j; ++k) v -= L[i * M + k] * L[j * M + k];
+            L[i * M + j] = v / ljj;
+        }
+    }
+    auto fwd = [&](std::vector<long double>& x) {                  // x <- L0^-1 x
+        for (int64_t i = 0; i < M; ++i) {
+            long double v = x[i];
+            for (int64_t k = 0; k < i; ++k) v -= L[i * M + k] * x[k];
+            x[i] = v / L[i * M + i];
+        }
+    };
+    std::vector<std::vector<long double>> Q((size_t)P, std::vector<long double>((size_t)M));
+    std::vector<long double> R((size_t)(P * P), 0.0L);
+    for (int64_t j = 0; j < P; ++j) {                              // column j of L0^-1 A^T, then Gram-Schmidt twice
+        std::vector<long double>& q = Q[j];
+        for (int64_t i = 0; i < M; ++i) q[i] = ctx->h_A[j * M + i];
+        fwd(q);
+        long double norm0 = 0.0L;
+        for (int64_t i = 0; i < M; ++i) norm0 += q[i] * q[i];
+        for (int pass = 0; pass < 2; ++pass)
+            for (int64_t i = 0; i < j; ++i) {
+                long double r = 0.0L;
+                for (int64_t k = 0; k < M; ++k) r += Q[i][k] * q[k];
+                for (int64_t k = 0; k < M; ++k) q[k] -= r * Q[i][k];
+                R[i * P + j] += r;
+            }
+        long double nrm = 0.0L;
+        for (int64_t i = 0; i < M; ++i) nrm += q[i] * q[i];
+        if (!(nrm > 1e-24L * norm0) || !(norm0 > 0.0L)) return false;      // A (numerically) rank deficient
+        nrm = sqrtl(nrm);
+        R[j * P + j] = nrm;
+        for (int64_t i = 0; i < M; ++i) q[i] /= nrm;
+    }
+    std::vector<long double> w((size_t)M);
+    for (int64_t i = 0; i < M; ++i) w[i] = (long double)ctx->h_mu[i] - (long double)yexp[i];
+    fwd(w);
+    std::vector<long double> v0((size_t)P, 0.0L);
+    for (int64_t j = 0; j < P; ++j)
+        for (int64_t k = 0; k < M; ++k) v0[j] += Q[j][k] * w[k];
+    long double cperp = 0.0L;
+    for (int64_t k = 0; k < M; ++k) {
+        long double t = w[k];
+        for (int64_t j = 0; j < P; ++j) t -= Q[j][k] * v0[j];
+        cperp += t * t;
+    }
+    double Rh[256], vh[16];
+    for (int i = 0; i < 256; ++i) Rh[i] = 0.0;
+    for (int i = 0; i < 16; ++i) vh[i] = 0.0;
+    for (int64_t i = 0; i < P; ++i) {
+        vh[i] = (double)v0[i];
+        for (int64_t j = i; j < P; ++j) Rh[i * 16 + j] = (double)R[i * P + j];
+    }
+    if (dev_alloc(ctx, &ctx->lr_R, 256) || dev_alloc(ctx, &ctx->lr_v0, 16)) return false;
+    if (hipMemcpy(ctx->lr_R, Rh, sizeof(Rh), hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (hipMemcpy(ctx->lr_v0, vh, sizeof(vh), hipMemcpyHostToDevice) != hipSuccess) return false;
+    ctx->lr_cperp = (double)cperp;
+    ctx->lr_logdet0 = (double)logdet;
+    return true;
 }
 
 extern "C" int gpb_emu_predict(gpb_ctx* ctx, const double* Xs, int64_t W, int on_device, const double* extra_std,
@@ -431,6 +526,7 @@ extern "C" int gpb_like_set(gpb_ctx* ctx, const double* yexp_host, const double*
     if ((rc = dev_alloc(ctx, &ctx->Cexp, M * M))) return rc;
     GPB_HIP(hipMemcpy(ctx->yexp, yexp_host, sizeof(double) * M, hipMemcpyHostToDevice));
     GPB_HIP(hipMemcpy(ctx->Cexp, cov_exp_host, sizeof(double) * M * M, hipMemcpyHostToDevice));
+    ctx->lr_ok = lowrank_setup(ctx, yexp_host, cov_exp_host);
     ctx->have_like = true;
     return 0;
 }
@@ -609,6 +705,7 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 19: if (value < 0 || value > 64) return GPB_E_ARG; ctx->kcross_chunks = value; break;
         case 20: if (value < 1 || value > 2) return GPB_E_ARG; ctx->kcross_wpl = value; break;
         case 21: if (value < 0 || value > 1) return GPB_E_ARG; ctx->static64 = value; break;
+        case 23: if (value < 0 || value > 1) return GPB_E_ARG; ctx->lowrank = value; break;
         case 22: if (value < 0) return GPB_E_ARG; ctx->mid_switch = value; break;
         case 11: if (value < 0 || value > 1) return GPB_E_ARG; ctx->fuse_finalize = value; break;
         case 12: if (value != 0 && value != 64 && value != 128) return GPB_E_ARG; ctx->trtri_tile = value; break;

@@ -72,6 +72,15 @@ struct gpb_ctx {
     int mode = 0;
     int64_t M = 0;
     bool have_transform = false, have_like = false;
+    // host copies of the observable transform (PCA modes) for the low-rank form of the likelihood
+    std::vector<double> h_A, h_mu, h_C0;
+    // low-rank likelihood (gpb_like.hip, k_loglike_lowrank): C = C0 + A^T D A with C0 = C_trunc + C_exp fixed
+    double* lr_R = nullptr;        // [16][16] upper-triangular R of  L0^-1 A^T = Q R  (zero padded)
+    double* lr_v0 = nullptr;       // [16]     Q^T L0^-1 (mu - yexp)
+    double lr_cperp = 0.0;         // |(I - Q Q^T) L0^-1 (mu - yexp)|^2
+    double lr_logdet0 = 0.0;       // log det C0
+    bool lr_ok = false;
+    int lowrank = 1;               // use it when it applies (tune key 23)
     double* A = nullptr;           // [P][M]
     double* mu = nullptr;          // [M]
     double* scale = nullptr;       // [M]

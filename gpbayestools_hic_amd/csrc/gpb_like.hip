@@ -502,6 +502,118 @@ static int launch_loglike_wg(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accum
     return 0;
 }
 
+// ------------------------------------------------------------------ low-rank block log-likelihood, one lane per walker
+// C_w = C0 + A^T diag(var_w) A with the same C0 for every walker (gpb_api.hip: lowrank_setup has the algebra):
+//     loglike_w = -1/2 (c_perp + v^T S^-1 v) - 1/2 (log det C0 + log det S),   S = I + R diag(var_w) R^T,  v = R m_w + v0
+// a PP x PP Cholesky in one lane's registers instead of the M x M one (M = 64: 90 k flops and a 64-column
+// dependency chain per walker; here ~1 k flops).  R is upper triangular, so row i of R touches p >= i only.
+// Same conventions as the dense kernels: a non-positive pivot inside the box gives NaN and counts in notpd; the
+// fused k_finalize sums (part) use k_finalize's order.
+template <int PP>
+__global__ __launch_bounds__(64) void k_loglike_lowrank(const double* __restrict__ mean_pc,
+                                                        const double* __restrict__ var_pc, int64_t Wld, int64_t W,
+                                                        int P, const double* __restrict__ Rg,
+                                                        const double* __restrict__ v0g, double cperp, double logdet0,
+                                                        double* __restrict__ ll, int accumulate,
+                                                        int* __restrict__ notpd, BoxArgs box, PartArgs part) {
+    __shared__ double sR[PP][PP + 1];
+    __shared__ double sv0[PP];
+    for (int e = threadIdx.x; e < PP * PP; e += 64) sR[e / PP][e % PP] = Rg[(e / PP) * 16 + (e % PP)];
+    if (threadIdx.x < PP) sv0[threadIdx.x] = v0g[threadIdx.x];
+    __syncthreads();
+    const int64_t w = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (w >= W) return;
+    double m[PP], g[PP];
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+        m[p] = 0.0; g[p] = 0.0;
+        if (p < P) {
+            if (part.mpart) {
+                double a = 0.0, sq = 0.0;
+                for (int c = 0; c < part.nchunk; ++c) a += part.mpart[((int64_t)c * P + p) * Wld + w];
+                for (int i = 0; i < part.nI64; ++i) sq += part.spart[((int64_t)i * P + p) * Wld + w];
+                m[p] = a;
+                g[p] = (part.amp[p] + part.noise[p]) - sq;
+            } else {
+                m[p] = mean_pc[(int64_t)p * Wld + w];
+                g[p] = var_pc[(int64_t)p * Wld + w];
+            }
+        }
+    }
+    bool inside = true;
+    if (box.X) {
+        for (int k = 0; k < box.d; ++k) {
+            const double x = box.X[w * box.d + k];
+            inside = inside && (x > box.lo[k]) && (x < box.hi[k]);
+        }
+    }
+    // S (lower triangle, registers) and v
+    double S[PP][PP], v[PP];
+#pragma unroll
+    for (int i = 0; i < PP; ++i) {
+        double vi = sv0[i];
+#pragma unroll
+        for (int p = i; p < PP; ++p) vi = fma(sR[i][p], m[p], vi);
+        v[i] = vi;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double sij = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int p = i; p < PP; ++p) sij = fma(sR[i][p] * g[p], sR[j][p], sij);
+            S[i][j] = sij;
+        }
+    }
+    // Cholesky + forward solve, column by column
+    double q = 0.0, prod = 1.0;              // S >= I, so the pivots are >= 1: their product cannot underflow
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < PP; ++j) {
+        const double ajj = S[j][j];
+        bad = bad || !(ajj > 0.0);
+        const double rinv = rsqrt(ajj);
+        const double zj = v[j] * rinv;
+        q = fma(zj, zj, q);
+        prod *= ajj;
+#pragma unroll
+        for (int i = j + 1; i < PP; ++i) {
+            const double lij = S[i][j] * rinv;
+            v[i] = fma(-lij, zj, v[i]);
+#pragma unroll
+            for (int k = j + 1; k <= i; ++k) S[i][k] = fma(-lij, S[k][j] * rinv, S[i][k]);
+        }
+    }
+    double r = -0.5 * (cperp + q) - 0.5 * (logdet0 + log(prod));
+    if (bad && inside) {
+        r = nan("");
+        atomicAdd(notpd, 1);
+    }
+    r = accumulate ? (ll[w] + r) : r;
+    if (box.X) r = inside ? (r + box.inside_const) : box.outside;
+    ll[w] = r;
+}
+
+static bool lowrank_applies(const gpb_ctx* ctx) {
+    return ctx->lowrank && ctx->lr_ok && ctx->mode == GPB_MODE_PCA && ctx->P <= 16 && !ctx->force_generic_mvn;
+}
+
+static int launch_loglike_lowrank(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, const BoxArgs& box,
+                                  const PartArgs& part) {
+    const dim3 grid((unsigned)((W + 63) / 64));
+#define GPB_LR(PPV)                                                                                              \
+    hipLaunchKernelGGL(k_loglike_lowrank<PPV>, grid, dim3(64), 0, ctx->stream, ctx->mean_pc, ctx->var_pc, ctx->Wcap, \
+                       W, (int)ctx->P, ctx->lr_R, ctx->lr_v0, ctx->lr_cperp, ctx->lr_logdet0, ll_dev,              \
+                       accumulate ? 1 : 0, ctx->notpd, box, part)
+    switch (ctx->P) {                        // exact sizes: the work per walker grows with PP^3
+        case 1: GPB_LR(1); break;   case 2: GPB_LR(2); break;   case 3: GPB_LR(3); break;   case 4: GPB_LR(4); break;
+        case 5: GPB_LR(5); break;   case 6: GPB_LR(6); break;   case 7: GPB_LR(7); break;   case 8: GPB_LR(8); break;
+        case 9: GPB_LR(9); break;   case 10: GPB_LR(10); break; case 11: GPB_LR(11); break; case 12: GPB_LR(12); break;
+        case 13: GPB_LR(13); break; case 14: GPB_LR(14); break; case 15: GPB_LR(15); break; default: GPB_LR(16); break;
+    }
+#undef GPB_LR
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
 __global__ void k_box(const double* __restrict__ X, int64_t W, int d, const double* __restrict__ lo,
                       const double* __restrict__ hi, double outside, double inside_const, double* __restrict__ ll);
 
@@ -515,6 +627,7 @@ static bool block_kernels_apply(const gpb_ctx* ctx) {
 // walkers the per-walker strided reads of the partials cost more than the coalesced k_finalize they replace
 // (measured: +25 us on k_loglike_reg<64> at 2048 walkers against a 6.6 us kernel).
 bool loglike_fuses_finalize(const gpb_ctx* ctx, int64_t W) {
+    if (lowrank_applies(ctx)) return false;      // one lane per walker: k_finalize's coalesced sums are the faster way
     return block_kernels_apply(ctx) && ctx->P <= 32 && ctx->fuse_finalize && W <= ctx->mvn_wg_switch;
 }
 
@@ -523,11 +636,12 @@ int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, boo
     const int64_t M = ctx->M, P = ctx->P;
     const BoxArgs box{X_box, lo_dev, hi_dev, (int)ctx->d, outside, inside_const};
     if (from_partials && !loglike_fuses_finalize(ctx, W)) GPB_FAIL(GPB_E_STATE, "gpb: internal: partials without a fused consumer");
-    if (block_kernels_apply(ctx)) {
+    if (lowrank_applies(ctx) || block_kernels_apply(ctx)) {
         PartArgs part{nullptr, nullptr, nullptr, nullptr, 0, 0};
         if (from_partials)
             part = PartArgs{ctx->mpart, ctx->spart, ctx->amp, ctx->noise,
                             (int)((ctx->Np + KX_CHUNK - 1) / KX_CHUNK), (int)(ctx->Np / 64)};
+        if (lowrank_applies(ctx)) return launch_loglike_lowrank(ctx, W, ll_dev, accumulate, box, part);
         if (M <= 8) return launch_loglike_reg<8>(ctx, W, ll_dev, accumulate, box, part);
         if (M <= 16) return launch_loglike_reg<16>(ctx, W, ll_dev, accumulate, box, part);
         if (M <= 32) return launch_loglike_reg<32>(ctx, W, ll_dev, accumulate, box, part);

@@ -220,7 +220,8 @@ int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
  * 18 = cross-kernel distances as |a|^2 + |b|^2 - 2 a.b on centred coordinates (1, default) or as d differences (0);
  * 19 = 64-row chunks of the design per cross-kernel workgroup (0 = by grid size); 20 = walkers per lane there (1, 2);
  * 21 = 64-row predict tiles always launch static (1, default) or only when co-resident (0);
- * 22 = 64x128 predict tiles when at least this many of them exist per 256 CUs. */
+ * 22 = 64x128 predict tiles when at least this many of them exist per 256 CUs;
+ * 23 = low-rank form of the block log-likelihood when it applies (1, default) or the dense M x M kernels (0). */
 int gpb_debug_tune(gpb_ctx* ctx, int key, int value);
 /* debug hook: per-tile placement and timing of the predict kernel.  capacity > 0 arms (and clears) a trace of
  * that many records, 0 disarms; read copies up to max_records records of 8 uint32 {HW_ID register, XCC_ID,

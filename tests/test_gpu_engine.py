@@ -193,8 +193,16 @@ def test_loglike_fast_and_generic_paths(eng, M, P):
     Xw = synth.walkers(W, d, seed=5)
     mY, mC = oe.predict(Xw, True, np.zeros(W))
     ref = np.array([O.mvn_loglike(a, c) for a, c in zip(mY - yexp, mC + cexp)])
+    # default for P <= 16: the low-rank form (a P x P Cholesky per walker: C = C0 + A^T D A with the same C0 for all)
+    lowrank = eng.loglike(Xw).copy()
+    assert eng.last_not_pd == 0
+    assert relerr(lowrank, ref) < 1e-10
+    acc = eng.loglike(Xw, out=np.full(W, 2.5), accumulate=True)
+    assert relerr(acc, lowrank + 2.5) < 1e-13
+    eng.tune("lowrank", 0)                                       # the dense M x M kernels from here on
     fast = eng.loglike(Xw).copy()
     assert eng.last_not_pd == 0
+    assert relerr(lowrank, fast) < 1e-12
     # the block kernels sum the predict partials themselves in k_finalize's order: same bits with and without the fusion
     eng.tune("fuse_finalize", 0); unfused = eng.loglike(Xw).copy(); eng.tune("fuse_finalize", 1)
     assert np.array_equal(unfused, fast)
@@ -213,6 +221,30 @@ def test_loglike_fast_and_generic_paths(eng, M, P):
     # accumulate=True adds onto an existing vector (multi-emulator blocks)
     acc = eng.loglike(Xw, out=np.full(W, 2.5), accumulate=True)
     assert relerr(acc, fast + 2.5) < 1e-13
+    eng.tune("lowrank", 1)
+
+
+def test_lowrank_loglike_reports_indefinite_covariances_like_the_dense_kernels(eng):
+    """The low-rank form needs C0 = C_trunc + C_exp positive definite.  Nearly singular C0: both forms agree;
+    indefinite C0: the set-up declines, the dense kernel runs and reports every row (NaN + count)."""
+    from oracle import gp_oracle as O
+    from gpbayestools_hic_amd import synth
+    from gpbayestools_hic_amd.engine import MODE_PCA
+    N, d, M, P, W = 128, 5, 12, 4, 150
+    X = synth.lhs(N, d, seed=3); Y = synth.observables(X, M, seed=4)
+    oe = O.OracleEmulator(X, Y, np.zeros(d), np.ones(d), P).fit(synth.fixed_theta(d, P))
+    eng.set_data(X, oe.Z.T, "RBF", 0.1); eng.set_theta(oe.thetas); eng.factor()
+    # a nearly singular C0 (1e-9 I + 1e-9 I): the hardest conditioning the low-rank set-up can be handed
+    eng.set_transform(MODE_PCA, oe.mu, A=oe.A, cov_trunc=1e-9 * np.eye(M))
+    yexp = oe.predict(synth.truth_point(d)[None, :], return_cov=False)[0]
+    eng.set_likelihood(yexp, 1e-9 * np.eye(M))
+    Xw = synth.walkers(W, d, seed=8)
+    ok_lr = eng.loglike(Xw).copy(); n_lr = eng.last_not_pd
+    eng.tune("lowrank", 0); ok_dn = eng.loglike(Xw).copy(); n_dn = eng.last_not_pd; eng.tune("lowrank", 1)
+    assert n_lr == 0 and n_dn == 0 and relerr(ok_lr, ok_dn) < 1e-10
+    eng.set_likelihood(yexp, -0.5 * np.eye(M))                   # C0 not positive definite: the low-rank set-up
+    bad = eng.loglike(Xw)                                        # declines and the dense kernel reports the rows
+    assert eng.last_not_pd == W and np.all(np.isnan(bad))
 
 
 # ---------------------------------------------------------------- 64x64 tile variant (small walker batches / multi-GPU shards)
