@@ -510,30 +510,42 @@ static int launch_loglike_wg(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accum
 // Same conventions as the dense kernels: a non-positive pivot inside the box gives NaN and counts in notpd; the
 // fused k_finalize sums (part) use k_finalize's order.
 template <int PP>
-__global__ __launch_bounds__(64) void k_loglike_lowrank(const double* __restrict__ mean_pc,
+__global__ __launch_bounds__(256) void k_loglike_lowrank(const double* __restrict__ mean_pc,
                                                         const double* __restrict__ var_pc, int64_t Wld, int64_t W,
                                                         int P, const double* __restrict__ Rg,
                                                         const double* __restrict__ v0g, double cperp, double logdet0,
                                                         double* __restrict__ ll, int accumulate,
                                                         int* __restrict__ notpd, BoxArgs box, PartArgs part) {
+    // 256 threads serve 64 walkers: the four waves share the fused k_finalize sums (wave q: GPs q, q+4, ...; the
+    // loads are coalesced along the walkers), wave 0 then does the per-walker algebra.
     __shared__ double sR[PP][PP + 1];
     __shared__ double sv0[PP];
-    for (int e = threadIdx.x; e < PP * PP; e += 64) sR[e / PP][e % PP] = Rg[(e / PP) * 16 + (e % PP)];
+    __shared__ double smg[2][PP][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < PP * PP; e += 256) sR[e / PP][e % PP] = Rg[(e / PP) * 16 + (e % PP)];
     if (threadIdx.x < PP) sv0[threadIdx.x] = v0g[threadIdx.x];
+    const int64_t w = (int64_t)blockIdx.x * 64 + lane;
+    if (part.mpart && w < W) {
+        for (int p = grp; p < P; p += 4) {
+            double a = 0.0, sq = 0.0;
+#pragma unroll 8
+            for (int c = 0; c < part.nchunk; ++c) a += part.mpart[((int64_t)c * P + p) * Wld + w];
+#pragma unroll 8
+            for (int i = 0; i < part.nI64; ++i) sq += part.spart[((int64_t)i * P + p) * Wld + w];
+            smg[0][p][lane] = a;
+            smg[1][p][lane] = (part.amp[p] + part.noise[p]) - sq;
+        }
+    }
     __syncthreads();
-    const int64_t w = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (w >= W) return;
+    if (grp != 0 || w >= W) return;
     double m[PP], g[PP];
 #pragma unroll
     for (int p = 0; p < PP; ++p) {
         m[p] = 0.0; g[p] = 0.0;
         if (p < P) {
             if (part.mpart) {
-                double a = 0.0, sq = 0.0;
-                for (int c = 0; c < part.nchunk; ++c) a += part.mpart[((int64_t)c * P + p) * Wld + w];
-                for (int i = 0; i < part.nI64; ++i) sq += part.spart[((int64_t)i * P + p) * Wld + w];
-                m[p] = a;
-                g[p] = (part.amp[p] + part.noise[p]) - sq;
+                m[p] = smg[0][p][lane];
+                g[p] = smg[1][p][lane];
             } else {
                 m[p] = mean_pc[(int64_t)p * Wld + w];
                 g[p] = var_pc[(int64_t)p * Wld + w];
@@ -600,7 +612,7 @@ static int launch_loglike_lowrank(gpb_ctx* ctx, int64_t W, double* ll_dev, bool 
                                   const PartArgs& part) {
     const dim3 grid((unsigned)((W + 63) / 64));
 #define GPB_LR(PPV)                                                                                              \
-    hipLaunchKernelGGL(k_loglike_lowrank<PPV>, grid, dim3(64), 0, ctx->stream, ctx->mean_pc, ctx->var_pc, ctx->Wcap, \
+    hipLaunchKernelGGL(k_loglike_lowrank<PPV>, grid, dim3(256), 0, ctx->stream, ctx->mean_pc, ctx->var_pc, ctx->Wcap, \
                        W, (int)ctx->P, ctx->lr_R, ctx->lr_v0, ctx->lr_cperp, ctx->lr_logdet0, ll_dev,              \
                        accumulate ? 1 : 0, ctx->notpd, box, part)
     switch (ctx->P) {                        // exact sizes: the work per walker grows with PP^3
@@ -627,7 +639,7 @@ static bool block_kernels_apply(const gpb_ctx* ctx) {
 // walkers the per-walker strided reads of the partials cost more than the coalesced k_finalize they replace
 // (measured: +25 us on k_loglike_reg<64> at 2048 walkers against a 6.6 us kernel).
 bool loglike_fuses_finalize(const gpb_ctx* ctx, int64_t W) {
-    if (lowrank_applies(ctx)) return false;      // one lane per walker: k_finalize's coalesced sums are the faster way
+    if (lowrank_applies(ctx)) return ctx->fuse_finalize != 0;     // the kernel's four waves share k_finalize's sums
     return block_kernels_apply(ctx) && ctx->P <= 32 && ctx->fuse_finalize && W <= ctx->mvn_wg_switch;
 }
 

@@ -197,6 +197,8 @@ def test_loglike_fast_and_generic_paths(eng, M, P):
     lowrank = eng.loglike(Xw).copy()
     assert eng.last_not_pd == 0
     assert relerr(lowrank, ref) < 1e-10
+    eng.tune("fuse_finalize", 0); lr_unfused = eng.loglike(Xw).copy(); eng.tune("fuse_finalize", 1)
+    assert np.array_equal(lr_unfused, lowrank)                   # the fused k_finalize sums keep k_finalize's order
     acc = eng.loglike(Xw, out=np.full(W, 2.5), accumulate=True)
     assert relerr(acc, lowrank + 2.5) < 1e-13
     eng.tune("lowrank", 0)                                       # the dense M x M kernels from here on
