@@ -174,7 +174,8 @@ def test_lml_gradient_matches_oracle_and_finite_difference(eng):
 
 
 # ---------------------------------------------------------------- fused log-likelihood: both MVN kernels vs the oracle
-@pytest.mark.parametrize("M,P", [(4, 4), (13, 5), (32, 10), (41, 7), (64, 10), (64, 3), (100, 6)])
+@pytest.mark.parametrize("M,P", [(4, 4), (13, 5), (32, 10), (41, 7), (64, 10), (64, 3), (100, 6),
+                                 (20, 1), (24, 16), (24, 17), (3, 3)])      # low-rank form: P = 1, its largest P, one beyond
 def test_loglike_fast_and_generic_paths(eng, M, P):
     from oracle import gp_oracle as O
     from gpbayestools_hic_amd import synth
