@@ -52,42 +52,64 @@ class WalkerSharding:
         """Route the all-gather through the C ABI's own RCCL communicator (gpb_dist_*: ncclAllGather enqueued
         directly on the kernels' stream, no second stream and no event hops).  Collective: rank 0 creates the
         ncclUniqueId, torch.distributed carries it to the others.  bench.py goes through try_direct (below)."""
-        box = [engine.dist_uid() if self.rank == 0 else None]
+        uid = None
+        if self.rank == 0:
+            try:
+                uid = engine.dist_uid()
+            except Exception:           # still take part in the broadcast: every rank must see the same outcome
+                uid = None
+        box = [uid]
         self.dist.broadcast_object_list(box, src=0, group=self.group)
+        if box[0] is None:
+            raise RuntimeError("rank 0 could not create a ncclUniqueId (librccl not loadable?)")
         engine.dist_init(self.rank, self.world, box[0])
         self.direct = engine
         return self
 
+    def _all_ok(self, ok):
+        import torch
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return int(t.item()) == 1
+
+    def _drop_direct(self):
+        if self.direct is not None:
+            try:
+                self.direct.dist_finalize()
+            except Exception:
+                pass
+        self.direct = None
+
     def try_direct(self, engine):
         """enable_direct + a self-check against torch.distributed's all-gather on a test vector; every rank
         keeps the direct path only if it worked on ALL ranks.  Returns None when direct is on, else the reason
-        (the exchange then stays on torch.distributed — both are RCCL, nothing leaves the GPUs)."""
+        (the exchange then stays on torch.distributed — both are RCCL, nothing leaves the GPUs).  The ranks agree
+        after each stage, so that they always issue the same sequence of collectives."""
         import torch
         why = None
         try:
             self.enable_direct(engine)
-            n, dev = 64, torch.device("cuda", torch.cuda.current_device())
-            mine = torch.arange(n, dtype=torch.float64, device=dev) + 1000.0 * self.rank
-            ref = torch.empty(n * self.world, dtype=torch.float64, device=dev)
-            self.dist.all_gather_into_tensor(ref, mine, group=self.group)
+        except Exception as e:          # missing librccl, ncclCommInitRank refused, ...
+            why = "%s: %s" % (type(e).__name__, e)
+        if not self._all_ok(why is None):
+            self._drop_direct()
+            return why or "direct path could not be set up on another rank"
+        n, dev = 64, torch.device("cuda", torch.cuda.current_device())
+        mine = torch.arange(n, dtype=torch.float64, device=dev) + 1000.0 * self.rank
+        ref = torch.empty(n * self.world, dtype=torch.float64, device=dev)
+        self.dist.all_gather_into_tensor(ref, mine, group=self.group)
+        try:
             got = torch.full_like(ref, -1.0)
             got[self.rank * n:(self.rank + 1) * n] = mine
             engine.dist_allgather(got[self.rank * n:(self.rank + 1) * n], got)
             torch.cuda.synchronize()
             if not torch.equal(ref, got):
                 why = "direct all-gather disagrees with torch.distributed"
-        except Exception as e:      # missing librccl, ncclCommInitRank refused, ...
+        except Exception as e:
             why = "%s: %s" % (type(e).__name__, e)
-        ok = torch.tensor([0 if why else 1], dtype=torch.int32, device="cuda")
-        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=self.group)
-        if int(ok.item()) == 0:
-            if self.direct is not None:
-                try:
-                    self.direct.dist_finalize()
-                except Exception:
-                    pass
-            self.direct = None
-            return why or "direct path failed on another rank"
+        if not self._all_ok(why is None):
+            self._drop_direct()
+            return why or "direct all-gather failed its self-check on another rank"
         return None
 
     def rows(self, W):
