@@ -20,8 +20,9 @@ c_i64 = C.c_int64
 c_u64 = C.c_uint64
 VP = C.c_void_p
 
-# name -> (restype, argtypes); mirrors include/gpbayes.h one to one
-PROTOTYPES = {
+# name -> (restype, argtypes); BOUNDARY mirrors include/gpbayes.h one to one (the drop-in C ABI), DEBUG mirrors
+# include/gpbayes_debug.h (test / tuning / measurement hooks)
+BOUNDARY = {
     "gpb_version": (C.c_int, []),
     "gpb_device_count": (C.c_int, []),
     "gpb_ctx_create": (C.c_int, [C.c_int, VP, C.POINTER(VP)]),
@@ -48,11 +49,15 @@ PROTOTYPES = {
     "gpb_param_map": (C.c_int, [VP, VP, c_i64, VP]),
     "gpb_stretch_propose": (C.c_int, [VP, VP, c_i64, c_i64, C.c_int, c_u64, c_u64, C.c_double, VP, VP, C.c_int]),
     "gpb_stretch_accept": (C.c_int, [VP, VP, VP, c_i64, c_i64, C.c_int, c_u64, c_u64, VP, VP, VP, VP, C.c_int]),
-    "gpb_test_split_perm": (C.c_int, [VP, c_i64, c_u64, c_u64, VP]),
     "gpb_dist_uid": (C.c_int, [VP]),
     "gpb_dist_init": (C.c_int, [VP, C.c_int, C.c_int, VP]),
     "gpb_dist_allgather": (C.c_int, [VP, VP, VP, c_i64]),
     "gpb_dist_finalize": (C.c_int, [VP]),
+}
+DEBUG = {
+    "gpb_test_split_perm": (C.c_int, [VP, c_i64, c_u64, c_u64, VP]),
+    "gpb_test_philox": (C.c_int, [VP, c_i64, VP, VP]),
+    "gpb_test_stretch_draws": (C.c_int, [VP, c_i64, C.c_int, c_u64, c_u64, C.c_int, VP, VP, VP, VP]),
     "gpb_test_gemm": (C.c_int, [VP, c_i64, c_i64, c_i64, VP, VP, VP, C.c_int]),
     "gpb_debug_force_tile": (C.c_int, [VP, C.c_int, c_i64]),
     "gpb_debug_tune": (C.c_int, [VP, C.c_int, C.c_int]),
@@ -63,6 +68,7 @@ PROTOTYPES = {
     "gpb_profile_read": (C.c_int, [VP, VP, VP, VP]),
     "gpb_probe_fp64": (C.c_int, [VP, C.c_int, VP]),
 }
+PROTOTYPES = dict(BOUNDARY, **DEBUG)
 
 _lib = None
 

@@ -1,5 +1,7 @@
 // gpb_api.hip — C-ABI entry points (include/gpbayes.h): state management, host<->HBM staging,
-// and kernel sequencing on the context's HIP stream.  No compute happens on the host.
+// and kernel sequencing on the context's HIP stream.  Every per-row number is produced by the kernels; the one
+// piece of host arithmetic is lowrank_setup: an M x M long-double Cholesky + thin QR, once per gpb_like_set (O(M^3):
+// callers that re-set the likelihood per batch pay it every time).
 #include "gpb_internal.h"
 #include <dlfcn.h>
 #include <math.h>
@@ -162,6 +164,14 @@ extern "C" int gpb_gp_set(gpb_ctx* ctx, int64_t N, int64_t d, int64_t P, const d
     ctx->N = N; ctx->d = d; ctx->P = P; ctx->dpad = dpad; ctx->kind = kernel_id; ctx->alpha_reg = alpha;
     ctx->Np = round_up(N, NB);
     ctx->have_theta = ctx->factored = false;
+    // whatever was installed for the previous GPs (observable transform sized [old P][M], likelihood block, low-rank
+    // factors, parameter map) does not describe the new ones: it has to be set again
+    ctx->have_transform = ctx->have_like = ctx->lr_ok = false;
+    ctx->M = 0;
+    dev_free(&ctx->A); dev_free(&ctx->mu); dev_free(&ctx->scale); dev_free(&ctx->C0); dev_free(&ctx->yexp);
+    dev_free(&ctx->Cexp); dev_free(&ctx->lr_R); dev_free(&ctx->lr_v0); dev_free(&ctx->pmap_int); dev_free(&ctx->pmap_tab);
+    ctx->h_A.clear(); ctx->h_mu.clear(); ctx->h_C0.clear();
+    ctx->pmap_d_in = ctx->pmap_d_out = 0; ctx->pmap_groups = ctx->pmap_maxpc = 0;
     const int64_t Np = ctx->Np;
     // workspaces sized by (Np, P) are stale now
     dev_free(&ctx->KsT); dev_free(&ctx->mpart); dev_free(&ctx->spart); dev_free(&ctx->mean_pc);
@@ -256,8 +266,9 @@ extern "C" int gpb_gp_factor(gpb_ctx* ctx, int* info_host) {
     if (!ctx) return GPB_E_ARG;
     int rc = factor_impl(ctx, info_host, true);
     if (rc < 0) return rc;
-    ctx->factored = true;        // per-GP failures are reported through info / the return code
-    if (rc > 0) ctx->err = "gpb_gp_factor: kernel matrix not positive definite (see info)";
+    // a failed GP leaves NaNs in L, L^-1 and alpha: the predict / likelihood entry points refuse to run on them
+    ctx->factored = rc == 0;
+    if (rc > 0) ctx->err = "gpb_gp_factor: kernel matrix not positive definite (see info); no factorisation installed";
     return rc;
 }
 
@@ -311,6 +322,7 @@ extern "C" int gpb_gp_lml(gpb_ctx* ctx, const double* theta_host, double* lml_ho
         if (info_host) info_host[p] = info[p];
     }
     ctx->factored = true;
+    for (int64_t p = 0; p < P; ++p) if (info[p] != 0) ctx->factored = false;     // see gpb_gp_factor
     return 0;
 }
 
@@ -685,7 +697,7 @@ extern "C" int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles
 }
 
 // Launch-geometry knobs (never change a result); the key list is documented with the declaration in
-// include/gpbayes.h and mirrored by GPEngine.tune() in engine.py.
+// include/gpbayes_debug.h and mirrored by GPEngine.tune() in engine.py.
 extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
     if (!ctx) return GPB_E_ARG;
     switch (key) {

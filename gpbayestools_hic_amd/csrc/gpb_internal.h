@@ -6,6 +6,7 @@
 #include <utility>
 #include <vector>
 #include "../../include/gpbayes.h"
+#include "../../include/gpbayes_debug.h"
 
 namespace gpb {
 

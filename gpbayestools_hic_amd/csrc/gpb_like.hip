@@ -576,7 +576,10 @@ __global__ __launch_bounds__(256) void k_loglike_lowrank(const double* __restric
         }
     }
     // Cholesky + forward solve, column by column
-    double q = 0.0, prod = 1.0;              // S >= I, so the pivots are >= 1: their product cannot underflow
+    // log det S = sum of log pivots, four pivots per logarithm like the dense kernels (S >= I, so the pivots are >= 1
+    // and a product cannot underflow; four of them overflow only beyond 1e77 each, i.e. never for a C0 that factorises
+    // in fp64, whereas all PP <= 16 in one product overflowed from 1e19 per pivot: C0 ~ 1e-20 * I)
+    double q = 0.0, prod = 1.0, logsum = 0.0;
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < PP; ++j) {
@@ -586,6 +589,7 @@ __global__ __launch_bounds__(256) void k_loglike_lowrank(const double* __restric
         const double zj = v[j] * rinv;
         q = fma(zj, zj, q);
         prod *= ajj;
+        if ((j & 3) == 3 || j == PP - 1) { logsum += log(prod); prod = 1.0; }
 #pragma unroll
         for (int i = j + 1; i < PP; ++i) {
             const double lij = S[i][j] * rinv;
@@ -594,7 +598,8 @@ __global__ __launch_bounds__(256) void k_loglike_lowrank(const double* __restric
             for (int k = j + 1; k <= i; ++k) S[i][k] = fma(-lij, S[k][j] * rinv, S[i][k]);
         }
     }
-    double r = -0.5 * (cperp + q) - 0.5 * (logdet0 + log(prod));
+    double r = -0.5 * (cperp + q) - 0.5 * (logdet0 + logsum);
+    bad = bad || !(logsum < INFINITY);       // an overflowing pivot product is a failure, not a silent -inf
     if (bad && inside) {
         r = nan("");
         atomicAdd(notpd, 1);
@@ -801,6 +806,7 @@ __global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, 
                           int randomize) {
     // 32 lanes per walker (one parameter each): these kernels sit between the log-probability batches of a
     // step, so they are organised for latency, not for thread economy — every lane redoes the walker's draws
+#pragma clang fp contract(off)       // emcee's arithmetic rounds every product: no fused multiply-adds in here
     const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t k = gid >> 5;
     const int t0 = (int)(gid & 31);
@@ -808,8 +814,10 @@ __global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, 
     const SplitPerm pi = make_perm(seed, step, 2 * nhalf, hb, randomize);
     const U4 r = philox(seed, (uint32_t)k, step, (uint32_t)half, 0u);
     const double u = u01(r.x, r.y);
+    // emcee StretchMove.get_proposal, operation for operation:
+    //   zz = ((a - 1) * u + 1) ** 2 / a ;  q = c - (c - s) * zz ;  factor = (ndim - 1) * log(zz)
     const double zs = (a - 1.0) * u + 1.0;
-    const double zz = zs * zs / a;                                   // emcee StretchMove.get_proposal
+    const double zz = (zs * zs) / a;
     const int64_t j = (int64_t)(((uint64_t)r.z * (uint64_t)nhalf) >> 32);
     const double* s = pos + pi(2 * k + half) * d;
     const double* c = pos + pi(2 * j + (1 - half)) * d;
@@ -822,6 +830,7 @@ __global__ void k_accept(double* __restrict__ pos, double* __restrict__ lp, int6
                          long long* __restrict__ naccept, int hb, int randomize) {
     // 32 lanes per walker, all inside one wave: every lane takes the same decision from the OLD lp[idx]
     // (the load precedes lane 0's store in program order), then moves its own parameters
+#pragma clang fp contract(off)
     const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t k = gid >> 5;
     const int t0 = (int)(gid & 31);
@@ -831,8 +840,8 @@ __global__ void k_accept(double* __restrict__ pos, double* __restrict__ lp, int6
     const double u = u01(r.x, r.y);
     const int64_t idx = pi(2 * k + half);
     const double lpq_k = lpq[k];
-    const double diff = factor[k] + lpq_k - lp[idx];
-    const bool take = diff > log(u);                                 // emcee RedBlueMove.propose
+    const double diff = (factor[k] + lpq_k) - lp[idx];
+    const bool take = diff > log(u);                                 // emcee RedBlueMove.propose: f + nlp - lp[j] > log(rand)
     __builtin_amdgcn_wave_barrier();                                 // keep the loads above the stores below
     if (take) {
         for (int t = t0; t < d; t += 32) pos[idx * d + t] = q[k * d + t];
@@ -841,6 +850,28 @@ __global__ void k_accept(double* __restrict__ pos, double* __restrict__ lp, int6
             if (naccept) naccept[idx] += 1;
         }
     }
+}
+
+// test hooks: the generator and the draws of a (seed, step, half), for the parity tests against the oracle
+__global__ void k_philox_test(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* v = in + 6 * i;
+    const U4 r = philox((uint64_t)v[0] | ((uint64_t)v[1] << 32), v[2], v[3], v[4], v[5]);
+    out[4 * i + 0] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+}
+__global__ void k_stretch_draws(int64_t nhalf, int half, uint64_t seed, uint32_t step, int hb, int randomize,
+                                double* __restrict__ u_z, long long* __restrict__ jj, double* __restrict__ u_acc,
+                                long long* __restrict__ perm) {
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k >= 2 * nhalf) return;
+    perm[k] = make_perm(seed, step, 2 * nhalf, hb, randomize)(k);
+    if (k >= nhalf) return;
+    const U4 r = philox(seed, (uint32_t)k, step, (uint32_t)half, 0u);           // as k_propose
+    u_z[k] = u01(r.x, r.y);
+    jj[k] = (long long)(((uint64_t)r.z * (uint64_t)nhalf) >> 32);
+    const U4 ra = philox(seed, (uint32_t)k, step, (uint32_t)half, 1u);          // as k_accept
+    u_acc[k] = u01(ra.x, ra.y);
 }
 
 // test hook: out[i] = pi_step(i)
@@ -902,6 +933,34 @@ extern "C" int gpb_test_split_perm(gpb_ctx* ctx, int64_t n, uint64_t seed, uint6
     if (!ctx || n < 2 || n > (1ll << 30) || !out_dev) return GPB_E_ARG;
     hipLaunchKernelGGL(k_perm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                        reinterpret_cast<long long*>(out_dev), n, seed, (uint32_t)step, half_bits(n));
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gpb_test_philox(gpb_ctx* ctx, int64_t n, const uint32_t* in_host, uint32_t* out_host) {
+    if (!ctx || n < 1 || n > (1 << 20) || !in_host || !out_host) return GPB_E_ARG;
+    GPB_HIP(hipSetDevice(ctx->device));
+    uint32_t *din = nullptr, *dout = nullptr;
+    GPB_HIP(hipMalloc(&din, sizeof(uint32_t) * 6 * n));
+    GPB_HIP(hipMalloc(&dout, sizeof(uint32_t) * 4 * n));
+    GPB_HIP(hipMemcpy(din, in_host, sizeof(uint32_t) * 6 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_philox_test, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, din, dout, n);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out_host, dout, sizeof(uint32_t) * 4 * n, hipMemcpyDeviceToHost);
+    (void)hipFree(din); (void)hipFree(dout);
+    GPB_HIP(e);
+    return 0;
+}
+
+extern "C" int gpb_test_stretch_draws(gpb_ctx* ctx, int64_t nwalkers, int half, uint64_t seed, uint64_t step,
+                                      int randomize_split, double* u_z_dev, int64_t* j_dev, double* u_acc_dev,
+                                      int64_t* perm_dev) {
+    if (!ctx || nwalkers < 2 || (nwalkers & 1) || nwalkers > (1ll << 30) || (half != 0 && half != 1) || !u_z_dev ||
+        !j_dev || !u_acc_dev || !perm_dev)
+        return GPB_E_ARG;
+    hipLaunchKernelGGL(k_stretch_draws, dim3((unsigned)((nwalkers + 255) / 256)), dim3(256), 0, ctx->stream,
+                       nwalkers / 2, half, seed, (uint32_t)step, half_bits(nwalkers), randomize_split ? 1 : 0, u_z_dev,
+                       reinterpret_cast<long long*>(j_dev), u_acc_dev, reinterpret_cast<long long*>(perm_dev));
     GPB_HIP(hipGetLastError());
     return 0;
 }

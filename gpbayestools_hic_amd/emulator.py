@@ -39,13 +39,55 @@ def _check_random_state(seed):
     raise ValueError("%r cannot be used to seed a numpy.random.RandomState instance" % seed)
 
 
+class FittedKernel:
+    """`gp.kernel_` of a fitted GP: the sklearn composite `c * RBF|Matern(length_scale) + WhiteKernel(noise_level)`
+    the reference builds (src/emulator.py:286-306), as a read-only view with the attributes and the printed form
+    the reference uses (`theta`, `bounds`, `'... kernel: {}'.format(gp.kernel_)`, src/emulator.py:320-328;
+    sk:kernels.py:887-888, 987-988, 1316-1317, 1437-1440, 1584-1593, 1783-1793)."""
+
+    def __init__(self, theta, bounds, kernel_type):
+        self.theta = np.array(theta, dtype=np.float64)          # [log c, log l_1..l_d, log noise]
+        self.bounds = np.array(bounds, dtype=np.float64)        # log-space, like sklearn's kernel_.bounds
+        self.kernel_type = kernel_type
+        self.nu = {"RBF": None, "Matern": 1.5, "Matern25": 2.5}[kernel_type]
+
+    @property
+    def n_dims(self):
+        return self.theta.shape[0]
+
+    @property
+    def constant_value(self):
+        return float(np.exp(self.theta[0]))
+
+    @property
+    def length_scale(self):
+        return np.exp(self.theta[1:-1])
+
+    @property
+    def noise_level(self):
+        return float(np.exp(self.theta[-1]))
+
+    def __repr__(self):
+        ls = self.length_scale
+        inner = "[{}]".format(", ".join(map("{0:.3g}".format, ls))) if ls.shape[0] > 1 else "{0:.3g}".format(ls[0])
+        stat = "RBF(length_scale={})".format(inner) if self.nu is None else \
+            "Matern(length_scale={}, nu={:.3g})".format(inner, self.nu)
+        return "{0:.3g}**2 * {1} + WhiteKernel(noise_level={2:.3g})".format(
+            np.sqrt(self.constant_value), stat, self.noise_level)
+
+
 class FittedGP:
-    """Read-only view of one fitted GP with the sklearn attribute names the reference reads
-    (SURVEY §8b B3): kernel_theta (= kernel_.theta), log_marginal_likelihood_value_, alpha_, L_,
-    X_train_, predict()."""
+    """Read-only view of one fitted GP with the sklearn estimator surface the reference reads off `self.gps[i]`
+    (src/emulator.py:309-328,553,621): kernel_, log_marginal_likelihood_value_, alpha_, L_,
+    X_train_, y_train_, predict(), score(), sample_y()."""
 
     def __init__(self, emu, index):
         self._emu, self._i = emu, index
+
+    @property
+    def kernel_(self):
+        emu = self._emu
+        return FittedKernel(emu.thetas_[self._i], emu._theta0_bounds(emu.kernel_type_)[1], emu.kernel_type_)
 
     @property
     def kernel_theta(self):
@@ -58,6 +100,10 @@ class FittedGP:
     @property
     def X_train_(self):
         return self._emu._X_train
+
+    @property
+    def y_train_(self):
+        return self._emu._Z_train[self._i]
 
     @property
     def alpha_(self):
@@ -77,6 +123,13 @@ class FittedGP:
             return mm[:, self._i], cc[self._i]
         return m
 
+    def score(self, X, y):
+        """Coefficient of determination R^2 of the predictive mean (sklearn RegressorMixin.score, which the
+        reference logs per GP: src/emulator.py:316-318): 1 - sum (y - mean)^2 / sum (y - ybar)^2."""
+        y = np.asarray(y, dtype=np.float64)
+        m = self.predict(X)
+        return float(1.0 - ((y - m) ** 2).sum() / ((y - y.mean()) ** 2).sum())
+
     def sample_y(self, X, n_samples=1, random_state=0):
         """Draw from the GP posterior at X (sk:_gpr.py:498-540): mean/covariance from the device, the
         draw itself is numpy's RandomState.multivariate_normal exactly as sklearn calls it."""
@@ -85,9 +138,7 @@ class FittedGP:
         return rng.multivariate_normal(mean, cov, n_samples).T
 
     def __repr__(self):
-        th = self.kernel_theta
-        return "{:.3g}**2 * k(length_scale={}) + White(noise_level={:.3g})".format(
-            np.sqrt(np.exp(th[0])), np.array2string(np.exp(th[1:-1]), precision=3), np.exp(th[-1]))
+        return "GaussianProcessRegressor(alpha={:g}, kernel={!r})".format(self._emu.alpha, self.kernel_)
 
 
 class Emulator:
@@ -235,6 +286,11 @@ class Emulator:
         zt = self._Z_train.T
         self.gp_scores_ = 1.0 - ((zt - m) ** 2).sum(0) / ((zt - zt.mean(0)) ** 2).sum(0)
         log.info("GP scores: %s", self.gp_scores_)
+        if not self.perform_no_PCA_:                  # the reference's per-GP summary line (src/emulator.py:320-328)
+            for n, gp in enumerate(self.gps):
+                log.info("GP %d: %.5f of variance, LML = %.5g, Score = %.2f, kernel: %s", n,
+                         self.pca.explained_variance_ratio_[n], gp.log_marginal_likelihood_value_,
+                         self.gp_scores_[n], gp.kernel_)
 
     def _optimise(self, eng, kernel_type):
         """argmax LML per GP with scipy L-BFGS-B (sk:_gpr.py:296-337,654-670).  The P searches
@@ -367,10 +423,10 @@ class Emulator:
         return np.dot(Z, self._trans_matrix[:Z.shape[-1]]) + self.scaler.mean_
 
     # ------------------------------------------------------------------ hold-out validation helpers
-    def _holdout(self, nTestPoints, on_training):
+    def _holdout(self, nTestPoints, on_training, thetas=None):
         mask = np.ones(self.nev, dtype=bool)
         mask[self.nev - nTestPoints:] = False
-        self.trainEmulator(mask)
+        self.trainEmulator(mask, thetas=thetas)
         vmask = mask if on_training else ~mask
         pred, cov = self.predict(self.design_points_org_[vmask], return_cov=True)
         perr = np.sqrt(np.diagonal(cov, axis1=1, axis2=2))
@@ -384,32 +440,38 @@ class Emulator:
         r = lambda a: np.array(a).reshape(-1, self.nobs)
         return r(pred), r(perr), r(truth), r(terr)
 
-    def testEmulatorErrors(self, nTestPoints=1):
-        """Train on the first nev-nTestPoints points, predict the rest (src/emulator.py:636-679)."""
-        return self._holdout(nTestPoints, on_training=False)
+    def testEmulatorErrors(self, nTestPoints=1, thetas=None):
+        """Train on the first nev-nTestPoints points, predict the rest (src/emulator.py:636-679): returns
+        (predictions, their errors, true values, their errors), each [nTestPoints, nobs].  `thetas` (extension)
+        skips the hyper-parameter search of the retraining, as in trainEmulator."""
+        return self._holdout(nTestPoints, on_training=False, thetas=thetas)
 
-    def testEmulatorErrorsWithTrainingPoints(self, nTestPoints=1):
+    def testEmulatorErrorsWithTrainingPoints(self, nTestPoints=1, thetas=None):
         """Same split, but predict the training points themselves (src/emulator.py:682-726)."""
-        return self._holdout(nTestPoints, on_training=True)
+        return self._holdout(nTestPoints, on_training=True, thetas=thetas)
 
 
 def search_hyperparameters(make_engine, P, theta0, bounds, nrestarts=0, sharding=None, close=False, rng=None):
     """theta*[P, d+2] and LML*[P]: L-BFGS-B from `theta0` plus `nrestarts` log-uniform starts per GP
-    (sk:_gpr.py:296-337).  `make_engine(idx)` returns an object whose `.lml(theta[len(idx), d+2],
+    (sk:_gpr.py:296-337); `rng`: None (numpy's global RandomState, as sklearn), an int seed or a RandomState.  `make_engine(idx)` returns an object whose `.lml(theta[len(idx), d+2],
     eval_gradient=True)` serves the GPs `idx`.  With `sharding` (dist.GPSharding, SURVEY §8e "fit-side") the
     P searches are dealt round-robin to the ranks and ONE all-gather puts every result on every rank; a GP's
     search does not depend on which other GPs share its batch, so the result is the unsharded one."""
     idx = np.arange(P) if sharding is None else sharding.mine(P)
     k = theta0.size
+    # restart points as sklearn draws them: GPR(random_state=None) takes numpy's GLOBAL RandomState (np.random.seed
+    # makes a fit reproducible) and draws, GP after GP, one log-uniform theta per restart (sk:_gpr.py:259,318-325).
+    # Every rank draws all P x nrestarts points and keeps its own, so a sharded fit equals the unsharded one.
+    rs = _check_random_state(rng)
+    draws = np.array([[rs.uniform(bounds[:, 0], bounds[:, 1]) for _ in range(int(nrestarts))] for _ in range(P)])
+    restart_points = [draws[:, r, :] for r in range(int(nrestarts))]
     best_theta = np.tile(theta0, (idx.size, 1))
     best_val = np.full(idx.size, np.inf)
     if idx.size:
         eng = make_engine(idx)
         try:
             starts = [np.tile(theta0, (idx.size, 1))]
-            rng = rng if rng is not None else np.random.default_rng()
-            for _ in range(int(nrestarts)):
-                starts.append(rng.uniform(bounds[:, 0], bounds[:, 1], size=(idx.size, k)))
+            starts += [s[idx] for s in restart_points]
             for start in starts:
                 th, val = _batched_lbfgsb(eng, start, bounds)
                 better = val < best_val

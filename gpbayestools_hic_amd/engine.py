@@ -33,14 +33,13 @@ class GPEngine:
         if rc != 0:
             raise nat.GPBError(f"gpb_ctx_create failed ({rc})")
         self.h = h
-        if stream == "torch":
-            import torch
-            with torch.cuda.device(int(device)):
-                s = torch.cuda.current_stream(int(device)).cuda_stream
-            self._ck(self.lib.gpb_ctx_set_stream(h, nat.VP(s)))
+        self.device = int(device)
+        self._follow_torch = stream == "torch"
+        self._stream = None
+        if self._follow_torch:
+            self._track_stream()
         elif stream is not None:
             self._ck(self.lib.gpb_ctx_set_stream(h, nat.VP(int(stream))))
-        self.device = int(device)
         self.N = self.d = self.P = self.M = 0
 
     # ------------------------------------------------------------------ plumbing
@@ -67,10 +66,56 @@ class GPEngine:
         if self.N == 0:
             raise nat.GPBError("no GP data: call set_data / set_theta / factor first")
 
-    def _check_cols(self, X_dev):
+    def _track_stream(self):
+        """stream="torch": the kernels must run on the stream torch allocates and frees the caller's tensors on.
+        Called at the top of every method that takes torch tensors: if torch's current stream of this device has
+        changed since the last call (`with torch.cuda.stream(s):`, a sampler on a side stream) the context is
+        re-targeted onto it (gpb_ctx_set_stream drains the old stream first, so work already enqueued is ordered
+        before anything that follows)."""
+        if not self._follow_torch:
+            return
+        import torch
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        if s != self._stream:
+            self._ck(self.lib.gpb_ctx_set_stream(self.h, nat.VP(s)))
+            self._stream = s
+
+    def _dev(self, x, shape, name, dtype="torch.float64", contiguous=True):
+        """Validate a tensor whose raw pointer goes to the C ABI as DEVICE memory: a wrong device, dtype, shape
+        or stride would be read by the kernels as an address (a GPU fault, not an exception).  `shape` entries
+        of None are free.  Returns the tensor (made contiguous when `contiguous` is False = input may be a view)."""
+        if not _is_torch(x):
+            raise ValueError("%s: expected a torch tensor, got %s" % (name, type(x).__name__))
+        if not x.is_cuda or x.device.index != self.device:
+            raise ValueError("%s: tensor lives on %s, the engine on cuda:%d" % (name, x.device, self.device))
+        if str(x.dtype) != dtype:
+            raise ValueError("%s: expected %s, got %s" % (name, dtype, x.dtype))
+        if x.dim() != len(shape) or any(s is not None and int(s) != int(n) for s, n in zip(shape, x.shape)):
+            raise ValueError("%s: expected shape %s, got %s" % (name, tuple(shape), tuple(x.shape)))
+        if not x.is_contiguous():
+            if contiguous:
+                raise ValueError("%s: must be contiguous" % name)
+            x = x.contiguous()
+        return x
+
+    def _check_cols(self, X_dev, name="X"):
         """device inputs are used as they are: the kernels index them with the engine's d"""
-        if X_dev.dim() != 2 or X_dev.shape[1] != self.d or str(X_dev.dtype) != "torch.float64":
-            raise ValueError("expected a float64 [W, %d] tensor, got %s %s" % (self.d, X_dev.dtype, tuple(X_dev.shape)))
+        self._track_stream()
+        return self._dev(X_dev, (None, self.d), name, contiguous=False)
+
+    def _extra_std_dev(self, extra_std, W):
+        """extra_std of the torch path as a device vector [W] (None = 0)"""
+        if extra_std is None:
+            return None
+        import torch
+        if _is_torch(extra_std):
+            if extra_std.dim() == 0:
+                extra_std = extra_std.reshape(1)
+            if extra_std.numel() == 1 and W != 1:
+                extra_std = extra_std.expand(W)
+            return self._dev(extra_std, (W,), "extra_std", contiguous=False)
+        es = np.array(np.broadcast_to(np.asarray(extra_std, dtype=np.float64).reshape(-1), (W,)))     # writable copy
+        return torch.as_tensor(es, device=torch.device("cuda", self.device))
 
     # ------------------------------------------------------------------ GP state
     def set_data(self, X, Z, kernel="RBF", alpha=0.1):
@@ -80,6 +125,7 @@ class GPEngine:
         self.P = Z.shape[0]
         assert Z.shape[1] == self.N
         kid = KERNEL_IDS[kernel] if isinstance(kernel, str) else int(kernel)
+        self.M, self.pmap_d_in, self.pmap_d_out = 0, -1, -1       # gpb_gp_set drops the transform, likelihood and map
         self._ck(self.lib.gpb_gp_set(self.h, self.N, self.d, self.P, nat.ptr(X), nat.ptr(Z), kid, float(alpha)))
 
     def set_theta(self, theta):
@@ -117,11 +163,11 @@ class GPEngine:
         self._need_data()
         if _is_torch(Xs):
             import torch
-            self._check_cols(Xs)
+            Xs = self._check_cols(Xs, "Xs")
             W = Xs.shape[0]
             mean = torch.empty((W, self.P), dtype=torch.float64, device=Xs.device)
             var = torch.empty((W, self.P), dtype=torch.float64, device=Xs.device) if return_var else None
-            self._ck(self.lib.gpb_gp_predict(self.h, nat.ptr(Xs.contiguous()), W, 1, nat.ptr(mean), nat.ptr(var)))
+            self._ck(self.lib.gpb_gp_predict(self.h, nat.ptr(Xs), W, 1, nat.ptr(mean), nat.ptr(var)))
             return (mean, var) if return_var else mean
         Xs = nat.f64(Xs).reshape(-1, self.d)
         W = Xs.shape[0]
@@ -154,12 +200,12 @@ class GPEngine:
         self._need_data()
         if _is_torch(Xs):
             import torch
-            self._check_cols(Xs)
+            Xs = self._check_cols(Xs, "Xs")
             W = Xs.shape[0]
+            es = self._extra_std_dev(extra_std, W)       # numbers / numpy are uploaded, tensors are validated
             mean = torch.empty((W, self.M), dtype=torch.float64, device=Xs.device)
             cov = torch.empty((W, self.M, self.M), dtype=torch.float64, device=Xs.device) if return_cov else None
-            self._ck(self.lib.gpb_emu_predict(self.h, nat.ptr(Xs.contiguous()), W, 1, nat.ptr(extra_std),
-                                              nat.ptr(mean), nat.ptr(cov)))
+            self._ck(self.lib.gpb_emu_predict(self.h, nat.ptr(Xs), W, 1, nat.ptr(es), nat.ptr(mean), nat.ptr(cov)))
             return (mean, cov) if return_cov else mean
         Xs = nat.f64(Xs).reshape(-1, self.d)
         W = Xs.shape[0]
@@ -182,12 +228,14 @@ class GPEngine:
         npd = C.c_int(0)
         if _is_torch(Xs):
             import torch
-            self._check_cols(Xs)
+            Xs = self._check_cols(Xs, "Xs")
             W = Xs.shape[0]
             if out is None:
                 out = torch.empty(W, dtype=torch.float64, device=Xs.device)
                 accumulate = False
-            self._ck(self.lib.gpb_loglike(self.h, nat.ptr(Xs.contiguous()), W, 1, nat.ptr(out),
+            else:
+                self._dev(out, (W,), "out")
+            self._ck(self.lib.gpb_loglike(self.h, nat.ptr(Xs), W, 1, nat.ptr(out),
                                           1 if accumulate else 0, C.byref(npd) if check else None))
         else:
             Xs = nat.f64(Xs).reshape(-1, self.d)
@@ -204,9 +252,10 @@ class GPEngine:
         """Fused device log-posterior of the last emulator block: log-likelihood (+= when accumulate),
         strict prior box, constant.  Asynchronous; torch cuda tensors only."""
         self._need_data()
-        self._check_cols(X_dev)
-        if lo_dev.numel() != self.d or hi_dev.numel() != self.d or out.numel() != X_dev.shape[0]:
-            raise ValueError("logpost: shapes of lo, hi, out do not match X")
+        self._track_stream()
+        X_dev = self._dev(X_dev, (None, self.d), "X")               # contiguous: `out` rows must line up with X rows
+        self._dev(lo_dev, (self.d,), "lo"), self._dev(hi_dev, (self.d,), "hi")
+        self._dev(out, (X_dev.shape[0],), "out")
         self._ck(self.lib.gpb_logpost(self.h, nat.ptr(X_dev), X_dev.shape[0], nat.ptr(out), 1 if accumulate else 0,
                                       nat.ptr(lo_dev), nat.ptr(hi_dev), float(outside), float(const)))
         return out
@@ -216,9 +265,12 @@ class GPEngine:
         npd = C.c_int(0)
         if _is_torch(dY):
             import torch
+            self._track_stream()
+            dY = self._dev(dY, (None, None), "dY", contiguous=False)
             W, M = dY.shape
+            cov = self._dev(cov, (W, M, M), "cov", contiguous=False)
             out = torch.empty(W, dtype=torch.float64, device=dY.device)
-            self._ck(self.lib.gpb_mvn_loglike(self.h, nat.ptr(dY.contiguous()), nat.ptr(cov.contiguous()), W, M, 1,
+            self._ck(self.lib.gpb_mvn_loglike(self.h, nat.ptr(dY), nat.ptr(cov), W, M, 1,
                                               nat.ptr(out), C.byref(npd)))
         else:
             dY, cov = nat.f64(dY), nat.f64(cov)
@@ -230,9 +282,10 @@ class GPEngine:
         return out
 
     def box_finish(self, X_dev, lo_dev, hi_dev, outside, const, ll_dev):
+        self._track_stream()
+        X_dev = self._dev(X_dev, (None, None), "X")
         W, d = X_dev.shape
-        if lo_dev.numel() != d or hi_dev.numel() != d or ll_dev.numel() != W:
-            raise ValueError("box_finish: shapes of X, lo, hi, ll do not match")
+        self._dev(lo_dev, (d,), "lo"), self._dev(hi_dev, (d,), "hi"), self._dev(ll_dev, (W,), "ll")
         self._ck(self.lib.gpb_box_finish(self.h, nat.ptr(X_dev), W, d, nat.ptr(lo_dev), nat.ptr(hi_dev),
                                          float(outside), float(const), nat.ptr(ll_dev)))
 
@@ -265,12 +318,16 @@ class GPEngine:
     def param_map(self, X_dev, out=None):
         """X_dev[W, d_in] (torch cuda f64) -> GP input [W, d_out] on the device, asynchronous."""
         import torch
-        W, d = X_dev.shape
-        if d != getattr(self, "pmap_d_in", -1):
-            raise ValueError("param_map: X has %d columns, the map expects %d" % (d, getattr(self, "pmap_d_in", -1)))
+        self._track_stream()
+        if getattr(self, "pmap_d_in", -1) < 0:
+            raise nat.GPBError("param_map before set_param_map")
+        X_dev = self._dev(X_dev, (None, self.pmap_d_in), "X", contiguous=False)
+        W = X_dev.shape[0]
         if out is None:
             out = torch.empty((W, self.pmap_d_out), dtype=torch.float64, device=X_dev.device)
-        self._ck(self.lib.gpb_param_map(self.h, nat.ptr(X_dev.contiguous()), W, nat.ptr(out)))
+        else:
+            self._dev(out, (W, self.pmap_d_out), "out")
+        self._ck(self.lib.gpb_param_map(self.h, nat.ptr(X_dev), W, nat.ptr(out)))
         return out
 
     # ------------------------------------------------------------------ diagnostics
@@ -303,11 +360,10 @@ class GPEngine:
     def dist_allgather(self, send, recv):
         """In-stream ncclAllGather of float64 device tensors: recv[r*n:(r+1)*n] = rank r's send[:n]
         (in place when send is recv[rank*n:(rank+1)*n])."""
+        self._track_stream()
         n = send.numel()
-        if (not send.is_cuda or not recv.is_cuda or send.dtype != recv.dtype or str(send.dtype) != "torch.float64"
-                or not send.is_contiguous() or not recv.is_contiguous()
-                or recv.numel() != n * getattr(self, "_dist_world", 0)):
-            raise ValueError("dist_allgather: contiguous float64 device tensors, recv.numel() == world * send.numel()")
+        self._dev(send, (n,), "send")
+        self._dev(recv, (n * getattr(self, "_dist_world", 0),), "recv")
         self._ck(self.lib.gpb_dist_allgather(self.h, nat.VP(send.data_ptr()), nat.VP(recv.data_ptr()), n))
         return recv
 

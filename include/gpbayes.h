@@ -179,9 +179,6 @@ int gpb_stretch_accept(gpb_ctx* ctx, double* pos_dev, double* lp_dev /*[nw]*/, i
                        int half, uint64_t seed, uint64_t step,
                        const double* q_dev, const double* factor_dev, const double* lpq_dev /*[nw/2]*/,
                        int64_t* naccept_dev /*[nw]*/, int randomize_split);
-/* test hook: out_dev[i] = pi_step(i), the keyed permutation that shuffles the red/blue split */
-int gpb_test_split_perm(gpb_ctx* ctx, int64_t n, uint64_t seed, uint64_t step, int64_t* out_dev);
-
 /* ---- walker sharding over RCCL (one process per GPU) ------------------------------ *
  * gpb_dist_uid: rank 0 obtains a 128-byte ncclUniqueId to broadcast out of band.
  * gpb_dist_init / gpb_dist_allgather: in-stream ncclAllGather of per-walker
@@ -191,55 +188,6 @@ int gpb_dist_uid(void* uid128_host);
 int gpb_dist_init(gpb_ctx* ctx, int rank, int nranks, const void* uid128_host);
 int gpb_dist_allgather(gpb_ctx* ctx, const double* send_dev, double* recv_dev, int64_t count);
 int gpb_dist_finalize(gpb_ctx* ctx);
-
-/* ---- micro-benchmarks / self-tests (device) --------------------------------------- */
-/* C[M,N] = A*B through the f64 MFMA tile engine (K%16==0).  b_trans bits 0-1: 0 = A[M,K] B[K,N],
- * 1 = A[M,K] B[N,K]^T, 2 = A[K,M]^T B[K,N]; bit 2: 64x64 tiles instead of 128x128. */
-int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K,
-                  const double* A_host, const double* B_host, double* C_host, int b_trans);
-/* test/tuning hook: force the tile of the predict kernel (0 = automatic, 64, 128, 32 = 64 rows x 32
- * walkers, 65 = 64 rows x 128 walkers) and, when switch_tiles > 0, the number of 128x128 tiles per 256 CUs
- * from which the automatic choice uses them. */
-int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
-/* tuning hook for launch geometry (never changes results): key 0 = XCD affinity of the predict kernel
- * (-1 auto, 0 by walker tile, 1 by row block, 2 by GP, 3 by (GP, four row blocks) super-block: least
- * fabric traffic); 1 = persistent 64-tile workgroups per CU;
- * 2 = waves per tile (4 or 8); 3 = persistent workgroups per CU of the 128-tile 8-wave variant;
- * 4 = outer panel width of the blocked Cholesky; 5 = tile order when every predict tile has its own
- * co-resident workgroup (0 ticket queues, 1 sorted, 2 snake over the CUs, 3 snake of pairs);
- * 6 = persistent 64x32-tile workgroups per CU;
- * 7 = 64x64 predict tiles when at least this many of them exist per 256 CUs, else 64x32; 8 = largest batch whose block log-likelihood
- * (PCA mode, 32 < M <= 64) runs one workgroup per walker instead of one wave per walker;
- * 9 = tile (64 or 128) of the K=64 trailing updates inside an outer Cholesky panel;
- * 10 = wave priority of predict tiles by K-loop length (0/1); 11 = the block log-likelihood kernels sum the
- * predict partials themselves instead of a separate finalize launch (0/1); 12 / 14 = tile of the
- * triangular-inverse levels / of the end-of-panel Cholesky updates (0 = by fill, 64, 128);
- * 13 = co-resident workgroups per CU assumed when choosing the static predict launch (0 = built-in table);
- * 16 = persistent 64x128-tile workgroups per CU; 17 = leave out the all-zero m-tiles of the predict kernel's
- * diagonal blocks (1, default) or multiply them like any other (0: A/B measurements);
- * 18 = cross-kernel distances as |a|^2 + |b|^2 - 2 a.b on centred coordinates (1, default) or as d differences (0);
- * 19 = 64-row chunks of the design per cross-kernel workgroup (0 = by grid size); 20 = walkers per lane there (1, 2);
- * 21 = 64-row predict tiles always launch static (1, default) or only when co-resident (0);
- * 22 = 64x128 predict tiles when at least this many of them exist per 256 CUs;
- * 23 = low-rank form of the block log-likelihood when it applies (1, default) or the dense M x M kernels (0). */
-int gpb_debug_tune(gpb_ctx* ctx, int key, int value);
-/* debug hook: per-tile placement and timing of the predict kernel.  capacity > 0 arms (and clears) a trace of
- * that many records, 0 disarms; read copies up to max_records records of 8 uint32 {HW_ID register, XCC_ID,
- * GP, row block, walker tile, start, end (100 MHz ticks), blockIdx} to the host and re-arms. */
-int gpb_debug_tile_trace(gpb_ctx* ctx, int64_t capacity);
-int gpb_debug_tile_trace_read(gpb_ctx* ctx, uint32_t* records_host, int64_t max_records, int64_t* n_out);
-/* test hook: route gpb_loglike through the generic LDS/HBM Cholesky instead of the register-resident
- * fast path (PCA mode, M <= 64) so that both implementations can be checked against each other. */
-int gpb_debug_force_generic_mvn(gpb_ctx* ctx, int on);
-/* HIP-event timing of the dominant kernel (k_predict: V = L^-1 K*^T + sum of squares) on the
- * context's stream.  read: number of timed launches, their summed duration, and the (GP, walker)
- * pairs they processed; resets the counters. */
-int gpb_profile_enable(gpb_ctx* ctx, int on);
-int gpb_profile_read(gpb_ctx* ctx, int64_t* launches, double* total_ms, double* units);
-/* issue-rate probe: returns measured TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64
- * (mode 0), v_fma_f64 (mode 1) or both co-issued (mode 2); mode 3: shader cycles per MFMA (one wave
- * per SIMD); mode 4: shader clock in GHz held during the dense MFMA loop. */
-int gpb_probe_fp64(gpb_ctx* ctx, int mode, double* tflops_out);
 
 #ifdef __cplusplus
 }

@@ -9,8 +9,8 @@ import pytest
 from conftest import REPO
 
 
-def _declared():
-    txt = open(os.path.join(REPO, "include", "gpbayes.h")).read()
+def _declared(header="gpbayes.h"):
+    txt = open(os.path.join(REPO, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(gpb_[a-z0-9_]+)\s*\(", txt)))
 
@@ -26,13 +26,16 @@ def lib():
 def test_exports_every_declared_symbol(lib):
     names = _declared()
     assert len(names) >= 25
-    for n in names:
+    for n in names + _declared("gpbayes_debug.h"):
         assert hasattr(lib, n), n
 
 
-def test_binding_covers_header():
+def test_binding_covers_headers():
+    """the boundary header and the debug header are bound one to one, and the boundary holds no test hooks"""
     from gpbayestools_hic_amd import _native
-    assert sorted(_native.PROTOTYPES) == _declared()
+    assert sorted(_native.BOUNDARY) == _declared()
+    assert sorted(_native.DEBUG) == _declared("gpbayes_debug.h")
+    assert not [n for n in _declared() if re.match(r"gpb_(test|debug|probe|profile)_", n)]
 
 
 def test_version(lib):

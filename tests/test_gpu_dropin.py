@@ -148,3 +148,48 @@ def test_emulator_flag_validation(tmp_path):
     g = golden("g3_emulator_pca_rbf.npz")
     with pytest.raises(ValueError):
         _make_emulator(tmp_path, g, dict(exp_and_cov_diagonal=True))      # needs logTrafo (src/emulator.py:59-60)
+
+
+# ---------------------------------------------------------------- hold-out helpers + estimator surface (G8)
+@pytest.mark.parametrize("name,kw", [("pca", {}), ("log", dict(logTrafo=True))])
+def test_g8_holdout_helpers(tmp_path, name, kw):
+    """testEmulatorErrors / testEmulatorErrorsWithTrainingPoints (src/emulator.py:636-726) against the reference's
+    own trainEmulator + predict on the same split: at the reference's hyper-parameters to the predict bars, and
+    after this build's own L-BFGS-B search to optimiser tolerance."""
+    g = golden(f"g8_holdout_{name}.npz")
+    ntest, nobs = int(g["ntest"]), g["Y"].shape[1]
+    emu = _make_emulator(tmp_path, g, kw)
+    for tag, fn, nrows in (("test", emu.testEmulatorErrors, ntest),
+                           ("train", emu.testEmulatorErrorsWithTrainingPoints, emu.nev - ntest)):
+        pred, perr, truth, terr = fn(nTestPoints=ntest, thetas=g[f"{tag}_thetas"])
+        assert pred.shape == perr.shape == truth.shape == terr.shape == (nrows, nobs)
+        assert maxrel(truth, g[f"{tag}_truth"]) < 1e-15 and maxrel(terr, g[f"{tag}_truth_err"]) < 1e-14
+        assert relerr(pred, g[f"{tag}_pred"]) < 1e-10
+        assert relerr(perr, g[f"{tag}_pred_err"]) < 1e-9       # sqrt of a variance that carries 1e-10
+        assert emu._X_train.shape[0] == emu.nev - ntest         # retrained on the first nev - ntest events
+    # the full path: own hyper-parameter search (what the reference's helper does)
+    pred, perr, truth, terr = emu.testEmulatorErrors(nTestPoints=ntest)
+    assert np.allclose(emu.thetas_, g["test_thetas"], atol=2e-2)
+    assert relerr(pred, g["test_pred"]) < 1e-3 and relerr(perr, g["test_pred_err"]) < 1e-2
+    assert np.array_equal(truth, g["test_truth"])
+
+
+def test_g8_fitted_gp_estimator_surface(tmp_path):
+    """what the reference reads off `self.gps[i]` (src/emulator.py:316-328): score(X, z), kernel_ (theta, bounds,
+    printed form), log_marginal_likelihood_value_, y_train_"""
+    g = golden("g8_holdout_pca.npz")
+    ntest = int(g["ntest"])
+    emu = _make_emulator(tmp_path, g, {})
+    emu.testEmulatorErrorsWithTrainingPoints(nTestPoints=ntest, thetas=g["train_thetas"])
+    ntrain = emu.nev - ntest
+    assert maxrel(np.array([gp.y_train_ for gp in emu.gps]), g["y_train"]) < 1e-11
+    scores = np.array([gp.score(emu.design_points[:ntrain], g["y_train"][i]) for i, gp in enumerate(emu.gps)])
+    assert np.max(np.abs(scores - g["gp_score"])) < 1e-11
+    assert np.max(np.abs(emu.gp_scores_ - g["gp_score"])) < 1e-11
+    for i, gp in enumerate(emu.gps):
+        k = gp.kernel_
+        assert str(k) == str(g["kernel_repr"][i])
+        assert np.array_equal(k.theta, g["train_thetas"][i]) and k.n_dims == g["train_thetas"].shape[1]
+        assert maxrel(k.bounds, g["kernel_bounds"]) < 1e-15
+        assert "{}".format(k) == str(g["kernel_repr"][i]) and "kernel=" in repr(gp)
+        assert np.isfinite(gp.log_marginal_likelihood_value_)

@@ -99,6 +99,88 @@ def test_argument_errors_are_reported_not_crashes():
     eng.close()
 
 
+def test_torch_arguments_are_validated_before_their_pointers_reach_the_kernels():
+    """a CPU tensor, a wrong dtype / shape / stride or a host extra_std next to device inputs must raise: the C ABI
+    would read their addresses as device memory (checked on the host, never provoked on the card)"""
+    import torch
+    from gpbayestools_hic_amd import GPEngine
+    from gpbayestools_hic_amd.engine import MODE_PCA
+    rng = np.random.default_rng(0)
+    N, d, P, M, W = 64, 3, 2, 4, 8
+    eng = GPEngine(0)
+    eng.set_data(rng.random((N, d)), rng.standard_normal((P, N)))
+    eng.set_theta(np.tile(np.log([1.0, 1.0, 1.0, 1.0, 0.05]), (P, 1)))
+    eng.factor()
+    eng.set_transform(MODE_PCA, np.zeros(M), A=rng.standard_normal((P, M)), cov_trunc=0.1 * np.eye(M))
+    eng.set_likelihood(np.zeros(M), 0.01 * np.eye(M))
+    Xd = torch.as_tensor(rng.random((W, d)), device="cuda")
+    lo, hi = torch.zeros(d, dtype=torch.float64, device="cuda"), torch.ones(d, dtype=torch.float64, device="cuda")
+    out = torch.empty(W, dtype=torch.float64, device="cuda")
+    ref = eng.logpost(Xd, out, False, lo, hi, -np.inf, 0.0).clone()
+    bad_inputs = [Xd.cpu(), Xd.float(), Xd[:, :2], torch.empty((W, d, 1), dtype=torch.float64, device="cuda")]
+    for bad in bad_inputs:
+        for call in (lambda x: eng.predict(x), lambda x: eng.emu_predict(x), lambda x: eng.loglike(x),
+                     lambda x: eng.logpost(x, out, False, lo, hi, -np.inf, 0.0)):
+            with pytest.raises(ValueError):
+                call(bad)
+    with pytest.raises(ValueError):
+        eng.logpost(Xd, out.cpu(), False, lo, hi, -np.inf, 0.0)
+    with pytest.raises(ValueError):
+        eng.logpost(Xd, out[:-1], False, lo, hi, -np.inf, 0.0)
+    with pytest.raises(ValueError):
+        eng.logpost(Xd, out, False, lo.cpu(), hi, -np.inf, 0.0)
+    with pytest.raises(ValueError):
+        eng.logpost(Xd, torch.empty(2 * W, dtype=torch.float64, device="cuda")[::2], False, lo, hi, -np.inf, 0.0)
+    with pytest.raises(ValueError):
+        eng.loglike(Xd, out=out.cpu())
+    with pytest.raises(ValueError):
+        eng.box_finish(Xd, lo, hi[:-1], -np.inf, 0.0, out)
+    with pytest.raises(ValueError):
+        eng.mvn_loglike(torch.zeros((W, M), dtype=torch.float64, device="cuda"), torch.zeros((W, M, M + 1), dtype=torch.float64, device="cuda"))
+    with pytest.raises(ValueError):
+        eng.mvn_loglike(torch.zeros((W, M), dtype=torch.float64, device="cuda"), torch.eye(M, dtype=torch.float64).repeat(W, 1, 1))
+    with pytest.raises(ValueError):
+        eng.emu_predict(Xd, extra_std=torch.zeros(W, dtype=torch.float64))            # host tensor next to device inputs
+    # a transposed view is made contiguous, numbers / numpy extra_std are uploaded: same results as the plain calls
+    Xt = Xd.t().contiguous().t()
+    assert not Xt.is_contiguous() and torch.equal(eng.loglike(Xt), eng.loglike(Xd))
+    m0, c0 = eng.emu_predict(Xd, extra_std=None)
+    m1, c1 = eng.emu_predict(Xd, extra_std=0.0)
+    m2, c2 = eng.emu_predict(Xd, extra_std=np.zeros(W))
+    assert torch.equal(c0, c1) and torch.equal(c0, c2) and torch.equal(m0, m2)
+    _, c3 = eng.emu_predict(Xd, extra_std=0.2)
+    _, c4 = eng.emu_predict(Xd, extra_std=torch.full((W,), 0.2, dtype=torch.float64, device="cuda"))
+    assert torch.equal(c3, c4) and not torch.equal(c3, c0)
+    assert torch.equal(eng.logpost(Xd, out, False, lo, hi, -np.inf, 0.0), ref)
+    eng.close()
+
+
+def test_engine_follows_torchs_current_stream():
+    """stream="torch": a call made inside `with torch.cuda.stream(s)` runs on s (where torch allocates and frees the
+    caller's tensors), and back on the default stream afterwards — same numbers either way"""
+    import torch
+    from gpbayestools_hic_amd import GPEngine
+    rng = np.random.default_rng(1)
+    eng = GPEngine(0)
+    eng.set_data(rng.random((64, 3)), rng.standard_normal((2, 64)))
+    eng.set_theta(np.tile(np.log([1.0, 1.0, 1.0, 1.0, 0.05]), (2, 1)))
+    eng.factor()
+    Xd = torch.as_tensor(rng.random((100, 3)), device="cuda")
+    m0, v0 = eng.predict(Xd)
+    s0 = eng.lib.gpb_stream(eng.h)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        m1, v1 = eng.predict(Xd)
+        assert eng.lib.gpb_stream(eng.h) == side.cuda_stream != s0
+    side.synchronize()
+    m2, v2 = eng.predict(Xd)
+    assert eng.lib.gpb_stream(eng.h) == s0
+    torch.cuda.synchronize()
+    assert torch.equal(m0, m1) and torch.equal(v0, v1) and torch.equal(m0, m2)
+    eng.close()
+
+
 def test_two_walker_ensemble_runs():
     import types
     from gpbayestools_hic_amd import StretchSampler

@@ -88,6 +88,9 @@ def test_not_positive_definite_is_reported(eng):
         eng.factor()
     info = eng.factor(raise_on_fail=False)
     assert np.all(info > 0)
+    from gpbayestools_hic_amd._native import GPBError
+    with pytest.raises(GPBError):                                 # no factorisation installed: nothing runs on NaN factors
+        eng.predict(np.zeros((2, 3)))
     val, grad = eng.lml(th)
     assert np.all(np.isneginf(val)) and np.all(grad == 0.0)       # sk:_gpr.py:588-589
 
@@ -248,6 +251,42 @@ def test_lowrank_loglike_reports_indefinite_covariances_like_the_dense_kernels(e
     eng.set_likelihood(yexp, -0.5 * np.eye(M))                   # C0 not positive definite: the low-rank set-up
     bad = eng.loglike(Xw)                                        # declines and the dense kernel reports the rows
     assert eng.last_not_pd == W and np.all(np.isnan(bad))
+
+
+@pytest.mark.parametrize("c0", [1e-14, 1e-22])
+def test_lowrank_logdet_does_not_overflow_for_tiny_c0(eng, c0):
+    """npc = 16 (the low-rank form's largest) with C0 = c0 * I: the pivots of S = I + R D R^T are ~ var / c0, so all
+    16 in one product overflow from ~1e19 each (c0 = 1e-22: the old kernel returned -inf silently); four per
+    logarithm do not.  Reference: 60-digit Cholesky of the full M x M covariance (mpmath)."""
+    mp = pytest.importorskip("mpmath")
+    from gpbayestools_hic_amd import synth
+    from gpbayestools_hic_amd.engine import MODE_PCA
+    mp.mp.dps = 60
+    N, d, M, P, W = 128, 4, 24, 16, 6
+    rng = np.random.default_rng(12)
+    X = synth.lhs(N, d, seed=5)
+    Z = rng.standard_normal((P, N))
+    A = rng.standard_normal((P, M)); mu = rng.standard_normal(M)
+    eng.set_data(X, Z, "RBF", 0.1); eng.set_theta(synth.fixed_theta(d, P)); eng.factor()
+    eng.set_transform(MODE_PCA, mu, A=A, cov_trunc=0.5 * c0 * np.eye(M))
+    yexp = rng.standard_normal(M)
+    eng.set_likelihood(yexp, 0.5 * c0 * np.eye(M))
+    Xw = synth.walkers(W, d, seed=6)
+    got = eng.loglike(Xw)
+    assert eng.last_not_pd == 0 and np.all(np.isfinite(got))
+    gm, gv = eng.predict(Xw)
+    for w in range(W):
+        C = mp.matrix(M, M)
+        for i in range(M):
+            for j in range(M):
+                C[i, j] = mp.fsum(mp.mpf(gv[w, p]) * mp.mpf(A[p, i]) * mp.mpf(A[p, j]) for p in range(P))
+            C[i, i] += mp.mpf(c0)
+        y = mp.matrix([mp.fsum(mp.mpf(gm[w, p]) * mp.mpf(A[p, i]) for p in range(P)) + mp.mpf(mu[i]) - mp.mpf(yexp[i])
+                       for i in range(M)])
+        L = mp.cholesky(C)
+        v = mp.lu_solve(L, y)
+        ref = -mp.mpf(0.5) * mp.fsum(x * x for x in v) - mp.fsum(mp.log(L[i, i]) for i in range(M))
+        assert abs(got[w] - float(ref)) <= 1e-10 * abs(float(ref)), (w, got[w], float(ref))
 
 
 # ---------------------------------------------------------------- 64x64 tile variant (small walker batches / multi-GPU shards)

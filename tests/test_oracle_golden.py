@@ -140,3 +140,31 @@ def test_g6_mvn(M):
     assert relerr(O.mvn_loglike_batched(y, cov), ll) < 1e-11
     bad = -np.eye(M)
     assert np.isnan(O.mvn_loglike(y[0], bad))
+
+
+@pytest.mark.parametrize("name", ["pca", "log"])
+def test_g8_holdout_split(name):
+    """hold-out validation (src/emulator.py:636-726): the oracle trained on the first nev - ntest events at the
+    reference's hyper-parameters reproduces the reference's predictions for the held-out and the training events"""
+    g = golden(f"g8_holdout_{name}.npz")
+    ntest, npc = int(g["ntest"]), int(g["npc"])
+    log = name == "log"
+    Y = np.log(np.abs(g["Y"]) + 1e-30) if log else g["Y"]           # src/emulator.py:403-407
+    ntr = Y.shape[0] - ntest
+    for tag, rows in (("test", slice(ntr, None)), ("train", slice(0, ntr))):
+        oe = O.OracleEmulator(g["X"][:ntr], Y[:ntr], g["lo"], g["hi"], npc).fit(g[f"{tag}_thetas"])
+        mean, cov = oe.predict(g["X"][rows], True, 0.0)
+        err = np.sqrt(np.diagonal(cov, axis1=1, axis2=2))
+        if log:
+            mean, err = np.exp(mean), err * np.exp(mean)
+        assert relerr(mean, g[f"{tag}_pred"]) < 1e-10
+        assert relerr(err, g[f"{tag}_pred_err"]) < 1e-9
+        truth = np.exp(Y[rows]) if log else Y[rows]
+        assert maxrel(truth, g[f"{tag}_truth"]) < 1e-15
+    # estimator surface: R^2 of the predictive mean on the training targets (sklearn RegressorMixin.score)
+    oe = O.OracleEmulator(g["X"][:ntr], Y[:ntr], g["lo"], g["hi"], npc).fit(g["train_thetas"])
+    assert maxrel(oe.Z.T, g["y_train"]) < 1e-11
+    m, _ = oe.gp_predict(g["X"][:ntr])
+    z = g["y_train"].T
+    r2 = 1.0 - ((z - m) ** 2).sum(0) / ((z - z.mean(0)) ** 2).sum(0)
+    assert np.max(np.abs(r2 - g["gp_score"])) < 1e-11

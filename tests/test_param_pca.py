@@ -75,10 +75,14 @@ def test_emulator_with_parameter_pca_gpu(tmp_path):
     emu = Emulator(training_set_path=tp, parameter_file=pf, npc=int(g["npc"]), parameterTrafoPCA=True)
     assert maxrel(emu.PCA_new_design_points, g["new_design_points"]) < 1e-10
     emu.trainEmulator([True] * emu.nev, thetas=g["thetas"])
-    assert relerr(emu.lml_, g["lml"]) < 1e-8
+    assert relerr(emu.lml_, g["lml"]) < 1e-10         # measured 1e-15 (tools/gpu_param_pca_errors.py)
     mean, cov = emu.predict(g["Xs"], return_cov=True, extra_std=0.0)
-    assert relerr(mean, g["mean"]) < 1e-8
-    assert maxrel(cov, g["cov"]) < 1e-7
+    assert relerr(mean, g["mean"]) < 1e-11            # measured 6e-15
+    assert maxrel(cov, g["cov"]) < 1e-10              # measured 1.4e-15
+    eng = emu._engine_ready()
+    eng.tune("kcross_dot", 0)                         # the other form of the cross-kernel distance holds the bars too
+    mean_d, cov_d = emu.predict(g["Xs"], return_cov=True, extra_std=0.0)
+    assert relerr(mean_d, g["mean"]) < 1e-11 and maxrel(cov_d, g["cov"]) < 1e-10
 
 
 @pytest.mark.gpu
@@ -113,7 +117,7 @@ def test_chain_with_parameter_pca_uses_device_map(tmp_path):
     assert np.all(chain.log_likelihood(Xw, finite=True)[~inside] == -1e300)
     # against the reference's own predictions (golden) ...
     ref = np.array([O.mvn_loglike(m - yexp, c + np.diag(err ** 2)) for m, c in zip(g["mean"], g["cov"])]) + O.EXTRA_STD_CONST
-    assert relerr(lp[inside], ref[inside]) < 1e-6
+    assert relerr(lp[inside], ref[inside]) < 1e-10
     # ... and against the host-mapped route of this build (isolates the device map)
     mY, mC = chain._predict(Xw[inside], 0.0)
     ref2 = np.array([O.mvn_loglike(m - yexp, c + np.diag(err ** 2)) for m, c in zip(mY, mC)]) + O.EXTRA_STD_CONST

@@ -262,6 +262,67 @@ def g7_param_pca(Emulator):
         Xs=Xs, mean=mean, cov=cov)
 
 
+def _holdout_by_the_reference(emu, ntest, on_training):
+    """The two hold-out helpers (src/emulator.py:636-679, 682-726) call `self.predict(X, return_cov=True)` with the
+    scalar default `extra_std=0`, which raises under numpy >= 2 (`np.array(0, copy=False)`, src/emulator.py:578;
+    SURVEY §8 a6) — so the helpers themselves cannot run in this container.  Their steps are carried out here with
+    the reference's own `trainEmulator` and `predict` (array-valued extra_std = 0, the same numbers): mask the last
+    ntest events (:651-655), retrain, predict the validation events (:657-659), sqrt of the covariance diagonal,
+    undo the log transform (:661-673), reshape to [-1, nobs] (:675-678)."""
+    mask = [True] * emu.nev
+    for i in range(emu.nev - ntest, emu.nev):
+        mask[i] = False
+    emu.trainEmulator(mask)
+    vmask = np.array(mask if on_training else [not m for m in mask])
+    Xv = emu.design_points_org_[vmask, :]
+    pred, cov = emu.predict(Xv, return_cov=True, extra_std=np.zeros(Xv.shape[0]))
+    pred_err = np.sqrt(np.array([cov[i].diagonal() for i in range(cov.shape[0])]))
+    if emu.logTrafo_ and not emu.exp_and_cov_diagonal_:
+        pred, pred_err = np.exp(pred), pred_err * np.exp(pred)
+    if emu.logTrafo_:
+        truth = np.exp(emu.model_data[vmask, :])
+        truth_err = emu.model_data_err[vmask, :] * np.exp(emu.model_data[vmask, :])
+    else:
+        truth, truth_err = emu.model_data[vmask, :], emu.model_data_err[vmask, :]
+    r = lambda a: np.array(a).reshape(-1, emu.nobs)
+    return r(pred), r(pred_err), r(truth), r(truth_err)
+
+
+def g8_holdout(Emulator):
+    """Hold-out validation (src/emulator.py:636-726) and the sklearn estimator surface the reference reads off its
+    fitted GPs (`gp.score`, `gp.kernel_`: src/emulator.py:316-328).  The hyper-parameters the reference's L-BFGS-B
+    run ends on are stored so that the build can be checked at those values (tight) and after its own search
+    (optimiser tolerance)."""
+    for vi, (name, kw) in enumerate((("pca", {}), ("log", dict(logTrafo=True)))):
+        N, d, M, npc, ntest = 64, 5, 4, 3, 6
+        lo, hi, X, Y, Yerr = _make_inputs(name, N, d, M, 800 + 10 * vi)
+        Y = np.abs(Y) + 0.5                                   # positive observables (logTrafo takes logs)
+        tp = os.path.join(_work, f"holdout_{name}_train.pkl")
+        pf = os.path.join(_work, f"holdout_{name}_par.txt")
+        synth.write_training_pickle(tp, X, Y, Yerr)
+        synth.write_parameter_file(pf, lo, hi)
+        out = dict(lo=lo, hi=hi, X=X, Y=Y, Yerr=Yerr, npc=npc, ntest=ntest)
+        emu = Emulator(training_set_path=tp, parameter_file=pf, npc=npc, **kw)
+        try:                                                  # the record: the helper as shipped does not run here
+            emu.testEmulatorErrors(nTestPoints=ntest)
+            out["helper_runs_under_this_numpy"] = True
+        except ValueError:
+            out["helper_runs_under_this_numpy"] = False
+        for tag, on_training in (("test", False), ("train", True)):
+            pred, pred_err, truth, truth_err = _holdout_by_the_reference(emu, ntest, on_training)
+            out[f"{tag}_pred"], out[f"{tag}_pred_err"] = pred, pred_err
+            out[f"{tag}_truth"], out[f"{tag}_truth_err"] = truth, truth_err
+            out[f"{tag}_thetas"] = np.array([gp.kernel_.theta for gp in emu.gps])
+        # estimator surface after the last retraining (N - ntest points)
+        Xt = emu.design_points[:N - ntest]
+        Z = emu.pca.transform(emu.scaler.transform(emu.model_data[:N - ntest]))[:, :npc]
+        out["gp_score"] = np.array([gp.score(Xt, Z[:, i]) for i, gp in enumerate(emu.gps)])
+        out["kernel_repr"] = np.array([str(gp.kernel_) for gp in emu.gps])
+        out["kernel_bounds"] = emu.gps[0].kernel_.bounds
+        out["y_train"] = np.array([gp.y_train_ for gp in emu.gps])
+        np.savez_compressed(os.path.join(OUT, f"g8_holdout_{name}.npz"), **out)
+
+
 def g6_mvn(mcmc):
     rng = np.random.default_rng(600)
     out = {}
@@ -286,6 +347,7 @@ def main():
     g5_chain(mcmc, Emulator)
     g6_mvn(mcmc)
     g7_param_pca(Emulator)
+    g8_holdout(Emulator)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
