@@ -58,7 +58,8 @@ def cpu_baseline(info, emu, nrows):
 def extras(chain4, emu4, info4):
     """The other two BASELINE metrics, measured on the same box (N=1 only): GP predict points/s on
     BASELINE config 2 (1024 design pts x 15 params, 10 GPs, 10 000 test points) and the fixed-theta fit
-    (K build + Cholesky + L^-1 + alpha) expressed as Cholesky-equivalent GF/s (P N^3/3 flops / time)."""
+    (K build + Cholesky + L^-1 + alpha) at the design sizes of configs 2, 4 and 5, as Cholesky-equivalent GF/s
+    (P N^3/3 flops / time) and with its own roofline block."""
     import torch
     from gpbayestools_hic_amd import synth
     from gpbayestools_hic_amd.workload import build_chain
@@ -83,18 +84,30 @@ def extras(chain4, emu4, info4):
     t0 = time.perf_counter(); emu2.predict(Xh, return_cov=True, extra_std=0.0); th = time.perf_counter() - t0
     out["emulator_predict_cfg2_host"] = {"points": 10000, "ms": th * 1e3, "points_per_s": 10000 / th,
                                          "what": "Emulator.predict(return_cov=True): numpy in, mean[W,32] + cov[W,32,32] out (PCIe inclusive)"}
+    def fit_entry(eng, Nn, Pp, kernel):
+        """fit at fixed theta: K build + blocked Cholesky + L^-1 + alpha for all GPs (gpb_gp_factor).  Roofline block:
+        algorithmic flops = P (N^3/3 [Cholesky] + N^3/3 [triangular inverse]) against the fp64 MFMA peak; the chain of
+        N/64 dependent diagonal-block steps (k_chol_update / k_chol_trsm, gpb_chol.hip) is what bounds it."""
+        tf = timed(lambda: eng.factor(), 5)
+        both = 2.0 * Pp * Nn ** 3 / 3.0
+        return {"N": Nn, "gps": Pp, "kernel": kernel, "ms": tf * 1e3,
+                "cholesky_equiv_gflops": Pp * Nn ** 3 / 3 / tf / 1e9,
+                "roofline": {"bound": "mfma", "kernel": "k_chol_update + k_chol_trsm (chain), k_syrk, k_trtri_level",
+                             "flops": both, "achieved": both / tf / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": both / tf / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                             "frac_cholesky_only": Pp * Nn ** 3 / 3 / tf / 1e12 / FP64_MFMA_PEAK_TFLOPS},
+                "what": "K build + blocked Cholesky + L^-1 + alpha for all GPs; flops = P (N^3/3 + N^3/3)"}
+
     for tag, emu, info in (("cfg2", emu2, info2), ("cfg4", emu4, info4)):
-        eng = emu._engine_ready()
-        eng.factor(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            eng.factor()
-        torch.cuda.synchronize()
-        tf = (time.perf_counter() - t0) / 3
-        Nn, Pp = info["N"], info["P"]
-        out[f"fit_fixed_theta_{tag}"] = {"N": Nn, "gps": Pp, "ms": tf * 1e3,
-                                         "cholesky_equiv_gflops": Pp * Nn ** 3 / 3 / tf / 1e9,
-                                         "what": "K build + blocked Cholesky + L^-1 + alpha for all GPs; rate = P N^3/3 / time"}
+        out[f"fit_fixed_theta_{tag}"] = fit_entry(emu._engine_ready(), info["N"], info["P"], info["kernel"])
+    from gpbayestools_hic_amd import GPEngine
+    c5 = synth.CONFIGS[5]
+    eng5 = GPEngine(torch.cuda.current_device())
+    eng5.set_data(synth.lhs(c5["N"], c5["d"]), np.random.default_rng(1).standard_normal((c5["P"], c5["N"])),
+                  c5["kernel"], 0.1)
+    eng5.set_theta(synth.fixed_theta(c5["d"], c5["P"]))
+    out["fit_fixed_theta_cfg5"] = fit_entry(eng5, c5["N"], c5["P"], c5["kernel"])
+    eng5.close()
     return out
 
 

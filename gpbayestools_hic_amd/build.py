@@ -6,8 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgpbayes.so")
-SOURCES = ["gpb_api.hip", "gpb_fit.hip", "gpb_predict.hip", "gpb_like.hip", "gpb_cov.hip", "gpb_pmap.hip"]
-HEADERS = ["gpb_internal.h", "gemm_tile.h", os.path.join("..", "..", "include", "gpbayes.h"),
+SOURCES = ["gpb_api.hip", "gpb_fit.hip", "gpb_chol.hip", "gpb_predict.hip", "gpb_like.hip", "gpb_cov.hip", "gpb_pmap.hip"]
+HEADERS = ["gpb_internal.h", "gemm_tile.h", "chol_block.h", os.path.join("..", "..", "include", "gpbayes.h"),
            os.path.join("..", "..", "include", "gpbayes_debug.h")]
 
 

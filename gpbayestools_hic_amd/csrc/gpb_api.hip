@@ -128,6 +128,8 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     dev_free(&ctx->tile_trace);
     dev_free(&ctx->A); dev_free(&ctx->mu); dev_free(&ctx->scale); dev_free(&ctx->C0); dev_free(&ctx->yexp);
     dev_free(&ctx->Cexp); dev_free(&ctx->mvn_ws); dev_free(&ctx->notpd); dev_free(&ctx->tile_counter);
+    for (hipEvent_t e : ctx->chol_events) (void)hipEventDestroy(e);
+    if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -190,6 +192,9 @@ extern "C" int gpb_gp_set(gpb_ctx* ctx, int64_t N, int64_t d, int64_t P, const d
     if ((rc = dev_alloc(ctx, &ctx->Z, P * Np))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->K, P * Np * Np))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->Linv, P * Np * Np))) return rc;
+    // zeroed ONCE: the factorisation writes the diagonal blocks (with zeros above the diagonal) and the blocks below
+    // them, never the blocks above — and the 128-wide tiles of the predict / K^-1 products read those as zeros
+    GPB_HIP(hipMemsetAsync(ctx->Linv, 0, sizeof(double) * P * Np * Np, ctx->stream));
     if ((rc = dev_alloc(ctx, &ctx->T, P * Np * Np))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->yv, P * Np))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->alpha, P * Np))) return rc;
@@ -724,6 +729,8 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 14: if (value != 0 && value != 64 && value != 128) return GPB_E_ARG; ctx->syrk_tile = value; break;
         case 16: if (value < 1 || value > 8) return GPB_E_ARG; ctx->wgs_per_cu64x128 = value; break;
         case 13: if (value < 0 || value > 1024) return GPB_E_ARG; ctx->resident_occ = value; break;
+        case 24: if (value < 0 || value > 1) return GPB_E_ARG; ctx->chol_algo = value; break;
+        case 25: if (value < 0 || value > 1) return GPB_E_ARG; ctx->chol_lookahead = value; break;
         default: return GPB_E_ARG;
     }
     return 0;

@@ -1,0 +1,214 @@
+// gpb_chol.hip — blocked right-looking fp64 Cholesky of K + (sigma_n^2 + alpha) I for all P GPs of a context
+// (sk:_gpr.py:349 `cholesky(K, lower=True)` via src/emulator.py:309-315), organised around its serial chain.
+//
+// The factorisation of one GP is a chain of Np/64 dependent steps (factor the 64x64 diagonal block, solve the
+// column panel below it, update what the next step reads); only the P GPs run side by side.  Round 1 spent 3
+// launches and ~58 us per step, 36 us of them in the diagonal-block kernel on P workgroups while the rest of the
+// chip idled (profiles/r01_fit_kernel_stats_final.csv).  Here a step is TWO launches:
+//
+//   k_chol_trsm    L_ik = A_ik L_kk^-T for all row blocks i > k: one 64x64x64 MFMA product per workgroup, both
+//                  operand tiles resident in LDS (no K-loop pipeline: one barrier), written in place.
+//   k_chol_update  A_ij -= L_ik L_jk^T for the tiles of the columns j of the current outer panel (K = 64), and — in
+//                  the workgroup that owns tile (k+1, k+1), dispatched first — the NEXT step's diagonal block:
+//                  it is factored and inverted right there, from LDS, while the other tiles are still being updated.
+//
+// Once per outer panel (chol_outer columns) the whole trailing matrix is updated with K = panel width on the tile
+// engine (k_syrk in gpb_fit.hip), followed by a stand-alone diagonal-block launch (k_chol_diag) for the first block of
+// the next panel.
+//
+// potf2_inv_64 (the chain's body): 16x16 sub-blocks factored in ONE wave's registers (lane i = row i, readlane
+// broadcasts, no barriers: ~140 cycles per pivot, which is the rsqrt's dependent latency), the 48/32/16 rows below
+// solved by right-looking substitution (one row per lane, 16 dependent steps), the trailing part of the block and
+// the assembly of the inverse (block doubling 16 -> 32 -> 64) on v_mfma_f64_16x16x4_f64 straight from LDS.
+#include "gpb_internal.h"
+#include "gemm_tile.h"
+#include "chol_block.h"
+#include <math.h>
+#include <vector>
+
+namespace gpb {
+
+namespace {
+
+// s.a -> L block of K (upper zeroed), s.x -> diagonal block of Linv; reports a non-positive pivot
+__device__ __forceinline__ void store_diag(const CholLds& s, double* __restrict__ Kb, double* __restrict__ Xb, int64_t Np,
+                                           int64_t c0, int* __restrict__ info_p) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int idx = tid + CHOL_THREADS * e;
+        const int r = idx >> 5, c = (idx & 31) * 2;
+        const d2 lv = {c <= r ? s.a[r][c] : 0.0, c + 1 <= r ? s.a[r][c + 1] : 0.0};
+        const d2 xv = {c <= r ? s.x[r][c] : 0.0, c + 1 <= r ? s.x[r][c + 1] : 0.0};
+        *reinterpret_cast<d2*>(Kb + (int64_t)r * Np + c) = lv;
+        *reinterpret_cast<d2*>(Xb + (int64_t)r * Np + c) = xv;
+    }
+    if (tid == 0 && s.bad >= 0 && *info_p == 0) *info_p = (int)(c0 + s.bad + 1);     // LAPACK dpotrf's info
+}
+
+}  // namespace
+
+// Diagonal block kb alone (first block of an outer panel: its last update came from the panel-wide SYRK).
+__global__ __launch_bounds__(CHOL_THREADS, 4) void k_chol_diag(double* __restrict__ K, double* __restrict__ Linv, int64_t Np,
+                                                            int64_t kb, int* __restrict__ info) {
+    __shared__ CholLds s;
+    const int p = blockIdx.x;
+    const int64_t c0 = kb * 64;
+    double* Kb = K + (int64_t)p * Np * Np + c0 * Np + c0;
+    load_tile(Kb, Np, s.a, threadIdx.x);
+    potf2_inv_64(s);                                   // opens with a barrier
+    store_diag(s, Kb, Linv + (int64_t)p * Np * Np + c0 * Np + c0, Np, c0, info + p);
+}
+
+// Column panel: L_ik = A_ik L_kk^-T for row block i = kb + 1 + blockIdx.x, in place.
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_trsm(double* __restrict__ K, const double* __restrict__ Linv,
+                                                            int64_t Np, int64_t kb) {
+    __shared__ double sa[64][LDP], sx[64][LDP];
+    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t c0 = kb * 64, r0 = (kb + 1 + blockIdx.x) * 64;
+    double* Ap = K + (int64_t)p * Np * Np + r0 * Np + c0;
+    load_tile(Ap, Np, sa, tid);
+    load_tile(Linv + (int64_t)p * Np * Np + c0 * Np + c0, Np, sx, tid);
+    __syncthreads();
+    d4 acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    mma_nt_64(sa, sx, acc, wave, lane);                // out[i][j] = sum_k A[i][k] X[j][k]
+    const int m0 = (wave >> 2) * 32, n0 = (wave & 3) * 16, lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ap[(int64_t)(m0 + 16 * t + lk + 4 * r) * Np + n0 + lr] = acc[t][r];
+}
+
+// In-panel trailing update by block column kb (K = 64) + the next diagonal block.
+// Tiles (i, j), kb < j < je, j <= i < nb, numbered column by column; tile 0 = (kb+1, kb+1) is the next step's
+// diagonal block: its workgroup keeps the updated block in LDS, factors and inverts it, and stores L and L^-1.
+__global__ __launch_bounds__(CHOL_THREADS, 4) void k_chol_update(double* __restrict__ K, double* __restrict__ Linv,
+                                                              int64_t Np, int64_t kb, int64_t je,
+                                                              int* __restrict__ info) {
+    __shared__ CholLds s;
+    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t nb = Np / 64;
+    int64_t j = kb + 1, t = blockIdx.x;
+    while (t >= nb - j) { t -= nb - j; ++j; }          // column j holds nb - j tiles (rows j .. nb-1)
+    const int64_t i = j + t;
+    if (j >= je) return;
+    double* Kp = K + (int64_t)p * Np * Np;
+    const int64_t c0 = kb * 64;
+    load_tile(Kp + i * 64 * Np + c0, Np, s.a, tid);
+    if (i != j) load_tile(Kp + j * 64 * Np + c0, Np, s.x, tid);
+    const int m0 = (wave >> 2) * 32, n0 = (wave & 3) * 16, lr = lane & 15, lk = lane >> 4;
+    double* Cp = Kp + i * 64 * Np + j * 64;
+    d4 c[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[tt][r] = Cp[(int64_t)(m0 + 16 * tt + lk + 4 * r) * Np + n0 + lr];
+    __syncthreads();
+    d4 acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    mma_nt_64(s.a, i != j ? s.x : s.a, acc, wave, lane);
+    if (blockIdx.x != 0) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cp[(int64_t)(m0 + 16 * tt + lk + 4 * r) * Np + n0 + lr] = c[tt][r] - acc[tt][r];
+        return;
+    }
+    __syncthreads();                                   // every wave is done reading the operand tile in s.a
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s.a[m0 + 16 * tt + lk + 4 * r][n0 + lr] = c[tt][r] - acc[tt][r];
+    potf2_inv_64(s);                                   // opens with a barrier
+    store_diag(s, Cp, Linv + (int64_t)p * Np * Np + j * 64 * Np + j * 64, Np, j * 64, info + p);
+}
+
+// declared in gpb_fit.hip: trailing update by the panel [pb, pe): rows >= r0, columns [r0, ce), K = pe - pb
+void launch_syrk_range(gpb_ctx* ctx, hipStream_t stream, int64_t pb, int64_t pe, int64_t r0, int64_t ce);
+
+namespace {
+int ensure_lookahead(gpb_ctx* ctx, size_t nev) {
+    if (!ctx->side_stream) {
+        // lowest priority: the far update must only fill what the chain leaves idle (at equal priority the chain's
+        // 10-workgroup diagonal kernel waited 105 us instead of 16 behind the side stream's tiles)
+        // lowest priority: the far update should only fill what the chain leaves idle.  (It still delays the chain:
+        // once its tiles occupy every CU a 512-thread chain workgroup waits for a hole — 105-130 us instead of 16 for
+        // the first diagonal kernel after a panel, priority or not; masking the side stream off a share of the CUs
+        // (hipExtStreamCreateWithCUMask, 3/4 and 1/2) cost 30-50 % instead.  Net gain of the lookahead: 2-4 %.)
+        int lo = 0, hi = 0;
+        GPB_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        GPB_HIP(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, lo));
+    }
+    while (ctx->chol_events.size() < nev) {
+        hipEvent_t e;
+        GPB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->chol_events.push_back(e);
+    }
+    return 0;
+}
+}  // namespace
+
+// Schedule: per outer panel [pb, pe) the chain (diagonal block, then per 64-column step k_chol_trsm + k_chol_update),
+// then the panel's update of the trailing matrix with K = panel width — split in two (lookahead): the NEAR part, the
+// next panel's own columns [pe, pe + NBO), stays on the chain's stream; the FAR part, columns >= pe + NBO, goes to a
+// side stream and runs underneath the next panel's chain, which leaves nine tenths of the matrix cores idle (two events
+// per panel; the far parts of consecutive panels are ordered by the side stream itself).
+int launch_potrf_fused(gpb_ctx* ctx) {
+    const int64_t Np = ctx->Np, nb = Np / 64;
+    const int64_t NBO = ctx->chol_outer;               // outer panel width (multiple of 64)
+    const unsigned P = (unsigned)ctx->P;
+    const int64_t npanel = (Np + NBO - 1) / NBO;
+    const bool look = ctx->chol_lookahead && npanel > 2;
+    if (look) {
+        int rc = ensure_lookahead(ctx, (size_t)(2 * npanel));
+        if (rc) return rc;
+    }
+    GPB_HIP(hipMemsetAsync(ctx->info, 0, sizeof(int) * ctx->P, ctx->stream));
+    int64_t ip = 0;
+    bool far_pending = false;
+    for (int64_t pb = 0; pb < Np; pb += NBO, ++ip) {
+        const int64_t pe = imin64(pb + NBO, Np), je = pe / 64;
+        hipLaunchKernelGGL(k_chol_diag, dim3(P), dim3(CHOL_THREADS), 0, ctx->stream, ctx->K, ctx->Linv, Np, pb / 64,
+                           ctx->info);
+        for (int64_t kb = pb / 64; kb < je; ++kb) {
+            const int64_t rem = nb - kb - 1;
+            if (rem <= 0) break;
+            hipLaunchKernelGGL(k_chol_trsm, dim3((unsigned)rem, P), dim3(CHOL_THREADS), 0, ctx->stream, ctx->K, ctx->Linv,
+                               Np, kb);
+            if (kb + 1 < je) {
+                int64_t ntile = 0;
+                for (int64_t j = kb + 1; j < je; ++j) ntile += nb - j;
+                hipLaunchKernelGGL(k_chol_update, dim3((unsigned)ntile, P), dim3(CHOL_THREADS), 0, ctx->stream, ctx->K,
+                                   ctx->Linv, Np, kb, je, ctx->info);
+            }
+        }
+        if (pe >= Np) break;
+        const int64_t near_end = imin64(pe + NBO, Np);
+        if (!look || near_end >= Np) {                 // no far part (or lookahead off): everything on the chain's stream
+            if (far_pending) {                         // the previous far part wrote into these columns
+                GPB_HIP(hipEventRecord(ctx->chol_events[2 * ip - 1], ctx->side_stream));
+                GPB_HIP(hipStreamWaitEvent(ctx->stream, ctx->chol_events[2 * ip - 1], 0));
+                far_pending = false;
+            }
+            launch_syrk_range(ctx, ctx->stream, pb, pe, pe, Np);
+            continue;
+        }
+        // panel [pb, pe) is final: the far part may start
+        GPB_HIP(hipEventRecord(ctx->chol_events[2 * ip], ctx->stream));
+        if (far_pending) {                             // near part: after the previous far part, which wrote there
+            GPB_HIP(hipEventRecord(ctx->chol_events[2 * ip - 1], ctx->side_stream));
+            GPB_HIP(hipStreamWaitEvent(ctx->stream, ctx->chol_events[2 * ip - 1], 0));
+        }
+        launch_syrk_range(ctx, ctx->stream, pb, pe, pe, near_end);
+        GPB_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->chol_events[2 * ip], 0));
+        launch_syrk_range(ctx, ctx->side_stream, pb, pe, near_end, Np);
+        far_pending = true;
+    }
+    if (far_pending) {                                 // cannot happen (the last panel with a trailing part has no far part)
+        GPB_HIP(hipEventRecord(ctx->chol_events[0], ctx->side_stream));
+        GPB_HIP(hipStreamWaitEvent(ctx->stream, ctx->chol_events[0], 0));
+    }
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gpb

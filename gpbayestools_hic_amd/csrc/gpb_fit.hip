@@ -71,8 +71,8 @@ int launch_scale_design(gpb_ctx* ctx) {
 }
 
 // ------------------------------------------------------------------ K(X,X)
-// One 64x64 tile per workgroup; scaled design rows staged in LDS; HBM-write bound
-// (8*Np^2 bytes per GP).  Diagonal: c*1 + sigma_n^2 + alpha (sk:kernels.py:1559-1560,
+// One 64x64 tile per workgroup, tiles of the lower block triangle only (the factorisation reads nothing above
+// it); scaled design rows staged in LDS; HBM-write bound (4*Np^2 bytes per GP).  Diagonal: c*1 + sigma_n^2 + alpha (sk:kernels.py:1559-1560,
 // 1401-1412; sk:_gpr.py:347).  Padding rows/cols: identity.
 template <int KIND>
 __global__ __launch_bounds__(256) void k_kmat(const double* __restrict__ Xsc, const double* __restrict__ amp,
@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void k_kmat(const double* __restrict__ Xsc, co
                                               double* __restrict__ K, int64_t N, int64_t Np, int dpad) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int p = blockIdx.z;
+    if (blockIdx.x > blockIdx.y) return;               // lower block triangle only: nothing reads K above it
     const int64_t i0 = (int64_t)blockIdx.y * 64, j0 = (int64_t)blockIdx.x * 64;
     const int ldx = dpad + 1;
     double* Xi = sm;
@@ -319,11 +320,32 @@ __global__ __launch_bounds__(256, 2) void k_syrk(double* __restrict__ K, int64_t
     tile_store<T>(Kp + r0 * Np + r0, Np, mb, nb, m_ext, n_ext, -1.0, true, acc);
 }
 
+// Trailing update by the outer panel [pb, pe), K = panel width: rows >= r0, columns [r0, ce) (lower part).
+void launch_syrk_range(gpb_ctx* ctx, hipStream_t stream, int64_t pb, int64_t pe, int64_t r0, int64_t ce) {
+    const int64_t Np = ctx->Np;
+    const int64_t ntr = (Np - r0 + 127) / 128, ntc = (ce - r0 + 127) / 128;
+    const int64_t tiles128 = ntc * ntr - ntc * (ntc - 1) / 2;
+    const bool small = ctx->syrk_tile == 64 || (ctx->syrk_tile == 0 && tiles128 * ctx->P < 16 * (int64_t)ctx->num_cu);
+    if (small) {                                        // few 128-wide tiles: 64-wide ones fill the chip (same bits)
+        const unsigned nr = (unsigned)((Np - r0 + 63) / 64), nc = (unsigned)((ce - r0 + 63) / 64);
+        hipLaunchKernelGGL(k_syrk<64>, dim3(nc, nr, (unsigned)ctx->P), dim3(256), 0, stream, ctx->K, Np, pb,
+                           (int)(pe - pb), r0, ce);
+    } else {
+        hipLaunchKernelGGL(k_syrk<128>, dim3((unsigned)ntc, (unsigned)ntr, (unsigned)ctx->P), dim3(256), 0, stream,
+                           ctx->K, Np, pb, (int)(pe - pb), r0, ce);
+    }
+}
+// End of an outer panel [pb, pe): the whole trailing matrix takes the panel's update.
+void launch_syrk_panel(gpb_ctx* ctx, int64_t pb, int64_t pe) { launch_syrk_range(ctx, ctx->stream, pb, pe, pe, ctx->Np); }
+
+int launch_potrf_fused(gpb_ctx* ctx);                  // gpb_chol.hip: two launches per 64-column step
+
 int launch_potrf(gpb_ctx* ctx) {
+    if (ctx->chol_algo == 1) return launch_potrf_fused(ctx);
+    // round 1's schedule (three launches per step), kept for A/B measurements: tune key 24 = 0
     const int64_t Np = ctx->Np, nb = Np / 64;
     const int64_t NBO = ctx->chol_outer;               // outer panel width (multiple of 64)
     GPB_HIP(hipMemsetAsync(ctx->info, 0, sizeof(int) * ctx->P, ctx->stream));
-    GPB_HIP(hipMemsetAsync(ctx->Linv, 0, sizeof(double) * ctx->P * Np * Np, ctx->stream));
     for (int64_t kb = 0; kb < nb; ++kb) {
         const int64_t c0 = kb * 64, r0 = c0 + 64;
         const int64_t pb = (c0 / NBO) * NBO, pe = imin64(pb + NBO, Np);     // outer panel [pb, pe)
@@ -345,17 +367,7 @@ int launch_potrf(gpb_ctx* ctx) {
                 hipLaunchKernelGGL(k_syrk<128>, grid, dim3(256), 0, ctx->stream, ctx->K, Np, c0, 64, r0, pe);
             }
         } else {                                        // panel finished: whole trailing matrix, K = panel width
-            const int64_t nt = (Np - r0 + 127) / 128;
-            const bool small = ctx->syrk_tile == 64 ||
-                               (ctx->syrk_tile == 0 && nt * (nt + 1) / 2 * ctx->P < 16 * (int64_t)ctx->num_cu);
-            if (small) {                                // few 128-wide tiles: 64-wide ones fill the chip (same bits)
-                const unsigned n64 = (unsigned)((Np - r0 + 63) / 64);
-                hipLaunchKernelGGL(k_syrk<64>, dim3(n64, n64, (unsigned)ctx->P), dim3(256), 0, ctx->stream, ctx->K, Np,
-                                   pb, (int)(pe - pb), r0, Np);
-            } else {
-                hipLaunchKernelGGL(k_syrk<128>, dim3((unsigned)nt, (unsigned)nt, (unsigned)ctx->P), dim3(256), 0,
-                                   ctx->stream, ctx->K, Np, pb, (int)(pe - pb), r0, Np);
-            }
+            launch_syrk_panel(ctx, pb, pe);
         }
     }
     GPB_HIP(hipGetLastError());
@@ -371,10 +383,14 @@ __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict
                                                         double* __restrict__ T, int64_t Np, int64_t hs,
                                                         int ngroups) {
     __shared__ TileLds<T_> lds;
-    const int p = blockIdx.z / ngroups, g = blockIdx.z % ngroups;
+    const int p = blockIdx.y / ngroups, g = blockIdx.y % ngroups;
     const int64_t c0 = (int64_t)g * 2 * hs, r0 = c0 + hs;
     const int64_t n2 = imin64(hs, Np - r0);
-    const int64_t mb = (int64_t)blockIdx.y * T_, nb = (int64_t)blockIdx.x * T_;
+    // longest K loops first: the dispatcher hands out blocks with z slowest, so z carries the index the K range
+    // depends on (phase 1: k in [nb, hs), longest at nb = 0; phase 2: k in [0, mb + T), longest at the last mb).
+    // In x-major order the last long tile started when the chip was already draining: 343 -> us at hs = 1024.
+    const int64_t mb = (int64_t)(PHASE == 1 ? blockIdx.x : gridDim.z - 1 - blockIdx.z) * T_;
+    const int64_t nb = (int64_t)(PHASE == 1 ? blockIdx.z : blockIdx.x) * T_;
     if (n2 <= 0 || mb >= n2 || nb >= hs) return;
     const int m_ext = (int)imin64(T_, n2 - mb), n_ext = (int)imin64(T_, hs - nb);
     const int64_t off = (int64_t)p * Np * Np;
@@ -406,13 +422,13 @@ int launch_trtri(gpb_ctx* ctx) {
         const bool small = ctx->trtri_tile == 64 || (ctx->trtri_tile == 0 && tiles128 < 16 * (int64_t)ctx->num_cu);
         if (small) {
             const unsigned tl = (unsigned)((hs + 63) / 64);
-            dim3 grid(tl, tl, (unsigned)(ngroups * ctx->P));
+            dim3 grid(tl, (unsigned)(ngroups * ctx->P), tl);
             hipLaunchKernelGGL((k_trtri_level<1, 64>), grid, dim3(256), 0, ctx->stream, ctx->K, ctx->Linv, ctx->T, Np,
                                hs, ngroups);
             hipLaunchKernelGGL((k_trtri_level<2, 64>), grid, dim3(256), 0, ctx->stream, ctx->K, ctx->Linv, ctx->T, Np,
                                hs, ngroups);
         } else {
-            dim3 grid((unsigned)tl128, (unsigned)tl128, (unsigned)(ngroups * ctx->P));
+            dim3 grid((unsigned)tl128, (unsigned)(ngroups * ctx->P), (unsigned)tl128);
             hipLaunchKernelGGL((k_trtri_level<1, 128>), grid, dim3(256), 0, ctx->stream, ctx->K, ctx->Linv, ctx->T,
                                Np, hs, ngroups);
             hipLaunchKernelGGL((k_trtri_level<2, 128>), grid, dim3(256), 0, ctx->stream, ctx->K, ctx->Linv, ctx->T,

@@ -101,6 +101,10 @@ struct gpb_ctx {
     int predict_waves = 4;          // waves per k_predict tile (4 or 8)
     unsigned* tile_counter = nullptr;   // 8 ticket queues (stride 16) + done counter [128]; re-armed by the kernel
     int64_t chol_outer = 512;      // outer panel width of the two-level blocked Cholesky
+    int chol_lookahead = 1;        // far part of a panel's trailing update on a side stream, under the next panel's chain
+    hipStream_t side_stream = nullptr;
+    std::vector<hipEvent_t> chol_events;
+    int chol_algo = 1;             // 1 = two launches per step, next diagonal block fused into the update (gpb_chol.hip); 0 = round 1
     int syrk_tile = 0;              // tile of the end-of-panel trailing updates (0 = by fill, 64, 128)
     int trtri_tile = 0;            // tile of the triangular-inverse levels (0 = by fill, 64, 128)
     int chol_inner_tile = 64;      // tile of the K=64 trailing updates inside an outer panel (64 or 128)

@@ -50,7 +50,7 @@ extern "C" {
 #define GPB_E_RCCL    (-6)
 
 /* gpb_gp_get selectors */
-#define GPB_GET_K      0  /* [P,N,N] K(X,X)+(noise+alpha)I as built (lower triangle valid after factor -> use before) */
+#define GPB_GET_K      0  /* [P,N,N] K(X,X)+(noise+alpha)I: blocks of the LOWER 64-block triangle as built (call before gpb_gp_factor, which overwrites them) */
 #define GPB_GET_L      1  /* [P,N,N] lower Cholesky factor, upper zeroed  == GPR.L_     */
 #define GPB_GET_LINV   2  /* [P,N,N] L^-1 (lower)                                       */
 #define GPB_GET_ALPHA  3  /* [P,N]   K^-1 z                               == GPR.alpha_ */
