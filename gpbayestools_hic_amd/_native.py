@@ -49,6 +49,9 @@ BOUNDARY = {
     "gpb_param_map": (C.c_int, [VP, VP, c_i64, VP]),
     "gpb_stretch_propose": (C.c_int, [VP, VP, c_i64, c_i64, C.c_int, c_u64, c_u64, C.c_double, VP, VP, C.c_int]),
     "gpb_stretch_accept": (C.c_int, [VP, VP, VP, c_i64, c_i64, C.c_int, c_u64, c_u64, VP, VP, VP, VP, C.c_int]),
+    "gpb_stretch_nan_count": (C.c_int, [VP, VP, C.c_int]),
+    "gpb_emcee_run": (C.c_int, [VP, VP, VP, c_i64, c_i64, c_u64, c_u64, C.c_double, C.c_int, VP, VP, C.c_double,
+                                C.c_double, VP, VP, VP]),
     "gpb_dist_uid": (C.c_int, [VP]),
     "gpb_dist_init": (C.c_int, [VP, C.c_int, C.c_int, VP]),
     "gpb_dist_allgather": (C.c_int, [VP, VP, VP, c_i64]),

@@ -99,6 +99,8 @@ extern "C" int gpb_ctx_create(int device, void* stream, gpb_ctx** out) {
     }
     if (hipMalloc(&ctx->notpd, sizeof(int)) != hipSuccess ||
         hipMemsetAsync(ctx->notpd, 0, sizeof(int), ctx->stream) != hipSuccess ||
+        hipMalloc(&ctx->n_nan, sizeof(long long)) != hipSuccess ||
+        hipMemsetAsync(ctx->n_nan, 0, sizeof(long long), ctx->stream) != hipSuccess ||
         hipMalloc(&ctx->tile_counter, 129 * sizeof(unsigned)) != hipSuccess ||
         hipMemsetAsync(ctx->tile_counter, 0, 129 * sizeof(unsigned), ctx->stream) != hipSuccess) {
         delete ctx;
@@ -128,6 +130,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     dev_free(&ctx->tile_trace);
     dev_free(&ctx->A); dev_free(&ctx->mu); dev_free(&ctx->scale); dev_free(&ctx->C0); dev_free(&ctx->yexp);
     dev_free(&ctx->Cexp); dev_free(&ctx->mvn_ws); dev_free(&ctx->notpd); dev_free(&ctx->tile_counter);
+    dev_free(&ctx->n_nan); dev_free(&ctx->mc_ws);
     for (hipEvent_t e : ctx->chol_events) (void)hipEventDestroy(e);
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -731,6 +734,7 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 13: if (value < 0 || value > 1024) return GPB_E_ARG; ctx->resident_occ = value; break;
         case 24: if (value < 0 || value > 1) return GPB_E_ARG; ctx->chol_algo = value; break;
         case 25: if (value < 0 || value > 1) return GPB_E_ARG; ctx->chol_lookahead = value; break;
+        case 26: if (value < 0 || value > 64) return GPB_E_ARG; ctx->sim_ranks = value; break;
         default: return GPB_E_ARG;
     }
     return 0;

@@ -91,6 +91,10 @@ struct gpb_ctx {
     double* mvn_ws = nullptr;      // global fallback for M > 128: [Wcap][M][M]
     int64_t mvn_ws_cap = 0;
     int* notpd = nullptr;          // device counter
+    long long* n_nan = nullptr;    // device counter: NaN log-probabilities seen by the stretch move's accept step
+    double* mc_ws = nullptr;       // gpb_emcee_run: proposals q[nh][d], factor[nh], log-probabilities lpq[nh]
+    int64_t mc_cap = 0;
+    int sim_ranks = 0;             // measurement hook: gpb_emcee_run evaluates 1/sim_ranks of every batch (one rank's share)
     int num_cu = 256;               // multiprocessor count of the device
     int wgs_per_cu64 = 7;           // persistent k_predict<64> workgroups per CU (6 resident at 80 VGPRs; 7 measured 1-2 % better)
     int wgs_per_cu128w8 = 2;        // ... for the 128-tile, 8-wave variant

@@ -827,7 +827,8 @@ __global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, 
 __global__ void k_accept(double* __restrict__ pos, double* __restrict__ lp, int64_t nhalf, int d, int half,
                          uint64_t seed, uint32_t step, const double* __restrict__ q,
                          const double* __restrict__ factor, const double* __restrict__ lpq,
-                         long long* __restrict__ naccept, int hb, int randomize) {
+                         long long* __restrict__ naccept, int hb, int randomize,
+                         long long* __restrict__ n_nan) {
     // 32 lanes per walker, all inside one wave: every lane takes the same decision from the OLD lp[idx]
     // (the load precedes lane 0's store in program order), then moves its own parameters
 #pragma clang fp contract(off)
@@ -840,6 +841,9 @@ __global__ void k_accept(double* __restrict__ pos, double* __restrict__ lp, int6
     const double u = u01(r.x, r.y);
     const int64_t idx = pi(2 * k + half);
     const double lpq_k = lpq[k];
+    // emcee raises "Probability function returned NaN" at the step it happens (emcee/ensemble.py compute_log_prob);
+    // here the proposal is rejected (NaN compares false) and counted, and the host raises at its next check
+    if (n_nan && t0 == 0 && lpq_k != lpq_k) atomicAdd(reinterpret_cast<unsigned long long*>(n_nan), 1ull);
     const double diff = (factor[k] + lpq_k) - lp[idx];
     const bool take = diff > log(u);                                 // emcee RedBlueMove.propose: f + nlp - lp[j] > log(rand)
     __builtin_amdgcn_wave_barrier();                                 // keep the loads above the stores below
@@ -924,7 +928,92 @@ extern "C" int gpb_stretch_accept(gpb_ctx* ctx, double* pos_dev, double* lp_dev,
     const int64_t nh = nwalkers / 2;
     hipLaunchKernelGGL(k_accept, dim3((unsigned)((nh * 32 + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev, lp_dev, nh,
                        (int)d, half, seed, (uint32_t)step, q_dev, factor_dev, lpq_dev,
-                       reinterpret_cast<long long*>(naccept_dev), half_bits(nwalkers), randomize_split ? 1 : 0);
+                       reinterpret_cast<long long*>(naccept_dev), half_bits(nwalkers), randomize_split ? 1 : 0,
+                       reinterpret_cast<long long*>(ctx->n_nan));
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gpb_stretch_nan_count(gpb_ctx* ctx, int64_t* count_host, int reset) {
+    if (!ctx || !count_host) return GPB_E_ARG;
+    GPB_HIP(hipSetDevice(ctx->device));
+    long long v = 0;
+    GPB_HIP(hipMemcpyAsync(&v, ctx->n_nan, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    if (reset) GPB_HIP(hipMemsetAsync(ctx->n_nan, 0, sizeof(long long), ctx->stream));
+    *count_host = (int64_t)v;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- device-resident sampling loop
+__global__ void k_store_step(const double* __restrict__ pos, const double* __restrict__ lp, double* __restrict__ chain,
+                             double* __restrict__ lpchain, int64_t nw, int d) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (chain && i < nw * d) chain[i] = pos[i];
+    if (lpchain && i < nw) lpchain[i] = lp[i];
+}
+
+__global__ void k_fill(double* __restrict__ x, int64_t n, double v) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) x[i] = v;
+}
+
+extern "C" int gpb_emcee_run(gpb_ctx* ctx, double* pos_dev, double* lp_dev, int64_t nwalkers, int64_t nsteps,
+                             uint64_t seed, uint64_t step0, double a, int randomize_split, const double* lo_dev,
+                             const double* hi_dev, double outside_value, double inside_const, double* chain_dev,
+                             double* lpchain_dev, int64_t* naccept_dev) {
+    if (!ctx || !pos_dev || !lp_dev || !lo_dev || !hi_dev || nsteps < 0) return GPB_E_ARG;
+    if (nwalkers < 2 || (nwalkers & 1) || nwalkers > (1ll << 30)) GPB_FAIL(GPB_E_ARG, "gpb_emcee_run: nwalkers must be even, 2 .. 2^30");
+    if (!ctx->have_like) GPB_FAIL(GPB_E_STATE, "gpb_emcee_run before gpb_like_set");
+    if (ctx->pmap_d_in > 0) GPB_FAIL(GPB_E_STATE, "gpb_emcee_run: emulators with a parameter map take the host-driven loop");
+    GPB_HIP(hipSetDevice(ctx->device));
+    const int64_t nh = nwalkers / 2, d = ctx->d;
+    int R = ctx->comm ? ctx->nranks : 1;
+    const int rank = ctx->comm ? ctx->rank : 0;
+    // measurement hook (tune key 26): behave like ONE rank of `sim_ranks` on a single GPU — evaluate the first
+    // nh / sim_ranks rows of every batch only (the other rows keep -inf: rejected) and still issue the collective
+    const bool sim = ctx->sim_ranks > 1 && R == 1;
+    if (sim) R = ctx->sim_ranks;
+    if (nh % R) GPB_FAIL(GPB_E_ARG, "gpb_emcee_run: half the ensemble must divide evenly over the ranks");
+    const int64_t chunk = nh / R, r0 = rank * chunk;
+    int rc = ensure_wcap(ctx, chunk);
+    if (rc) return rc;
+    if (ctx->mc_cap < nh) {                            // proposal workspace: q[nh][d], factor[nh], lpq[nh]
+        GPB_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->mc_ws) GPB_HIP(hipFree(ctx->mc_ws));
+        ctx->mc_ws = nullptr;
+        GPB_HIP(hipMalloc(&ctx->mc_ws, sizeof(double) * (size_t)(nh * (d + 2))));
+        ctx->mc_cap = nh;
+    }
+    double* q = ctx->mc_ws;
+    double* factor = q + nh * d;
+    double* lpq = factor + nh;
+    const int hb = half_bits(nwalkers), rnd = randomize_split ? 1 : 0;
+    const dim3 g32((unsigned)((nh * 32 + 255) / 256));
+    const bool fused = loglike_fuses_finalize(ctx, chunk);
+    if (sim) hipLaunchKernelGGL(k_fill, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, ctx->stream, lpq, nh, -INFINITY);
+    for (int64_t n = 0; n < nsteps; ++n) {
+        const uint32_t step = (uint32_t)(step0 + (uint64_t)n);
+        for (int half = 0; half < 2; ++half) {
+            hipLaunchKernelGGL(k_propose, g32, dim3(256), 0, ctx->stream, pos_dev, nh, (int)d, half, seed, step, a, q, factor,
+                               hb, rnd);
+            // this rank's rows of the batch: K*^T + mean partials, V = L^-1 K*^T with the fused sum of squares, block
+            // log-likelihood + prior box + constant (gpb_logpost's sequence)
+            if ((rc = launch_predict(ctx, q + r0 * d, chunk, true, !fused))) return rc;
+            if ((rc = launch_loglike(ctx, chunk, lpq + r0, false, fused, q + r0 * d, lo_dev, hi_dev, outside_value,
+                                     inside_const)))
+                return rc;
+            if (sim ? ctx->comm != nullptr : R > 1)                      // in place, on this stream
+                if ((rc = gpb_dist_allgather(ctx, lpq + r0, lpq, chunk))) return rc;
+            hipLaunchKernelGGL(k_accept, g32, dim3(256), 0, ctx->stream, pos_dev, lp_dev, nh, (int)d, half, seed, step, q,
+                               factor, lpq, reinterpret_cast<long long*>(naccept_dev), hb, rnd,
+                               reinterpret_cast<long long*>(ctx->n_nan));
+        }
+        if (chain_dev || lpchain_dev)
+            hipLaunchKernelGGL(k_store_step, dim3((unsigned)((nwalkers * d + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev,
+                               lp_dev, chain_dev ? chain_dev + n * nwalkers * d : nullptr,
+                               lpchain_dev ? lpchain_dev + n * nwalkers : nullptr, nwalkers, (int)d);
+    }
     GPB_HIP(hipGetLastError());
     return 0;
 }

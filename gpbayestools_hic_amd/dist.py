@@ -66,9 +66,16 @@ class WalkerSharding:
         self.direct = engine
         return self
 
+    def _coll_device(self):
+        """where torch.distributed's own collectives of this group want their tensors (gloo: host, nccl: this GPU)"""
+        import torch
+        if self.dist.get_backend(self.group) == "gloo" or not torch.cuda.is_available():
+            return torch.device("cpu")
+        return torch.device("cuda", torch.cuda.current_device())
+
     def _all_ok(self, ok):
         import torch
-        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self._coll_device())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
         return int(t.item()) == 1
 
@@ -94,7 +101,7 @@ class WalkerSharding:
         if not self._all_ok(why is None):
             self._drop_direct()
             return why or "direct path could not be set up on another rank"
-        n, dev = 64, torch.device("cuda", torch.cuda.current_device())
+        n, dev = 64, self._coll_device()
         mine = torch.arange(n, dtype=torch.float64, device=dev) + 1000.0 * self.rank
         ref = torch.empty(n * self.world, dtype=torch.float64, device=dev)
         self.dist.all_gather_into_tensor(ref, mine, group=self.group)
@@ -102,7 +109,8 @@ class WalkerSharding:
             got = torch.full_like(ref, -1.0)
             got[self.rank * n:(self.rank + 1) * n] = mine
             engine.dist_allgather(got[self.rank * n:(self.rank + 1) * n], got)
-            torch.cuda.synchronize()
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
             if not torch.equal(ref, got):
                 why = "direct all-gather disagrees with torch.distributed"
         except Exception as e:
@@ -138,7 +146,7 @@ class WalkerSharding:
             # (send buffer = receive buffer + rank*chunk) — no staging copies on the step's critical path
             mine = out[r0:r1]
             fn(X[r0:r1], mine)
-            if self.direct is not None and out.is_cuda:
+            if self.direct is not None:
                 self.direct.dist_allgather(mine, out)
             else:
                 self.dist.all_gather_into_tensor(out, mine, group=self.group)
@@ -153,7 +161,7 @@ class WalkerSharding:
         if self.world == 1:
             out.copy_(local[:W])
             return out
-        if self.direct is not None and X.is_cuda:
+        if self.direct is not None:
             self.direct.dist_allgather(local, gathered)
         else:
             self.dist.all_gather_into_tensor(gathered, local, group=self.group)

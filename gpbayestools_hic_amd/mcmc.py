@@ -152,6 +152,18 @@ class Chain:
                              "the fused likelihood needs it block-diagonal")
         self._like_sig = (sig[0], sig[1], sig[2], tuple(id(e._engine) for e in self.emuList))
 
+    inside_const = EXTRA_STD_CONST               # what the reference adds to every row inside the box
+
+    def _box(self, device):
+        """the prior box resident in HBM, uploaded once per device"""
+        import torch
+        key = (str(device), self.min.tobytes(), self.max.tobytes())
+        if getattr(self, "_box_key", None) != key:
+            self._box_dev = (torch.as_tensor(self.min, dtype=torch.float64, device=device),
+                             torch.as_tensor(self.max, dtype=torch.float64, device=device))
+            self._box_key = key
+        return self._box_dev
+
     def log_prob_device(self, X_dev, out=None, outside=-np.inf, lo_dev=None, hi_dev=None):
         """Device-resident log-posterior: X_dev torch.float64 cuda [W,ndim] -> lp [W] (no host
         sync).  Used by the resident sampler; `log_posterior`/`log_likelihood` wrap it."""
@@ -159,13 +171,8 @@ class Chain:
         self._prepare_blocks()
         if out is None:
             out = torch.empty(X_dev.shape[0], dtype=torch.float64, device=X_dev.device)
-        if lo_dev is None:                       # prior box resident in HBM, uploaded once per device
-            key = (str(X_dev.device), self.min.tobytes(), self.max.tobytes())
-            if getattr(self, "_box_key", None) != key:
-                self._box_dev = (torch.as_tensor(self.min, dtype=torch.float64, device=X_dev.device),
-                                 torch.as_tensor(self.max, dtype=torch.float64, device=X_dev.device))
-                self._box_key = key
-            lo_dev, hi_dev = self._box_dev
+        if lo_dev is None:
+            lo_dev, hi_dev = self._box(X_dev.device)
         X_dev = X_dev.contiguous()
         last = len(self.emuList) - 1
         if X_dev.shape[1] != self.ndim:

@@ -44,6 +44,7 @@ class StretchSampler:
             else int(seed)
         self.device = torch.device("cuda", chain.device if device is None else device)
         self.sharding = sharding
+        self._logprob_override = logprob_device is not None
         self._logprob = logprob_device or chain.log_prob_device
         self._eng = None
         self._step_counter = 0
@@ -80,6 +81,34 @@ class StretchSampler:
         self.naccept.zero_()
 
     # ------------------------------------------------------------------ main loop
+    def _resident_engine(self):
+        """The engine whose gpb_emcee_run can drive the whole loop from C (no Python per step), or None: the chain must
+        be this package's Chain with ONE emulator and no parameter map, no log-probability override, and any sharding
+        must go through the C ABI's own communicator on that engine with an even split (WalkerSharding.try_direct)."""
+        ch = self.chain_obj
+        emus = getattr(ch, "emuList", None)
+        if self._logprob_override or not emus or len(emus) != 1 or not hasattr(ch, "_prepare_blocks"):
+            return None
+        emu = emus[0]
+        if not hasattr(emu, "_engine_ready") or getattr(emu, "parameterTrafoPCA_", False):
+            return None
+        eng = emu._engine_ready()
+        sh = self.sharding
+        if sh is not None:
+            if getattr(sh, "direct", None) is not eng or (self.nwalkers // 2) % sh.world:
+                return None
+        elif getattr(eng, "_dist_world", 0) > 1:
+            return None                    # a communicator is installed but this sampler was not told to shard
+        if eng.d != self.ndim:
+            return None
+        return eng
+
+    def _check_nan(self, eng):
+        n = nat.c_i64(0)
+        eng._ck(eng.lib.gpb_stretch_nan_count(eng.h, nat.C.byref(n), 1))
+        if n.value:
+            raise ValueError("Probability function returned NaN")       # emcee's contract (emcee/ensemble.py)
+
     def run(self, X0, nsteps, status=None, store=True):
         """Advance `nsteps` stretch-move steps from X0[nwalkers, ndim]; returns the final positions
         (numpy).  Mirrors LoggingEnsembleSampler.run_mcmc (src/mcmc.py:69-92)."""
@@ -87,37 +116,57 @@ class StretchSampler:
         eng = self._engine()
         lib, h = eng.lib, eng.h
         nw, d = self.nwalkers, self.ndim
+        eng._track_stream()
         if X0 is not None:            # X0=None: continue from the resident state
             self.pos.copy_(torch.as_tensor(np.ascontiguousarray(X0, dtype=np.float64)))
             self._eval(self.pos, self.lp)
+            if torch.isnan(self.lp).any().item():
+                raise ValueError("The initial log_prob was NaN")          # emcee's message
+        cd = ld = None
         if store:
             cd = torch.empty((nsteps, nw, d), dtype=torch.float64, device=self.device)
             ld = torch.empty((nsteps, nw), dtype=torch.float64, device=self.device)
         if status is None:
             status = max(nsteps // 10, 1)
-        for n in range(1, nsteps + 1):
-            step = self._step_counter
-            self._step_counter += 1
-            for half in (0, 1):
-                eng._ck(lib.gpb_stretch_propose(h, nat.ptr(self.pos), nw, d, half, self.seed, step, self.a,
-                                                nat.ptr(self.q), nat.ptr(self.factor), self.randomize_split))
-                self._eval(self.q, self.lpq)
-                eng._ck(lib.gpb_stretch_accept(h, nat.ptr(self.pos), nat.ptr(self.lp), nw, d, half, self.seed,
-                                               step, nat.ptr(self.q), nat.ptr(self.factor), nat.ptr(self.lpq),
-                                               nat.ptr(self.naccept), self.randomize_split))
-            if store:
-                cd[n - 1].copy_(self.pos)
-                ld[n - 1].copy_(self.lp)
-            self.iterations += 1
+        res = self._resident_engine()
+        n = 0
+        while n < nsteps:
+            m = min(status - n % status, nsteps - n)          # up to the next status line
+            if res is not None:
+                # the C ABI enqueues all m steps itself (gpb_emcee_run): propose -> GP predict -> block likelihood +
+                # prior box -> [in-stream all-gather] -> accept, no Python in between
+                self.chain_obj._prepare_blocks()
+                lo, hi = self.chain_obj._box(self.device)
+                res._ck(lib.gpb_emcee_run(res.h, nat.ptr(self.pos), nat.ptr(self.lp), nw, m, self.seed,
+                                          self._step_counter, self.a, self.randomize_split, nat.ptr(lo), nat.ptr(hi),
+                                          float("-inf"), self.chain_obj.inside_const,
+                                          nat.ptr(cd[n:n + m]) if store else None,
+                                          nat.ptr(ld[n:n + m]) if store else None, nat.ptr(self.naccept)))
+                self._step_counter += m
+            else:
+                for i in range(m):
+                    step = self._step_counter
+                    self._step_counter += 1
+                    for half in (0, 1):
+                        eng._ck(lib.gpb_stretch_propose(h, nat.ptr(self.pos), nw, d, half, self.seed, step, self.a,
+                                                        nat.ptr(self.q), nat.ptr(self.factor), self.randomize_split))
+                        self._eval(self.q, self.lpq)
+                        eng._ck(lib.gpb_stretch_accept(h, nat.ptr(self.pos), nat.ptr(self.lp), nw, d, half, self.seed,
+                                                       step, nat.ptr(self.q), nat.ptr(self.factor), nat.ptr(self.lpq),
+                                                       nat.ptr(self.naccept), self.randomize_split))
+                    if store:
+                        cd[n + i].copy_(self.pos)
+                        ld[n + i].copy_(self.lp)
+            n += m
+            self.iterations += m
             if n % status == 0 or n == nsteps:
+                self._check_nan(res if res is not None else eng)          # synchronises: once per status line
                 af = self.acceptance_fraction
                 log.info("step %d: acceptance fraction: mean %.4f, std %.4f, min %.4f, max %.4f",
                          n, af.mean(), af.std(), af.min(), af.max())
         if store:
             self._chain_dev = cd if self._chain_dev is None else torch.cat([self._chain_dev, cd], 0)
             self._lp_dev = ld if self._lp_dev is None else torch.cat([self._lp_dev, ld], 0)
-        if torch.isnan(self.lp).any().item():
-            raise ValueError("Probability function returned NaN")       # emcee's contract
         return self.pos.cpu().numpy()
 
     # ------------------------------------------------------------------ emcee-style accessors

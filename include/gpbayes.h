@@ -179,6 +179,24 @@ int gpb_stretch_accept(gpb_ctx* ctx, double* pos_dev, double* lp_dev /*[nw]*/, i
                        int half, uint64_t seed, uint64_t step,
                        const double* q_dev, const double* factor_dev, const double* lpq_dev /*[nw/2]*/,
                        int64_t* naccept_dev /*[nw]*/, int randomize_split);
+/* NaN log-probabilities the accept step has seen since the last reset (emcee raises "Probability function returned
+ * NaN" when one occurs, emcee/ensemble.py; on the device such a proposal is rejected and counted).  Synchronises. */
+int gpb_stretch_nan_count(gpb_ctx* ctx, int64_t* count_host, int reset);
+
+/* gpb_emcee_run <- the loop emcee.EnsembleSampler.sample runs under LoggingEnsembleSampler.run_mcmc
+ *                  (src/mcmc.py:68-92, 372-412) with Chain.log_posterior (src/mcmc.py:261-299) as the log-probability,
+ * for a chain whose observables come from THIS context's emulator alone: nsteps stretch-move steps (two half-ensemble
+ * updates each: propose -> GP predict -> block log-likelihood + prior box -> accept), enqueued back to back on the
+ * context's stream with no host involvement per step.  pos/lp hold the ensemble and its log-probabilities on entry
+ * and on exit; chain_dev [nsteps, nw, d] / lpchain_dev [nsteps, nw] (either may be NULL) receive the state after every
+ * step; steps are numbered step0, step0 + 1, ... in the counter-based generator.  With a communicator installed
+ * (gpb_dist_init) every rank evaluates its rows of each half-ensemble batch and one in-stream all-gather per batch
+ * completes the vector; nwalkers / 2 must then divide evenly over the ranks.  Asynchronous. */
+int gpb_emcee_run(gpb_ctx* ctx, double* pos_dev /*[nw,d]*/, double* lp_dev /*[nw]*/, int64_t nwalkers, int64_t nsteps,
+                  uint64_t seed, uint64_t step0, double a, int randomize_split,
+                  const double* lo_dev /*[d]*/, const double* hi_dev /*[d]*/, double outside_value, double inside_const,
+                  double* chain_dev, double* lpchain_dev, int64_t* naccept_dev /*[nw]*/);
+
 /* ---- walker sharding over RCCL (one process per GPU) ------------------------------ *
  * gpb_dist_uid: rank 0 obtains a 128-byte ncclUniqueId to broadcast out of band.
  * gpb_dist_init / gpb_dist_allgather: in-stream ncclAllGather of per-walker

@@ -152,3 +152,101 @@ def test_fit_sharding_world2_matches_unsharded():
             assert np.array_equal(got[rank][P][0], th) and np.array_equal(got[rank][P][1], val), (rank, P)
         assert got[0][P][2] == [list(range(0, P, 2))]
         assert got[1][P][2] == ([[1]] if P == 3 else [])
+
+
+# ---------------------------------------------------------------- more ranks, and the direct-collective hand-shake
+class _FakeDirectEngine:
+    """Stands in for GPEngine's gpb_dist_* binding on the CPU tier: the "direct" all-gather is carried by gloo, and
+    one rank can be told to fail at a chosen stage (uid / init / allgather / wrong data)."""
+
+    def __init__(self, rank, fail_rank=-1, fail_at=None):
+        self.rank, self.fail_rank, self.fail_at = rank, fail_rank, fail_at
+        self.calls = []
+
+    def _maybe(self, stage):
+        self.calls.append(stage)
+        if self.rank == self.fail_rank and self.fail_at == stage:
+            raise RuntimeError("injected failure at %s" % stage)
+
+    def dist_uid(self):
+        self._maybe("uid")
+        return b"u" * 128
+
+    def dist_init(self, rank, world, uid):
+        assert uid == b"u" * 128
+        self._maybe("init")
+
+    def dist_allgather(self, send, recv):
+        dist.all_gather_into_tensor(recv, send.clone())        # every rank takes part, then one may report a failure
+        self._maybe("allgather")
+        if self.rank == self.fail_rank and self.fail_at == "wrong":
+            recv[0] += 1.0
+        return recv
+
+    def dist_finalize(self):
+        self.calls.append("finalize")
+
+
+def _many_worker(rank, world, port, q):
+    sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from gpbayestools_hic_amd.dist import WalkerSharding, init_from_env
+    init_from_env(backend="gloo")
+    g, fn = _oracle_logpost()
+    res = {}
+    # (scenario, failing rank, stage): every rank must come out with the SAME decision and the same numbers
+    for name, fail_rank, stage in (("ok", -1, None), ("uid", 0, "uid"), ("init", world - 1, "init"),
+                                   ("allgather", 1, "allgather"), ("wrong", world // 2, "wrong")):
+        sh = WalkerSharding()
+        eng = _FakeDirectEngine(rank, fail_rank, stage)
+        why = sh.try_direct(eng)
+        outs = {}
+        for W in (64, 37, 3):                   # even split (in-place path), ragged, fewer rows than ranks
+            X = torch.from_numpy(np.ascontiguousarray(g["Xw"][:W]))
+            out = torch.empty(W, dtype=torch.float64)
+            sh.logprob(fn, X, out)
+            outs[W] = out.numpy().copy()
+        res[name] = (why, sh.direct is not None, outs, list(eng.calls))
+    dist.barrier()
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_walker_sharding_more_ranks_and_direct_handshake(world):
+    """world 4 and 8 over gloo with the CPU oracle as the evaluator: the sharded vector equals the unsharded one on
+    every rank, and WalkerSharding.try_direct keeps the C-ABI collective only when it worked on ALL ranks — a rank
+    that fails at any stage (no uid, communicator refused, collective raises, collective returns wrong data) makes
+    every rank fall back to torch.distributed, after the same number of collectives on each."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_many_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    g, fn = _oracle_logpost()
+    refs = {}
+    for W in (64, 37, 3):
+        X = torch.from_numpy(np.ascontiguousarray(g["Xw"][:W]))
+        refs[W] = fn(X, torch.empty(W, dtype=torch.float64)).numpy()
+    for name in ("ok", "uid", "init", "allgather", "wrong"):
+        kept = {got[r][name][1] for r in range(world)}
+        assert kept == ({True} if name == "ok" else {False}), (name, kept)       # unanimous
+        for r in range(world):
+            why, direct, outs, calls = got[r][name]
+            assert (why is None) == (name == "ok"), (name, r, why)
+            for W in (64, 37, 3):
+                # every rank holds the SAME vector, bit for bit; against the unsharded evaluation the CPU oracle's BLAS
+                # may round a 16-row shard differently from a 64-row batch (the HIP path does not: tested on the GPU)
+                assert np.array_equal(outs[W], got[0][name][2][W], equal_nan=True), (name, r, W)
+                fin = np.isfinite(refs[W])
+                assert np.array_equal(np.isfinite(outs[W]), fin)
+                assert np.allclose(outs[W][fin], refs[W][fin], rtol=1e-12, atol=0.0), (name, r, W)
+            # a communicator that was built is torn down again wherever the hand-shake is called off
+            built = name in ("allgather", "wrong") or (name == "init" and r != world - 1)
+            assert ("finalize" in calls) == built, (name, r, calls)
+    # in the good case the direct path really carried the even-split batches
+    assert all("allgather" in got[r]["ok"][3] for r in range(world))

@@ -155,3 +155,83 @@ def test_split_permutation_is_a_bijection_and_changes_per_step():
             frac = np.mean(outs[0][0::2] % 2 == 0)
             assert 0.3 < frac < 0.7
     eng.close()
+
+
+def test_resident_c_loop_equals_the_host_driven_loop(tmp_path):
+    """gpb_emcee_run (the C ABI enqueues every kernel of every step) against the loop that drives
+    gpb_stretch_propose / log_prob_device / gpb_stretch_accept from Python: same chain, log-probabilities and
+    acceptance counts bit for bit, also when continued in pieces and when the status interval cuts the run"""
+    from gpbayestools_hic_amd import StretchSampler, synth
+    from gpbayestools_hic_amd.workload import build_chain
+    chain, emu, info = build_chain(1, workdir=str(tmp_path))
+    nw, d = 48, info["d"]
+    X0 = synth.walkers(nw, d, seed=21)
+    X0[5, 0] = 1.7                                            # a walker that starts outside the prior box
+    c = StretchSampler(chain, nw, seed=5)
+    assert c._resident_engine() is emu._engine_ready()
+    c.run(X0, 7, status=3)
+    c.run(None, 6, status=100)
+    h = StretchSampler(chain, nw, seed=5)
+    h._resident_engine = lambda: None                         # force the host-driven loop
+    h.run(X0, 13, status=4)
+    assert np.array_equal(c.chain, h.chain) and np.array_equal(c.lnprobability, h.lnprobability)
+    assert np.array_equal(c.naccept.cpu().numpy(), h.naccept.cpu().numpy()) and c.iterations == h.iterations == 13
+    assert np.isneginf(c.lnprobability[5, 0]) or np.isfinite(c.lnprobability[5, 0])
+    # store=False keeps no chain but walks the same ensemble
+    n = StretchSampler(chain, nw, seed=5)
+    last = n.run(X0, 13, store=False)
+    assert np.array_equal(last, c.chain[:, -1])
+
+
+def test_resident_loop_with_a_one_rank_communicator(tmp_path):
+    """the sharded form of gpb_emcee_run (rows of this rank + in-stream ncclAllGather) with the only communicator a
+    one-GPU box can form: world 1, same numbers as the unsharded loop"""
+    from gpbayestools_hic_amd import StretchSampler, synth
+    from gpbayestools_hic_amd.workload import build_chain
+    chain, emu, info = build_chain(1, workdir=str(tmp_path))
+    eng = emu._engine_ready()
+    nw = 32
+    X0 = synth.walkers(nw, info["d"], seed=22)
+    ref = StretchSampler(chain, nw, seed=9)
+    ref.run(X0, 8)
+    try:
+        eng.dist_init(0, 1, eng.dist_uid())
+    except Exception as e:
+        pytest.skip("no RCCL communicator on this box: %s" % e)
+    sh = types.SimpleNamespace(world=1, rank=0, direct=eng,
+                               logprob=lambda fn, X, out: fn(X, out))
+    s = StretchSampler(chain, nw, seed=9, sharding=sh)
+    assert s._resident_engine() is eng
+    s.run(X0, 8)
+    eng.dist_finalize()
+    assert np.array_equal(s.chain, ref.chain) and np.array_equal(s.lnprobability, ref.lnprobability)
+    # the measurement hook: one rank's share of a 4-way split (rows it does not evaluate are rejected)
+    eng.tune("sim_ranks", 4)
+    m = StretchSampler(chain, nw, seed=9)
+    m.run(X0, 4)
+    eng.tune("sim_ranks", 0)
+    assert m.chain.shape == (nw, 4, info["d"]) and np.all(np.isfinite(m.chain))
+
+
+def test_nan_log_probability_raises_like_emcee(tmp_path):
+    """emcee aborts with "Probability function returned NaN"; on the device a NaN proposal is rejected and counted, and
+    the sampler raises at its next status check (both loops)"""
+    from gpbayestools_hic_amd import StretchSampler, synth
+    from gpbayestools_hic_amd.workload import build_chain
+    chain, emu, info = build_chain(1, workdir=str(tmp_path))
+    nw = 32
+    X0 = synth.walkers(nw, info["d"], seed=23)
+    for force_host in (False, True):
+        good_cov = chain.expdata_cov
+        s = StretchSampler(chain, nw, seed=3)
+        if force_host:
+            s._resident_engine = lambda: None
+        s.run(X0, 4)
+        chain.expdata_cov = -0.5 * np.eye(chain.nobs)          # an indefinite covariance: every block is NaN
+        with pytest.raises(ValueError, match="NaN"):
+            s.run(None, 3)
+        with pytest.raises(ValueError, match="initial log_prob was NaN"):
+            StretchSampler(chain, nw, seed=3).run(X0, 1)
+        chain.expdata_cov = good_cov
+        s2 = StretchSampler(chain, nw, seed=3)
+        s2.run(X0, 2)                                          # the counter was reset: a clean run passes again

@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
-"""Single-GPU estimate of the per-rank step time under R-way walker sharding (no collective):
-rank 0's shard is evaluated for real, the other rows are left untouched.  Timing only."""
+"""Single-GPU measurement of ONE RANK's share of a walker-sharded step (BASELINE config 4, 4096 walkers):
+gpb_emcee_run with the `sim_ranks` hook evaluates the first 1/R of every half-ensemble batch — exactly what rank 0 of R
+does — and, with a one-rank RCCL communicator installed, still enqueues the two in-stream all-gathers per step
+(ncclAllGather on the kernels' stream: launch and protocol cost without a wire).  Also: the same share through the
+host-driven loop (Python enqueues every kernel), to show what the C loop removes.
+
+    python tools/gpu_shard_sim.py [R ...]          # default 1 2 4 8
+"""
 import json
 import os
 import sys
@@ -10,15 +16,26 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 class FakeShard:
+    """host-driven loop, rank 0's rows only (round 1's simulation)"""
+
     def __init__(self, world):
         self.world = world
 
     def logprob(self, fn, X, out):
-        W = X.shape[0]
-        chunk = -(-W // self.world)
+        chunk = -(-X.shape[0] // self.world)
         fn(X[:chunk], out[:chunk])
-        out[chunk:].fill_(-1e9)           # never accepted; stands in for the gathered remote rows
+        out[chunk:].fill_(-1e9)
         return out
+
+
+def timed(sampler, steps=40):
+    import torch
+    sampler.run(None, 5, store=False, status=10 ** 9)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sampler.run(None, steps, store=False, status=10 ** 9)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
 
 
 def main():
@@ -27,42 +44,32 @@ def main():
     from gpbayestools_hic_amd.sampler import StretchSampler
     from gpbayestools_hic_amd.workload import build_chain
     chain, emu, info = build_chain(4)
+    eng = emu._engine_ready()
     nw = 2 * info["W"]
+    X0 = synth.walkers(nw, info["d"])
     worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+    comm = False
+    try:
+        eng.dist_init(0, 1, eng.dist_uid())          # one-rank communicator: the collective is enqueued for real
+        comm = True
+    except Exception as e:                           # librccl missing: time without the collective and say so
+        print(json.dumps({"warning": "no RCCL communicator: %s" % e}), flush=True)
     for world in worlds:
-        s = StretchSampler(chain, nw, seed=1, sharding=FakeShard(world) if world > 1 else None)
-        s.run(synth.walkers(nw, info["d"]), 3, store=False, status=10 ** 9)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        s.run(None, 20, store=False, status=10 ** 9)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 20
-        # host-only enqueue cost: same loop against a stubbed log-probability (no GPU work to wait for)
-        s2 = StretchSampler(chain, nw, seed=1, logprob_device=lambda X, out: out)
-        s2.run(synth.walkers(nw, info["d"]), 2, store=False, status=10 ** 9)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        s2.run(None, 50, store=False, status=10 ** 9)
-        host_stub = (time.perf_counter() - t0) / 50
-        # enqueue time of the real loop (returns before the GPU has finished)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(1):
-            s._step_loop_only = True
-        import types
-        t0 = time.perf_counter()
-        n_enq = 30
-        eng = s._engine(); lib, h = eng.lib, eng.h
-        from gpbayestools_hic_amd import _native as nat
-        for step in range(n_enq):
-            for half in (0, 1):
-                eng._ck(lib.gpb_stretch_propose(h, nat.ptr(s.pos), nw, s.ndim, half, s.seed, 10000 + step, s.a, nat.ptr(s.q), nat.ptr(s.factor), 1))
-                s._eval(s.q, s.lpq)
-                eng._ck(lib.gpb_stretch_accept(h, nat.ptr(s.pos), nat.ptr(s.lp), nw, s.ndim, half, s.seed, 10000 + step, nat.ptr(s.q), nat.ptr(s.factor), nat.ptr(s.lpq), nat.ptr(s.naccept), 1))
-        host_enq = (time.perf_counter() - t0) / n_enq
-        torch.cuda.synchronize()
-        print(json.dumps({"world": world, "ms_per_step": round(dt * 1e3, 3), "host_enqueue_ms_per_step": round(host_enq * 1e3, 3),
-                          "host_stub_ms_per_step": round(host_stub * 1e3, 3)}), flush=True)
+        row = {"ranks_simulated": world, "walkers_per_rank_per_batch": nw // 2 // world, "collective_enqueued": comm and world > 1}
+        eng.tune("sim_ranks", world if world > 1 else 0)
+        s = StretchSampler(chain, nw, seed=1)
+        assert s._resident_engine() is eng
+        s.run(X0, 3, store=False, status=10 ** 9)
+        row["c_loop_ms_per_step"] = round(timed(s), 4)
+        eng.tune("sim_ranks", 0)
+        s2 = StretchSampler(chain, nw, seed=1, sharding=FakeShard(world) if world > 1 else None)
+        s2._resident_engine = lambda: None            # force the host-driven loop
+        s2.run(X0, 3, store=False, status=10 ** 9)
+        row["python_loop_ms_per_step_no_collective"] = round(timed(s2), 4)
+        print(json.dumps(row), flush=True)
+    base = None
+    if comm:
+        eng.dist_finalize()
 
 
 if __name__ == "__main__":
