@@ -193,6 +193,9 @@ def main():
                            else "torch.distributed " + dist.get_backend()
                                 + (" (direct path not used: %s)" % direct_why if direct_why else ""))},
             "acceptance_fraction": acc, "ranks_hold_identical_ensemble": consistent,
+            # proposals outside the prior box cost nothing, here as in the reference (src/mcmc.py:275-283): share of the
+            # timed region's proposal rows (this rank's) that lay inside the box and were evaluated
+            "rows_inside_box_fraction": (units / (launches * P * (nwalkers // 2 // world))) if launches else None,
             "gflop_per_step_algorithmic": flops_per_walker(N, d, P, M, info["kernel"]) * nwalkers / 1e9,
             "roofline": {"bound": "mfma", "kernel": "k_predict (V = L^-1 K*^T, fused sum of squares)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -200,14 +203,15 @@ def main():
                          "launches": launches, "avg_launch_ms": kms / max(launches, 1)},
         }
         # HBM-side traffic of the dominant kernel: PMC counters need rocprofv3, so the per-launch figure comes
-        # from the committed summary of the same command (profiles/r01_pmc_traffic.json), when it matches.
+        # from the committed summary of the same command (profiles/r02_pmc_traffic.json), when it matches.
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
                 pmc = json.load(f)
             wl = pmc["workload"]
-            if (wl["config"], wl["N"], wl["P"], wl["W_per_launch"]) == (args.config, N, P, nwalkers // 2) and world == 1:
+            if (wl["config"], wl["N"], wl["P"], wl["W_per_launch"]) == (args.config, N, P, nwalkers // 2) and world == 1 \
+                    and wl.get("compacted") and out["rows_inside_box_fraction"] and out["rows_inside_box_fraction"] < 0.6:
                 out["roofline"]["traffic"] = pmc["k_predict"]["bytes_per_launch_corrected"]
-                out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)"
+                out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_pmc_traffic.json)"
                 out["roofline"]["algorithmic_bytes"] = pmc["k_predict"]["algorithmic_bytes_per_launch"]
         except Exception:
             pass

@@ -99,6 +99,8 @@ extern "C" int gpb_ctx_create(int device, void* stream, gpb_ctx** out) {
     }
     if (hipMalloc(&ctx->notpd, sizeof(int)) != hipSuccess ||
         hipMemsetAsync(ctx->notpd, 0, sizeof(int), ctx->stream) != hipSuccess ||
+        hipMalloc(&ctx->rows_live, sizeof(unsigned long long)) != hipSuccess ||
+        hipMemsetAsync(ctx->rows_live, 0, sizeof(unsigned long long), ctx->stream) != hipSuccess ||
         hipMalloc(&ctx->n_nan, sizeof(long long)) != hipSuccess ||
         hipMemsetAsync(ctx->n_nan, 0, sizeof(long long), ctx->stream) != hipSuccess ||
         hipMalloc(&ctx->tile_counter, 129 * sizeof(unsigned)) != hipSuccess ||
@@ -130,7 +132,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     dev_free(&ctx->tile_trace);
     dev_free(&ctx->A); dev_free(&ctx->mu); dev_free(&ctx->scale); dev_free(&ctx->C0); dev_free(&ctx->yexp);
     dev_free(&ctx->Cexp); dev_free(&ctx->mvn_ws); dev_free(&ctx->notpd); dev_free(&ctx->tile_counter);
-    dev_free(&ctx->n_nan); dev_free(&ctx->mc_ws);
+    dev_free(&ctx->n_nan); dev_free(&ctx->mc_ws); dev_free(&ctx->rows_live); dev_free(&ctx->cmp_idx);
     for (hipEvent_t e : ctx->chol_events) (void)hipEventDestroy(e);
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -180,7 +182,7 @@ extern "C" int gpb_gp_set(gpb_ctx* ctx, int64_t N, int64_t d, int64_t P, const d
     const int64_t Np = ctx->Np;
     // workspaces sized by (Np, P) are stale now
     dev_free(&ctx->KsT); dev_free(&ctx->mpart); dev_free(&ctx->spart); dev_free(&ctx->mean_pc);
-    dev_free(&ctx->var_pc); dev_free(&ctx->Xs); dev_free(&ctx->estd);
+    dev_free(&ctx->var_pc); dev_free(&ctx->Xs); dev_free(&ctx->estd); dev_free(&ctx->cmp_idx);
     ctx->Wcap = 0;
     int rc;
     if ((rc = dev_alloc(ctx, &ctx->X, Np * dpad))) return rc;
@@ -589,6 +591,13 @@ extern "C" int gpb_logpost(gpb_ctx* ctx, const double* Xs_dev, int64_t W, double
     int rc = ensure_wcap(ctx, W);
     if (rc) return rc;
     const bool fused = loglike_fuses_finalize(ctx, W);
+    if (!accumulate && compaction_applies(ctx)) {
+        // the rows inside the prior box only, as the reference does (src/mcmc.py:194-203, 275-283); no host round trip
+        if ((rc = launch_compact(ctx, Xs_dev, W, lo_dev, hi_dev, outside_value, ll_dev))) return rc;
+        if ((rc = launch_predict(ctx, ctx->Xs, W, true, !fused, ctx->cmp_idx))) return rc;
+        return launch_loglike(ctx, W, ll_dev, false, fused, nullptr, nullptr, nullptr, outside_value, inside_const,
+                              ctx->cmp_idx);
+    }
     if ((rc = launch_predict(ctx, Xs_dev, W, true, !fused))) return rc;
     return launch_loglike(ctx, W, ll_dev, accumulate != 0, fused, Xs_dev, lo_dev, hi_dev, outside_value, inside_const);
 }
@@ -735,6 +744,7 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 24: if (value < 0 || value > 1) return GPB_E_ARG; ctx->chol_algo = value; break;
         case 25: if (value < 0 || value > 1) return GPB_E_ARG; ctx->chol_lookahead = value; break;
         case 26: if (value < 0 || value > 64) return GPB_E_ARG; ctx->sim_ranks = value; break;
+        case 27: if (value < 0 || value > 1) return GPB_E_ARG; ctx->compact = value; break;
         default: return GPB_E_ARG;
     }
     return 0;
@@ -763,6 +773,13 @@ extern "C" int gpb_profile_read(gpb_ctx* ctx, int64_t* launches, double* total_m
         ms += t;
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
+    }
+    if (ctx->prof_compacted) {                       // compacted launches: the rows they evaluated were counted on the device
+        unsigned long long live = 0;
+        GPB_HIP(hipMemcpy(&live, ctx->rows_live, sizeof(live), hipMemcpyDeviceToHost));
+        GPB_HIP(hipMemset(ctx->rows_live, 0, sizeof(live)));
+        ctx->prof_units += (double)ctx->P * (double)live;
+        ctx->prof_compacted = false;
     }
     *launches = (int64_t)ctx->prof_events.size();
     *total_ms = ms;

@@ -62,6 +62,10 @@ struct gpb_ctx {
     double* spart = nullptr;       // [Np/64][P][Wcap]  sum-of-squares partials per 64-row block
     double* mean_pc = nullptr;     // [P][Wcap]
     double* var_pc = nullptr;      // [P][Wcap]
+    int* cmp_idx = nullptr;        // compaction of a log-posterior batch to the rows inside the prior box: [0] = count, [4..] = row indices
+    int compact = 1;               // gpb_logpost / gpb_emcee_run evaluate the rows inside the box only (the reference: src/mcmc.py:278-283)
+    unsigned long long* rows_live = nullptr;   // device counter: rows evaluated by compacted launches while profiling
+    bool prof_compacted = false;
     double* vbuf = nullptr;        // [P][Np][Wcap] V = L^-1 K*^T (covariance path only)
     int64_t vbuf_cap = 0;
     double* covbuf = nullptr;      // [P][Wc][Wc]
@@ -171,16 +175,24 @@ int launch_lml_grad(gpb_ctx* ctx, double* grad_host);
 // predict side (gpb_predict.hip)
 int ensure_wcap(gpb_ctx* ctx, int64_t W);
 // finalize = false leaves the mean / variance as partials (mpart, spart) for a consumer that sums them itself
-int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var, bool finalize = true);
+// nrows_dev (device int, optional): the batch was compacted, only its first *nrows_dev rows are live
+int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var, bool finalize = true,
+                   const int* nrows_dev = nullptr);
 int launch_predict_cov(gpb_ctx* ctx, const double* Xs_dev, int64_t W, double* cov_dev);
 // likelihood (gpb_like.hip)
 int launch_obs(gpb_ctx* ctx, int64_t W, const double* estd_dev, double* mean_dev, double* cov_dev);
 // true when launch_loglike will take the block log-likelihood kernels that sum the partials themselves
 bool loglike_fuses_finalize(const gpb_ctx* ctx, int64_t W);
+// cmp_dev (optional): the batch was compacted by launch_compact: row w of the workspace is row cmp_dev[4 + w] of ll_dev
 int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, bool from_partials,
                    const double* X_box = nullptr, const double* lo_dev = nullptr, const double* hi_dev = nullptr,
-                   double outside = 0.0, double inside_const = 0.0);
+                   double outside = 0.0, double inside_const = 0.0, const int* cmp_dev = nullptr);
+// ll[row] = outside for the rows outside the open box; the rows inside are gathered into ctx->Xs (in order), their
+// indices and count into ctx->cmp_idx
+int launch_compact(gpb_ctx* ctx, const double* X_dev, int64_t W, const double* lo_dev, const double* hi_dev,
+                   double outside, double* ll_dev);
 int launch_mvn(gpb_ctx* ctx, const double* dY_dev, const double* cov_dev, int64_t W, int64_t M, double* ll_dev);
+bool compaction_applies(const gpb_ctx* ctx);
 // test hooks
 int launch_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K, const double* A, const double* B,
                      double* C, int b_trans);

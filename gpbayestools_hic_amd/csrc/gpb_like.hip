@@ -226,6 +226,9 @@ struct BoxArgs {
     int d;
     double outside;       // -inf or -1e300
     double inside_const;  // 2 log(1e-16)
+    // compacted batch (launch_compact): X == nullptr, the box is already applied; workspace row w is row cmp[4 + w] of
+    // the output, rows w >= cmp[0] do not exist (their numbers are stale workspace contents and are discarded)
+    const int* cmp;
 };
 
 // Optional fused k_finalize: mpart != nullptr -> the kernel sums the per-chunk mean partials and the per-row-block
@@ -333,15 +336,17 @@ __global__ __launch_bounds__(256) void k_loglike_reg(const double* __restrict__ 
         }
         inside = __all(ok);
     }
-    if (lane == 0) {
+    if (lane == 0 && (!box.cmp || w < box.cmp[0])) {
+        const int64_t wo = box.cmp ? box.cmp[4 + w] : w;
         double r = -0.5 * q - logdet;
         if (bad && inside) {
             r = nan("");
             atomicAdd(notpd, 1);
         }
-        r = accumulate ? (ll[w] + r) : r;
+        r = accumulate ? (ll[wo] + r) : r;
         if (box.X) r = inside ? (r + box.inside_const) : box.outside;
-        ll[w] = r;
+        else if (box.cmp) r += box.inside_const;
+        ll[wo] = r;
     }
 }
 
@@ -481,14 +486,18 @@ __global__ __launch_bounds__(256) void k_loglike_wg(const double* __restrict__ m
         double logdet = 0.0;
         for (int g = 0; g < 16; ++g) logdet = fma(0.5, col[g], logdet);      // fixed order (as k_loglike_reg)
         const bool inside = !s_outside;
-        double r = -0.5 * q - logdet;
-        if (bad && inside) {
-            r = nan("");
-            atomicAdd(notpd, 1);
+        if (!box.cmp || w < box.cmp[0]) {
+            const int64_t wo = box.cmp ? box.cmp[4 + w] : w;
+            double r = -0.5 * q - logdet;
+            if (bad && inside) {
+                r = nan("");
+                atomicAdd(notpd, 1);
+            }
+            r = accumulate ? (ll[wo] + r) : r;
+            if (box.X) r = inside ? (r + box.inside_const) : box.outside;
+            else if (box.cmp) r += box.inside_const;
+            ll[wo] = r;
         }
-        r = accumulate ? (ll[w] + r) : r;
-        if (box.X) r = inside ? (r + box.inside_const) : box.outside;
-        ll[w] = r;
     }
 }
 
@@ -537,7 +546,8 @@ __global__ __launch_bounds__(256) void k_loglike_lowrank(const double* __restric
         }
     }
     __syncthreads();
-    if (grp != 0 || w >= W) return;
+    if (grp != 0 || w >= W || (box.cmp && w >= box.cmp[0])) return;
+    const int64_t wo = box.cmp ? box.cmp[4 + w] : w;
     double m[PP], g[PP];
 #pragma unroll
     for (int p = 0; p < PP; ++p) {
@@ -604,9 +614,10 @@ __global__ __launch_bounds__(256) void k_loglike_lowrank(const double* __restric
         r = nan("");
         atomicAdd(notpd, 1);
     }
-    r = accumulate ? (ll[w] + r) : r;
+    r = accumulate ? (ll[wo] + r) : r;
     if (box.X) r = inside ? (r + box.inside_const) : box.outside;
-    ll[w] = r;
+    else if (box.cmp) r += box.inside_const;
+    ll[wo] = r;
 }
 
 static bool lowrank_applies(const gpb_ctx* ctx) {
@@ -649,9 +660,11 @@ bool loglike_fuses_finalize(const gpb_ctx* ctx, int64_t W) {
 }
 
 int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, bool from_partials, const double* X_box,
-                   const double* lo_dev, const double* hi_dev, double outside, double inside_const) {
+                   const double* lo_dev, const double* hi_dev, double outside, double inside_const, const int* cmp_dev) {
     const int64_t M = ctx->M, P = ctx->P;
-    const BoxArgs box{X_box, lo_dev, hi_dev, (int)ctx->d, outside, inside_const};
+    const BoxArgs box{X_box, lo_dev, hi_dev, (int)ctx->d, outside, inside_const, cmp_dev};
+    if (cmp_dev && !(lowrank_applies(ctx) || block_kernels_apply(ctx)))
+        GPB_FAIL(GPB_E_STATE, "gpb: internal: compacted batch without a block likelihood kernel");
     if (from_partials && !loglike_fuses_finalize(ctx, W)) GPB_FAIL(GPB_E_STATE, "gpb: internal: partials without a fused consumer");
     if (lowrank_applies(ctx) || block_kernels_apply(ctx)) {
         PartArgs part{nullptr, nullptr, nullptr, nullptr, 0, 0};
@@ -726,6 +739,71 @@ int launch_mvn(gpb_ctx* ctx, const double* dY_dev, const double* cov_dev, int64_
                            ll_dev, ctx->notpd);
     GPB_HIP(hipGetLastError());
     return 0;
+}
+
+// ------------------------------------------------------------------ compaction to the rows inside the prior box
+// The reference evaluates the emulators for the rows inside the box only (src/mcmc.py:194-203, 275-283) and an
+// all-outside batch costs it nothing (:278-279).  Here: ONE workgroup marks the rows (strict inequalities), writes
+// `outside` for those outside, and gathers the others — in order — into Xc with their indices and count in cmp
+// ([0] = count, [4..] = indices).  The count stays on the device: the kernels that follow are launched for the whole
+// batch and those of their workgroups that find no row leave at once.  From uniform starting positions more than half of
+// a stretch move's proposals (z > 1) leave a 20-dimensional box; a burnt-in ensemble hardly ever does.
+__global__ __launch_bounds__(1024) void k_compact(const double* __restrict__ X, int64_t W, int d, const double* __restrict__ lo,
+                                                  const double* __restrict__ hi, double outside, double* __restrict__ ll,
+                                                  double* __restrict__ Xc, int* __restrict__ cmp,
+                                                  unsigned long long* __restrict__ rows_live) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int64_t w0 = 0; w0 < W; w0 += 1024) {
+        const int64_t w = w0 + tid;
+        bool in = w < W;
+        if (in) {
+            for (int k = 0; k < d; ++k) {
+                const double x = X[w * d + k];
+                in = in && (x > lo[k]) && (x < hi[k]);            // strict (src/mcmc.py:275)
+            }
+            if (!in) ll[w] = outside;
+        }
+        const unsigned long long m = __ballot(in);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int i = 0; i < wave; ++i) off += wsum[i];
+        if (in) {
+            const int slot = off + before;
+            cmp[4 + slot] = (int)w;
+            for (int k = 0; k < d; ++k) Xc[(int64_t)slot * d + k] = X[w * d + k];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int i = 0; i < 16; ++i) tot += wsum[i];
+            base += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        cmp[0] = base;
+        if (rows_live) atomicAdd(rows_live, (unsigned long long)base);
+    }
+}
+
+int launch_compact(gpb_ctx* ctx, const double* X_dev, int64_t W, const double* lo_dev, const double* hi_dev,
+                   double outside, double* ll_dev) {
+    if (W > ctx->Wcap || W >= (1ll << 31)) GPB_FAIL(GPB_E_STATE, "gpb: internal: compaction beyond the workspace");
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, X_dev, W, (int)ctx->d, lo_dev, hi_dev, outside, ll_dev,
+                       ctx->Xs, ctx->cmp_idx, ctx->profile ? ctx->rows_live : nullptr);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+// true when gpb_logpost / gpb_emcee_run may evaluate the rows inside the box only (a block likelihood kernel follows)
+bool compaction_applies(const gpb_ctx* ctx) {
+    return ctx->compact && (lowrank_applies(ctx) || block_kernels_apply(ctx));
 }
 
 // ------------------------------------------------------------------ prior box
@@ -999,10 +1077,18 @@ extern "C" int gpb_emcee_run(gpb_ctx* ctx, double* pos_dev, double* lp_dev, int6
                                hb, rnd);
             // this rank's rows of the batch: K*^T + mean partials, V = L^-1 K*^T with the fused sum of squares, block
             // log-likelihood + prior box + constant (gpb_logpost's sequence)
-            if ((rc = launch_predict(ctx, q + r0 * d, chunk, true, !fused))) return rc;
-            if ((rc = launch_loglike(ctx, chunk, lpq + r0, false, fused, q + r0 * d, lo_dev, hi_dev, outside_value,
-                                     inside_const)))
-                return rc;
+            if (compaction_applies(ctx)) {
+                if ((rc = launch_compact(ctx, q + r0 * d, chunk, lo_dev, hi_dev, outside_value, lpq + r0))) return rc;
+                if ((rc = launch_predict(ctx, ctx->Xs, chunk, true, !fused, ctx->cmp_idx))) return rc;
+                if ((rc = launch_loglike(ctx, chunk, lpq + r0, false, fused, nullptr, nullptr, nullptr, outside_value,
+                                         inside_const, ctx->cmp_idx)))
+                    return rc;
+            } else {
+                if ((rc = launch_predict(ctx, q + r0 * d, chunk, true, !fused))) return rc;
+                if ((rc = launch_loglike(ctx, chunk, lpq + r0, false, fused, q + r0 * d, lo_dev, hi_dev, outside_value,
+                                         inside_const)))
+                    return rc;
+            }
             if (sim ? ctx->comm != nullptr : R > 1)                      // in place, on this stream
                 if ((rc = gpb_dist_allgather(ctx, lpq + r0, lpq, chunk))) return rc;
             hipLaunchKernelGGL(k_accept, g32, dim3(256), 0, ctx->stream, pos_dev, lp_dev, nh, (int)d, half, seed, step, q,

@@ -45,8 +45,14 @@ __global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, i
                                                 double* __restrict__ KsT, double* __restrict__ mpart,
                                                 int64_t N, int64_t Np, int64_t Wld, int P,
                                                 const double* __restrict__ dnorm, const double* __restrict__ muS,
-                                                int chunks_per_wg) {
+                                                int chunks_per_wg, const int* __restrict__ nrows) {
     constexpr int WT = 64 * WPL;                        // walkers per workgroup: lane l holds walkers l, l + 64, ...
+    // compacted batches (gpb_logpost): only the first *nrows rows (those inside the prior box) exist; the launch
+    // geometry was sized for the whole batch and the workgroups beyond them leave at once
+    if (nrows) {
+        W = *nrows;
+        if ((int64_t)blockIdx.x * WT >= W) return;
+    }
     __shared__ double red[4][WT];
     __shared__ double sdn[KX_CHUNK];
     __shared__ __attribute__((aligned(16))) double sbuf[WT * (DPAD + 1)];  // walker tile, then the design rows
@@ -368,8 +374,16 @@ template <int T, int NW, int TN, int KB>
 __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (T == 64 && TN == 64 && NW == 4 ? 6 : 4))) void k_predict(const double* __restrict__ Linv, const double* __restrict__ KsT,
                                                      double* __restrict__ spart, int64_t Np, int64_t Wld, int P,
                                                      int nI, int nW, int xcd_mode, unsigned* __restrict__ queue,
-                                                     unsigned nblocks, unsigned* __restrict__ trace, int tri_skip) {
+                                                     unsigned nblocks, unsigned* __restrict__ trace, int tri_skip,
+                                                     const int* __restrict__ nrows) {
     constexpr int prio_levels = 0;
+    if (nrows) {
+        // compacted batch: only the walker tiles that hold rows exist.  The tile list (and with it the LPT order and
+        // the balance of the eight queues) is rebuilt for them; the grid was sized for the whole batch, the surplus
+        // workgroups find their queues empty.
+        nW = (*nrows + TN - 1) / TN;
+        nblocks = (unsigned)((xcd_mode == 1 ? ((P * nI + 7) / 8) * 8 : P * nI) * nW);
+    }
     __shared__ TileLds<T, TN, KB> lds;
     // The ticket lives in the padding of the last A row (never touched by the loaders, the MFMA fragment reads
     // or the epilogue's scratch): the operand tiles alone are an exact fraction of the CU's 160 KB LDS, and a
@@ -424,8 +438,12 @@ template <int T, int NW, int TN, int KB>
 __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (KB == 32 ? 3 : 4))) void k_predict_static(
     const double* __restrict__ Linv, const double* __restrict__ KsT, double* __restrict__ spart, int64_t Np, int64_t Wld,
     int P, int nI, int nW, int xcd_mode, unsigned nblocks, int order, unsigned ncu_x, int prio_levels,
-    unsigned* __restrict__ trace, int tri_skip) {
+    unsigned* __restrict__ trace, int tri_skip, const int* __restrict__ nrows) {
     __shared__ TileLds<T, TN, KB> lds;
+    if (nrows) {                                       // compacted batch: the tile list of the live walker tiles only
+        nW = (*nrows + TN - 1) / TN;
+        nblocks = (unsigned)((xcd_mode == 1 ? ((P * nI + 7) / 8) * 8 : P * nI) * nW);
+    }
     const unsigned qx = blockIdx.x & 7u;
     const unsigned nq = (nblocks > qx) ? (nblocks - qx + 7u) / 8u : 0u;
     unsigned t = blockIdx.x >> 3;
@@ -483,12 +501,14 @@ int ensure_wcap(gpb_ctx* ctx, int64_t W) {
     GPB_HIP(hipMalloc(&ctx->spart, sizeof(double) * nI64 * P * need));
     GPB_HIP(hipMalloc(&ctx->mean_pc, sizeof(double) * P * need));
     GPB_HIP(hipMalloc(&ctx->var_pc, sizeof(double) * P * need));
+    if (ctx->cmp_idx) { GPB_HIP(hipFree(ctx->cmp_idx)); ctx->cmp_idx = nullptr; }
+    GPB_HIP(hipMalloc(&ctx->cmp_idx, sizeof(int) * (need + 4)));    // [0] = number of rows inside the box, [4..] = their indices
     ctx->Wcap = need;
     return 0;
 }
 
 template <int KIND>
-static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int64_t Wuse) {
+static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int64_t Wuse, const int* nrows_dev) {
     const int nchunk = (int)((ctx->Np + KX_CHUNK - 1) / KX_CHUNK);
     // chunks per workgroup: as many as still leave >= 4 workgroups per CU (a geometry choice: the per-chunk
     // partials and their order do not depend on it; measured, cfg 4: 1 / 2 / 4 chunks at 512 / 1024 / 2048+ walkers)
@@ -507,15 +527,16 @@ static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int
         if (ctx->kcross_dot && wpl == 2)                                                                         \
             hipLaunchKernelGGL((k_kcross<KIND, DP, true, (DP <= 32 ? 2 : 1)>), grid, dim3(256), 0, ctx->stream,  \
                                Xs_dev, W, (int)ctx->d, ctx->Xc, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT,         \
-                               ctx->mpart, ctx->N, ctx->Np, ctx->Wcap, (int)ctx->P, ctx->dnorm, ctx->muS, cpw);  \
+                               ctx->mpart, ctx->N, ctx->Np, ctx->Wcap, (int)ctx->P, ctx->dnorm, ctx->muS, cpw,   \
+                               nrows_dev);                                                                       \
         else if (ctx->kcross_dot)                                                                                \
             hipLaunchKernelGGL((k_kcross<KIND, DP, true, 1>), grid, dim3(256), 0, ctx->stream, Xs_dev, W,        \
                                (int)ctx->d, ctx->Xc, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT, ctx->mpart,        \
-                               ctx->N, ctx->Np, ctx->Wcap, (int)ctx->P, ctx->dnorm, ctx->muS, cpw);              \
+                               ctx->N, ctx->Np, ctx->Wcap, (int)ctx->P, ctx->dnorm, ctx->muS, cpw, nrows_dev);   \
         else                                                                                                     \
             hipLaunchKernelGGL((k_kcross<KIND, DP, false, 1>), grid, dim3(256), 0, ctx->stream, Xs_dev, W,       \
                                (int)ctx->d, ctx->Xsc, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT, ctx->mpart,       \
-                               ctx->N, ctx->Np, ctx->Wcap, (int)ctx->P, ctx->dnorm, ctx->muS, cpw);              \
+                               ctx->N, ctx->Np, ctx->Wcap, (int)ctx->P, ctx->dnorm, ctx->muS, cpw, nrows_dev);   \
     } while (0)
     switch (ctx->dpad) {
         case 8: GPB_KX(8); break;
@@ -531,13 +552,13 @@ static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int
 }
 
 // Xs_dev: [W][d] on the device.  Results land in ctx->mean_pc / var_pc ([P][Wcap]).
-int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var, bool finalize) {
+int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var, bool finalize, const int* nrows_dev) {
     if (!ctx->factored) GPB_FAIL(GPB_E_STATE, "gpb: predict before gpb_gp_factor");
     if (W > ctx->Wcap) GPB_FAIL(GPB_E_STATE, "gpb: internal: W exceeds workspace");
     const int64_t Wuse = round_up(W, WPAD);
-    if (ctx->kind == GPB_KERNEL_RBF) launch_kcross_kind<GPB_KERNEL_RBF>(ctx, Xs_dev, W, Wuse);
-    else if (ctx->kind == GPB_KERNEL_MATERN15) launch_kcross_kind<GPB_KERNEL_MATERN15>(ctx, Xs_dev, W, Wuse);
-    else launch_kcross_kind<GPB_KERNEL_MATERN25>(ctx, Xs_dev, W, Wuse);
+    if (ctx->kind == GPB_KERNEL_RBF) launch_kcross_kind<GPB_KERNEL_RBF>(ctx, Xs_dev, W, Wuse, nrows_dev);
+    else if (ctx->kind == GPB_KERNEL_MATERN15) launch_kcross_kind<GPB_KERNEL_MATERN15>(ctx, Xs_dev, W, Wuse, nrows_dev);
+    else launch_kcross_kind<GPB_KERNEL_MATERN25>(ctx, Xs_dev, W, Wuse, nrows_dev);
     const int nchunk = (int)((ctx->Np + KX_CHUNK - 1) / KX_CHUNK);
     const int nI64 = (int)(ctx->Np / 64);
     if (need_var) {
@@ -590,11 +611,11 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
             hipLaunchKernelGGL((k_predict_static<TT, WW, NN, KK>), dim3(grid), dim3(64 * WW), 0, ctx->stream,     \
                                ctx->Linv, ctx->KsT, ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW, xcd_rows, \
                                (unsigned)nblocks, resident, (unsigned)(ctx->num_cu / 8),                          \
-                               ctx->tile_priority ? nI : 0, ctx->tile_trace, ctx->tri_skip);                      \
+                               ctx->tile_priority ? nI : 0, ctx->tile_trace, ctx->tri_skip, nrows_dev);           \
         else                                                                                                     \
             hipLaunchKernelGGL((k_predict<TT, WW, NN, KK>), dim3(grid), dim3(64 * WW), 0, ctx->stream, ctx->Linv,  \
                                ctx->KsT, ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW, xcd_rows,            \
-                               ctx->tile_counter, (unsigned)nblocks, ctx->tile_trace, ctx->tri_skip);              \
+                               ctx->tile_counter, (unsigned)nblocks, ctx->tile_trace, ctx->tri_skip, nrows_dev);   \
     } while (0)
         // (32-deep K-steps for the 64-row tiles were measured: within 2.5 % either way, not kept)
         if (T == 128)      { if (nwv == 8) GPB_PRED(128, 8, 128, 16); else GPB_PRED(128, 4, 128, 16); }
@@ -606,7 +627,8 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
         if (ctx->profile) {
             GPB_HIP(hipEventRecord(e1, ctx->stream));
             ctx->prof_events.push_back({e0, e1});
-            ctx->prof_units += (double)ctx->P * (double)W;
+            if (!nrows_dev) ctx->prof_units += (double)ctx->P * (double)W;      // compacted: counted on the device
+            else ctx->prof_compacted = true;
         }
     }
     if (finalize)

@@ -209,3 +209,41 @@ def test_long_host_batches_go_through_in_slabs(tmp_path):
     assert np.array_equal(mean[-60:], emu.predict(Xin[-60:], return_cov=False))
     m2, c2 = emu.predict(Xin[:40], return_cov=True, extra_std=0.0)
     assert np.array_equal(m2, mean[:40]) and c2.shape == (40, emu.nobs, emu.nobs)
+
+
+@pytest.mark.parametrize("cfg,W", [(1, 64), (1, 257), (3, 512), (3, 1300)])
+def test_compaction_to_rows_inside_the_box_changes_no_number(tmp_path, cfg, W):
+    """gpb_logpost evaluates only the rows inside the prior box, as the reference does (src/mcmc.py:194-203, 275-283):
+    the same numbers as evaluating every row (bit for bit, whatever the mix: none, some, most or all rows outside),
+    through Chain.log_posterior, log_likelihood(finite=True) and the resident sampler."""
+    from gpbayestools_hic_amd import StretchSampler, synth
+    from gpbayestools_hic_amd.workload import build_chain
+    chain, emu, info = build_chain(cfg, workdir=str(tmp_path))
+    eng = emu._engine_ready()
+    d = info["d"]
+    rng = np.random.default_rng(W)
+    base = synth.walkers(W, d, seed=W)
+    for frac_out in (0.0, 0.3, 0.9, 1.0):
+        X = base.copy()
+        out = rng.random(W) < frac_out
+        if frac_out == 1.0:
+            out[:] = True
+        X[out, rng.integers(0, d, out.sum())] = rng.choice([-0.25, 1.5, 0.0, 1.0], out.sum())   # outside or ON the boundary
+        res = {}
+        for compact in (1, 0):
+            eng.tune("compact", compact)
+            res[compact] = (chain.log_posterior(X), chain.log_likelihood(X, finite=True))
+        eng.tune("compact", 1)
+        assert np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1], res[0][1]), frac_out
+        assert np.array_equal(np.isneginf(res[1][0]), out) and np.all(res[1][1][out] == -1e300)
+    if cfg == 1:
+        nw = 64
+        X0 = synth.walkers(nw, d, seed=3)
+        chains = {}
+        for compact in (1, 0):
+            eng.tune("compact", compact)
+            s = StretchSampler(chain, nw, seed=11)
+            s.run(X0, 6)
+            chains[compact] = (s.chain, s.lnprobability)
+        eng.tune("compact", 1)
+        assert np.array_equal(chains[1][0], chains[0][0]) and np.array_equal(chains[1][1], chains[0][1])
