@@ -74,6 +74,26 @@ def extras(chain4, emu4, info4):
         return e0.elapsed_time(e1) / reps * 1e-3
 
     out = {}
+    # the dominant kernel on FULL batches (every row inside the prior box, as in a burnt-in ensemble): 2048-row
+    # log-posterior calls of the timed configuration.  The timed region itself starts from walkers spread uniformly
+    # over the box, where about half of every half-ensemble's proposals fall outside it and are not evaluated, so its
+    # k_predict launches run on ~950-row batches with a partly filled last tile.
+    eng4 = emu4._engine_ready()
+    Xin = torch.as_tensor(synth.walkers(info4["W"], info4["d"], seed=synth.SEED + 9), device="cuda")
+    lp = torch.empty(info4["W"], dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        chain4.log_prob_device(Xin, lp)
+    torch.cuda.synchronize()
+    eng4.profile(True)
+    for _ in range(10):
+        chain4.log_prob_device(Xin, lp)
+    n_l, ms_l, units_l = eng4.profile_read()
+    eng4.profile(False)
+    tf = units_l / n_l * float(info4["N"]) ** 2 / (ms_l / n_l * 1e-3) / 1e12
+    out["k_predict_full_batch_cfg4"] = {"rows": info4["W"], "launches": n_l, "avg_launch_ms": ms_l / n_l, "achieved": tf,
+                                        "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS, "frac": tf / FP64_MFMA_PEAK_TFLOPS,
+                                        "what": "k_predict on 2048-row batches with every row inside the prior box "
+                                                "(algorithmic flops N^2 per (GP, row))"}
     _, emu2, info2 = build_chain(2)
     eng2 = emu2._engine_ready()
     Xs = torch.as_tensor(synth.walkers(10000, info2["d"]), device="cuda")
@@ -153,6 +173,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Which loop drives the steps: gpb_emcee_run (the C ABI enqueues every kernel and, when sharded, the in-stream
+    # all-gather) or the host-driven loop (Python enqueues; the all-gather through torch.distributed).  A build box has
+    # one GPU, so the sharded form of the C loop runs for the first time on the multi-GPU node: it is checked here
+    # against the host-driven loop on a short run (every rank must reproduce the same ensemble) and dropped on ALL ranks
+    # if any rank disagrees or raises.
+    loop = "gpb_emcee_run" if sampler._resident_engine() is not None else "host-driven"
+    if world > 1 and loop == "gpb_emcee_run":
+        ok = True
+        try:
+            ref = StretchSampler(chain, nwalkers, seed=777, sharding=sharding, device=local)
+            ref._resident_engine = lambda: None
+            a = ref.run(X0, 2, status=10 ** 9, store=False)
+            tst = StretchSampler(chain, nwalkers, seed=777, sharding=sharding, device=local)
+            b = tst.run(X0, 2, status=10 ** 9, store=False)
+            ok = bool(np.array_equal(a, b))
+        except Exception as e:          # noqa: BLE001
+            print(f"rank {rank}: gpb_emcee_run self-check raised {type(e).__name__}: {e}", file=sys.stderr)
+            ok = False
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            sampler._resident_engine = lambda: None
+            loop = "host-driven (gpb_emcee_run failed its self-check against it)"
+
     sampler.run(X0, args.warmup, status=10 ** 9, store=False)
     eng.profile(True)
     barrier()
@@ -187,7 +231,7 @@ def main():
             "config": {"workload": f"BASELINE config {args.config}: {N} design pts x {d} params x {M} observables, "
                                    f"{P} GPs ({info['kernel']}), {nwalkers} walkers, stretch move, "
                                    f"fixed hyper-parameters", "walkers": nwalkers,
-                       "parallelism": f"walker-shard x{world}" if world > 1 else "single GPU",
+                       "parallelism": f"walker-shard x{world}" if world > 1 else "single GPU", "step_loop": loop,
                        "allgather": None if world == 1 else (
                            "gpb_dist_allgather (ncclAllGather on the kernel stream)" if sharding.direct is not None
                            else "torch.distributed " + dist.get_backend()
@@ -197,6 +241,7 @@ def main():
             # timed region's proposal rows (this rank's) that lay inside the box and were evaluated
             "rows_inside_box_fraction": (units / (launches * P * (nwalkers // 2 // world))) if launches else None,
             "gflop_per_step_algorithmic": flops_per_walker(N, d, P, M, info["kernel"]) * nwalkers / 1e9,
+            "gflop_per_step_algorithmic_note": "SURVEY 8(d)'s figure for 4096 evaluated walkers; rows outside the box are not evaluated",
             "roofline": {"bound": "mfma", "kernel": "k_predict (V = L^-1 K*^T, fused sum of squares)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / FP64_MFMA_PEAK_TFLOPS) if achieved else None, "traffic": None,
