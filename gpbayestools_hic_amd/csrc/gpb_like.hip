@@ -534,13 +534,25 @@ __global__ __launch_bounds__(256) void k_loglike_lowrank(const double* __restric
     for (int e = threadIdx.x; e < PP * PP; e += 256) sR[e / PP][e % PP] = Rg[(e / PP) * 16 + (e % PP)];
     if (threadIdx.x < PP) sv0[threadIdx.x] = v0g[threadIdx.x];
     const int64_t w = (int64_t)blockIdx.x * 64 + lane;
-    if (part.mpart && w < W) {
+    if (part.mpart && w < W && (!box.cmp || w < box.cmp[0])) {
+        // k_finalize's sums, in its order (same bits) — but 16 partials of the mean AND 16 of the variance in flight per
+        // round trip to L2 (with 8 of one kind a 64-walker workgroup spent most of its 20 us waiting for 24 of them)
         for (int p = grp; p < P; p += 4) {
             double a = 0.0, sq = 0.0;
-#pragma unroll 8
-            for (int c = 0; c < part.nchunk; ++c) a += part.mpart[((int64_t)c * P + p) * Wld + w];
-#pragma unroll 8
-            for (int i = 0; i < part.nI64; ++i) sq += part.spart[((int64_t)i * P + p) * Wld + w];
+            const double* mp = part.mpart + (int64_t)p * Wld + w;
+            const double* sp = part.spart + (int64_t)p * Wld + w;
+            const int64_t st = (int64_t)P * Wld;
+            const int nboth = part.nchunk < part.nI64 ? part.nchunk : part.nI64;
+            int c = 0;
+            for (; c + 16 <= nboth; c += 16) {
+                double mv[16], sv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { mv[u] = mp[(c + u) * st]; sv[u] = sp[(c + u) * st]; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { a += mv[u]; sq += sv[u]; }
+            }
+            for (int u = c; u < part.nchunk; ++u) a += mp[u * st];
+            for (int u = c; u < part.nI64; ++u) sq += sp[u * st];
             smg[0][p][lane] = a;
             smg[1][p][lane] = (part.amp[p] + part.noise[p]) - sq;
         }
@@ -748,55 +760,80 @@ int launch_mvn(gpb_ctx* ctx, const double* dY_dev, const double* cov_dev, int64_
 // ([0] = count, [4..] = indices).  The count stays on the device: the kernels that follow are launched for the whole
 // batch and those of their workgroups that find no row leave at once.  From uniform starting positions more than half of
 // a stretch move's proposals (z > 1) leave a 20-dimensional box; a burnt-in ensemble hardly ever does.
-__global__ __launch_bounds__(1024) void k_compact(const double* __restrict__ X, int64_t W, int d, const double* __restrict__ lo,
-                                                  const double* __restrict__ hi, double outside, double* __restrict__ ll,
-                                                  double* __restrict__ Xc, int* __restrict__ cmp,
-                                                  unsigned long long* __restrict__ rows_live) {
-    __shared__ int wsum[16];
-    __shared__ int base;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) base = 0;
+// Pass 1: 256 rows per workgroup, staged through LDS with coalesced loads (a lane reading its own row touches 64
+// different cache lines per instruction).  rank[w] = position of row w among the live rows of its workgroup (-1: outside),
+// blockcnt[b] = live rows of workgroup b.
+__global__ __launch_bounds__(256) void k_compact_mark(const double* __restrict__ X, int64_t W, int d,
+                                                      const double* __restrict__ lo, const double* __restrict__ hi,
+                                                      double outside, double* __restrict__ ll, int* __restrict__ rank,
+                                                      int* __restrict__ blockcnt) {
+    extern __shared__ double srow[];                   // [256][d + 1]
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ldr = d + 1;
+    const int64_t w0 = (int64_t)blockIdx.x * 256, nrow = imin64(256, W - w0);
+    for (int64_t e = tid; e < nrow * d; e += 256) srow[(e / d) * ldr + (e % d)] = X[w0 * d + e];
     __syncthreads();
-    for (int64_t w0 = 0; w0 < W; w0 += 1024) {
-        const int64_t w = w0 + tid;
-        bool in = w < W;
-        if (in) {
-            for (int k = 0; k < d; ++k) {
-                const double x = X[w * d + k];
-                in = in && (x > lo[k]) && (x < hi[k]);            // strict (src/mcmc.py:275)
-            }
-            if (!in) ll[w] = outside;
+    const bool have = tid < nrow;
+    int ok = have ? 1 : 0;
+    if (have)
+        for (int k = 0; k < d; ++k) {
+            const double x = srow[tid * ldr + k];
+            ok &= (int)(x > lo[k]) & (int)(x < hi[k]);          // strict (src/mcmc.py:275); no short circuit
         }
-        const unsigned long long m = __ballot(in);
-        const int before = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wave] = __popcll(m);
-        __syncthreads();
-        int off = base;
-        for (int i = 0; i < wave; ++i) off += wsum[i];
-        if (in) {
-            const int slot = off + before;
-            cmp[4 + slot] = (int)w;
-            for (int k = 0; k < d; ++k) Xc[(int64_t)slot * d + k] = X[w * d + k];
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
-            for (int i = 0; i < 16; ++i) tot += wsum[i];
-            base += tot;
-        }
-        __syncthreads();
+    const bool in = ok != 0;
+    if (have && !in) ll[w0 + tid] = outside;
+    const unsigned long long m = __ballot(in);
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0;
+    for (int i = 0; i < wave; ++i) off += wsum[i];
+    if (have) rank[w0 + tid] = in ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+    if (tid == 0) blockcnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// Pass 2: the live rows of workgroup b go to slots base_b + rank, base_b = live rows of the workgroups before it (the
+// order of the rows is kept); cmp[0] = total, cmp[4 + slot] = row.
+__global__ __launch_bounds__(256) void k_compact_gather(const double* __restrict__ X, int64_t W, int d,
+                                                        const int* __restrict__ rank, const int* __restrict__ blockcnt,
+                                                        double* __restrict__ Xc, int* __restrict__ cmp,
+                                                        unsigned long long* __restrict__ rows_live) {
+    __shared__ int s_base;
+    __shared__ int row_of[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t w0 = (int64_t)blockIdx.x * 256, nrow = imin64(256, W - w0);
+    if (tid < 64) {                                    // fixed-order sum of the counts before this workgroup
+        int s = 0;
+        for (int b = lane; b < (int)blockIdx.x; b += 64) s += blockcnt[b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) s_base = s;
     }
-    if (tid == 0) {
-        cmp[0] = base;
-        if (rows_live) atomicAdd(rows_live, (unsigned long long)base);
+    const int r = tid < nrow ? rank[w0 + tid] : -1;
+    if (r >= 0) row_of[r] = tid;
+    __syncthreads();
+    const int base = s_base, cnt = blockcnt[blockIdx.x];
+    if (r >= 0) cmp[4 + base + r] = (int)(w0 + tid);
+    for (int64_t e = tid; e < (int64_t)cnt * d; e += 256) {
+        const int s = (int)(e / d), k = (int)(e % d);
+        Xc[((int64_t)base + s) * d + k] = X[(w0 + row_of[s]) * d + k];
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        cmp[0] = base + cnt;
+        if (rows_live) atomicAdd(rows_live, (unsigned long long)(base + cnt));
     }
 }
 
 int launch_compact(gpb_ctx* ctx, const double* X_dev, int64_t W, const double* lo_dev, const double* hi_dev,
                    double outside, double* ll_dev) {
     if (W > ctx->Wcap || W >= (1ll << 31)) GPB_FAIL(GPB_E_STATE, "gpb: internal: compaction beyond the workspace");
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, X_dev, W, (int)ctx->d, lo_dev, hi_dev, outside, ll_dev,
-                       ctx->Xs, ctx->cmp_idx, ctx->profile ? ctx->rows_live : nullptr);
+    const unsigned nb = (unsigned)((W + 255) / 256);
+    int* rank = ctx->cmp_idx + 4 + ctx->Wcap;          // [Wcap] ranks, then [Wcap / 256 + 1] workgroup counts
+    int* blockcnt = rank + ctx->Wcap;
+    const size_t sh = sizeof(double) * 256 * (size_t)(ctx->d + 1);
+    hipLaunchKernelGGL(k_compact_mark, dim3(nb), dim3(256), sh, ctx->stream, X_dev, W, (int)ctx->d, lo_dev, hi_dev, outside,
+                       ll_dev, rank, blockcnt);
+    hipLaunchKernelGGL(k_compact_gather, dim3(nb), dim3(256), 0, ctx->stream, X_dev, W, (int)ctx->d, rank, blockcnt, ctx->Xs,
+                       ctx->cmp_idx, ctx->profile ? ctx->rows_live : nullptr);
     GPB_HIP(hipGetLastError());
     return 0;
 }

@@ -502,7 +502,8 @@ int ensure_wcap(gpb_ctx* ctx, int64_t W) {
     GPB_HIP(hipMalloc(&ctx->mean_pc, sizeof(double) * P * need));
     GPB_HIP(hipMalloc(&ctx->var_pc, sizeof(double) * P * need));
     if (ctx->cmp_idx) { GPB_HIP(hipFree(ctx->cmp_idx)); ctx->cmp_idx = nullptr; }
-    GPB_HIP(hipMalloc(&ctx->cmp_idx, sizeof(int) * (need + 4)));    // [0] = number of rows inside the box, [4..] = their indices
+    // [0] = number of rows inside the box, [4..] = their indices; then the compaction's scratch: ranks, workgroup counts
+    GPB_HIP(hipMalloc(&ctx->cmp_idx, sizeof(int) * (size_t)(4 + 2 * need + need / 256 + 8)));
     ctx->Wcap = need;
     return 0;
 }
@@ -517,7 +518,10 @@ static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int
     const int wpl = (ctx->kcross_dot && ctx->kcross_wpl == 2 && ctx->dpad <= 32 && Wuse >= 256 && Wuse % 128 == 0) ? 2 : 1;
     int cpw = ctx->kcross_chunks;
     if (cpw <= 0) {
-        const int64_t wgs1 = (Wuse / (64 * wpl)) * nchunk * ctx->P;
+        // compacted batches: about half of a stretch move's proposals from a spread-out ensemble are live (the count is
+        // known on the device only); sizing the chunks per workgroup for the whole batch left 2.5 workgroups per CU
+        const int64_t Wgeo = nrows_dev ? round_up(Wuse / 2, 64 * wpl) : Wuse;
+        const int64_t wgs1 = (Wgeo / (64 * wpl)) * nchunk * ctx->P;
         cpw = 1;
         while (cpw < 8 && wgs1 / (2 * cpw) >= 4 * (int64_t)ctx->num_cu) cpw *= 2;
     }
