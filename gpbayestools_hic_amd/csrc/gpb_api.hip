@@ -348,16 +348,16 @@ extern "C" int gpb_gp_predict(gpb_ctx* ctx, const double* Xs, int64_t W, int on_
     const int64_t P = ctx->P;
     dim3 grid((unsigned)((W + 255) / 256));
     if (on_device) {
-        hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->mean_pc, mean, W, ctx->Wcap, (int)P);
-        if (var) hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->var_pc, var, W, ctx->Wcap, (int)P);
+        hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->mean_pc, mean, W, ctx->Wld, (int)P);
+        if (var) hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->var_pc, var, W, ctx->Wld, (int)P);
         GPB_HIP(hipGetLastError());
         return 0;
     }
     if ((rc = ensure_out(ctx, 2 * W * P))) return rc;
-    hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->mean_pc, ctx->out_stage, W, ctx->Wcap, (int)P);
+    hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->mean_pc, ctx->out_stage, W, ctx->Wld, (int)P);
     GPB_HIP(hipMemcpyAsync(mean, ctx->out_stage, sizeof(double) * W * P, hipMemcpyDeviceToHost, ctx->stream));
     if (var) {
-        hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->var_pc, ctx->out_stage + W * P, W, ctx->Wcap, (int)P);
+        hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->var_pc, ctx->out_stage + W * P, W, ctx->Wld, (int)P);
         GPB_HIP(hipMemcpyAsync(var, ctx->out_stage + W * P, sizeof(double) * W * P, hipMemcpyDeviceToHost, ctx->stream));
     }
     GPB_HIP(hipStreamSynchronize(ctx->stream));
@@ -377,7 +377,7 @@ extern "C" int gpb_gp_predict_cov(gpb_ctx* ctx, const double* Xs, int64_t W, int
     dim3 grid((unsigned)((W + 255) / 256));
     if (on_device) {
         if ((rc = launch_predict_cov(ctx, Xs_dev, W, cov))) return rc;
-        hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->mean_pc, mean, W, ctx->Wcap, (int)P);
+        hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->mean_pc, mean, W, ctx->Wld, (int)P);
         GPB_HIP(hipGetLastError());
         return 0;
     }
@@ -385,7 +385,7 @@ extern "C" int gpb_gp_predict_cov(gpb_ctx* ctx, const double* Xs, int64_t W, int
     double* dm = ctx->out_stage;
     double* dc = dm + W * P;
     if ((rc = launch_predict_cov(ctx, Xs_dev, W, dc))) return rc;
-    hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->mean_pc, dm, W, ctx->Wcap, (int)P);
+    hipLaunchKernelGGL(k_transpose_pw, grid, dim3(256), 0, ctx->stream, ctx->mean_pc, dm, W, ctx->Wld, (int)P);
     GPB_HIP(hipMemcpyAsync(mean, dm, sizeof(double) * W * P, hipMemcpyDeviceToHost, ctx->stream));
     GPB_HIP(hipMemcpyAsync(cov, dc, sizeof(double) * P * W * W, hipMemcpyDeviceToHost, ctx->stream));
     GPB_HIP(hipStreamSynchronize(ctx->stream));

@@ -85,7 +85,7 @@ __global__ void k_cov_pack(const double* __restrict__ src, double* __restrict__ 
 
 int launch_predict_cov(gpb_ctx* ctx, const double* Xs_dev, int64_t W, double* cov_dev /*[P][W][W]*/) {
     // Wld: leading dimension of K*^T / V (workspace capacity); Wc: padded extent of this batch (cov's own ld)
-    const int64_t P = ctx->P, Np = ctx->Np, Wld = ctx->Wcap, Wc = round_up(W, WPAD);
+    const int64_t P = ctx->P, Np = ctx->Np, Wc = round_up(W, WPAD), Wld = Wc;   // launch_predict lays the batch out with ld = Wc
     const int64_t need_v = P * Np * Wld, need_c = P * Wc * Wc;
     if (need_v > ctx->vbuf_cap) {
         GPB_HIP(hipStreamSynchronize(ctx->stream));

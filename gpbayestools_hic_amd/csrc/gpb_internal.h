@@ -55,6 +55,7 @@ struct gpb_ctx {
 
     // ---- predict workspace ------------------------------------------------------
     int64_t Wcap = 0;              // padded capacity (multiple of WPAD)
+    int64_t Wld = 0;               // leading dimension of the current batch's workspaces (set by launch_predict: the padded batch)
     double* Xs = nullptr;          // [Wcap][d] staged inputs (when caller passes host memory)
     double* estd = nullptr;        // [Wcap]
     double* KsT = nullptr;         // [P][Np][Wcap]

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_obs(const double* __restrict__ mean_pc,
 int launch_obs(gpb_ctx* ctx, int64_t W, const double* estd_dev, double* mean_dev, double* cov_dev) {
     const size_t sh = (2 * ctx->P + ctx->M) * sizeof(double);
     hipLaunchKernelGGL(k_obs, dim3((unsigned)W), dim3(256), sh, ctx->stream, ctx->mean_pc,
-                       cov_dev ? ctx->var_pc : nullptr, estd_dev, ctx->Wcap, (int)ctx->P, (int)ctx->M, ctx->mode,
+                       cov_dev ? ctx->var_pc : nullptr, estd_dev, ctx->Wld, (int)ctx->P, (int)ctx->M, ctx->mode,
                        ctx->A, ctx->mu, ctx->scale, ctx->C0, mean_dev, cov_dev);
     GPB_HIP(hipGetLastError());
     return 0;
@@ -355,7 +355,7 @@ static int launch_loglike_reg(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accu
                               const PartArgs& part) {
     const size_t sh = (64 * (MP + 1) + (size_t)ctx->P * 64) * sizeof(double);
     hipLaunchKernelGGL(k_loglike_reg<MP>, dim3((unsigned)((W + 3) / 4)), dim3(256), sh, ctx->stream, ctx->mean_pc,
-                       ctx->var_pc, ctx->Wcap, W, (int)ctx->P, (int)ctx->M, ctx->A, ctx->mu, ctx->C0, ctx->yexp,
+                       ctx->var_pc, ctx->Wld, W, (int)ctx->P, (int)ctx->M, ctx->A, ctx->mu, ctx->C0, ctx->yexp,
                        ctx->Cexp, ll_dev, accumulate ? 1 : 0, ctx->notpd, box, part);
     GPB_HIP(hipGetLastError());
     return 0;
@@ -505,7 +505,7 @@ static int launch_loglike_wg(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accum
                              const PartArgs& part) {
     const size_t sh = ((size_t)ctx->P * 64 + 2 * 66 + 2 * (size_t)ctx->P) * sizeof(double);
     hipLaunchKernelGGL(k_loglike_wg, dim3((unsigned)W), dim3(256), sh, ctx->stream, ctx->mean_pc, ctx->var_pc,
-                       ctx->Wcap, W, (int)ctx->P, (int)ctx->M, ctx->A, ctx->mu, ctx->C0, ctx->yexp, ctx->Cexp, ll_dev,
+                       ctx->Wld, W, (int)ctx->P, (int)ctx->M, ctx->A, ctx->mu, ctx->C0, ctx->yexp, ctx->Cexp, ll_dev,
                        accumulate ? 1 : 0, ctx->notpd, box, part);
     GPB_HIP(hipGetLastError());
     return 0;
@@ -640,7 +640,7 @@ static int launch_loglike_lowrank(gpb_ctx* ctx, int64_t W, double* ll_dev, bool 
                                   const PartArgs& part) {
     const dim3 grid((unsigned)((W + 63) / 64));
 #define GPB_LR(PPV)                                                                                              \
-    hipLaunchKernelGGL(k_loglike_lowrank<PPV>, grid, dim3(256), 0, ctx->stream, ctx->mean_pc, ctx->var_pc, ctx->Wcap, \
+    hipLaunchKernelGGL(k_loglike_lowrank<PPV>, grid, dim3(256), 0, ctx->stream, ctx->mean_pc, ctx->var_pc, ctx->Wld, \
                        W, (int)ctx->P, ctx->lr_R, ctx->lr_v0, ctx->lr_cperp, ctx->lr_logdet0, ll_dev,              \
                        accumulate ? 1 : 0, ctx->notpd, box, part)
     switch (ctx->P) {                        // exact sizes: the work per walker grows with PP^3
@@ -711,11 +711,11 @@ int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, boo
     }
     if (gws)
         hipLaunchKernelGGL(k_loglike<true>, dim3((unsigned)W), dim3(256), sh, ctx->stream, ctx->mean_pc, ctx->var_pc,
-                           ctx->Wcap, (int)P, (int)M, ctx->mode, ctx->A, ctx->mu, ctx->scale, ctx->C0, ctx->yexp,
+                           ctx->Wld, (int)P, (int)M, ctx->mode, ctx->A, ctx->mu, ctx->scale, ctx->C0, ctx->yexp,
                            ctx->Cexp, gws, ll_dev, accumulate ? 1 : 0, ctx->notpd);
     else
         hipLaunchKernelGGL(k_loglike<false>, dim3((unsigned)W), dim3(256), sh, ctx->stream, ctx->mean_pc, ctx->var_pc,
-                           ctx->Wcap, (int)P, (int)M, ctx->mode, ctx->A, ctx->mu, ctx->scale, ctx->C0, ctx->yexp,
+                           ctx->Wld, (int)P, (int)M, ctx->mode, ctx->A, ctx->mu, ctx->scale, ctx->C0, ctx->yexp,
                            ctx->Cexp, gws, ll_dev, accumulate ? 1 : 0, ctx->notpd);
     if (X_box)
         hipLaunchKernelGGL(k_box, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, ctx->stream, X_box, W, (int)ctx->d,

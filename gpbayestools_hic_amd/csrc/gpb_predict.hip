@@ -531,16 +531,16 @@ static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int
         if (ctx->kcross_dot && wpl == 2)                                                                         \
             hipLaunchKernelGGL((k_kcross<KIND, DP, true, (DP <= 32 ? 2 : 1)>), grid, dim3(256), 0, ctx->stream,  \
                                Xs_dev, W, (int)ctx->d, ctx->Xc, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT,         \
-                               ctx->mpart, ctx->N, ctx->Np, ctx->Wcap, (int)ctx->P, ctx->dnorm, ctx->muS, cpw,   \
+                               ctx->mpart, ctx->N, ctx->Np, ctx->Wld, (int)ctx->P, ctx->dnorm, ctx->muS, cpw,   \
                                nrows_dev);                                                                       \
         else if (ctx->kcross_dot)                                                                                \
             hipLaunchKernelGGL((k_kcross<KIND, DP, true, 1>), grid, dim3(256), 0, ctx->stream, Xs_dev, W,        \
                                (int)ctx->d, ctx->Xc, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT, ctx->mpart,        \
-                               ctx->N, ctx->Np, ctx->Wcap, (int)ctx->P, ctx->dnorm, ctx->muS, cpw, nrows_dev);   \
+                               ctx->N, ctx->Np, ctx->Wld, (int)ctx->P, ctx->dnorm, ctx->muS, cpw, nrows_dev);   \
         else                                                                                                     \
             hipLaunchKernelGGL((k_kcross<KIND, DP, false, 1>), grid, dim3(256), 0, ctx->stream, Xs_dev, W,       \
                                (int)ctx->d, ctx->Xsc, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT, ctx->mpart,       \
-                               ctx->N, ctx->Np, ctx->Wcap, (int)ctx->P, ctx->dnorm, ctx->muS, cpw, nrows_dev);   \
+                               ctx->N, ctx->Np, ctx->Wld, (int)ctx->P, ctx->dnorm, ctx->muS, cpw, nrows_dev);   \
     } while (0)
     switch (ctx->dpad) {
         case 8: GPB_KX(8); break;
@@ -560,6 +560,10 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
     if (!ctx->factored) GPB_FAIL(GPB_E_STATE, "gpb: predict before gpb_gp_factor");
     if (W > ctx->Wcap) GPB_FAIL(GPB_E_STATE, "gpb: internal: W exceeds workspace");
     const int64_t Wuse = round_up(W, WPAD);
+    // leading dimension of this batch's workspaces (K*^T, partials, per-GP means / variances): the padded batch, not the
+    // capacity — with the capacity left at 4096 by an earlier call a 256-walker batch read its 64-walker tile rows
+    // 32 KB apart and k_predict_static ran 13 % slower (117 -> 133 us), k_kcross 24 % (20 -> 25 us)
+    ctx->Wld = Wuse;
     if (ctx->kind == GPB_KERNEL_RBF) launch_kcross_kind<GPB_KERNEL_RBF>(ctx, Xs_dev, W, Wuse, nrows_dev);
     else if (ctx->kind == GPB_KERNEL_MATERN15) launch_kcross_kind<GPB_KERNEL_MATERN15>(ctx, Xs_dev, W, Wuse, nrows_dev);
     else launch_kcross_kind<GPB_KERNEL_MATERN25>(ctx, Xs_dev, W, Wuse, nrows_dev);
@@ -613,12 +617,12 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
     do {                                                                                                         \
         if (resident)                                                                                            \
             hipLaunchKernelGGL((k_predict_static<TT, WW, NN, KK>), dim3(grid), dim3(64 * WW), 0, ctx->stream,     \
-                               ctx->Linv, ctx->KsT, ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW, xcd_rows, \
+                               ctx->Linv, ctx->KsT, ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xcd_rows, \
                                (unsigned)nblocks, resident, (unsigned)(ctx->num_cu / 8),                          \
                                ctx->tile_priority ? nI : 0, ctx->tile_trace, ctx->tri_skip, nrows_dev);           \
         else                                                                                                     \
             hipLaunchKernelGGL((k_predict<TT, WW, NN, KK>), dim3(grid), dim3(64 * WW), 0, ctx->stream, ctx->Linv,  \
-                               ctx->KsT, ctx->spart, ctx->Np, ctx->Wcap, (int)ctx->P, nI, nW, xcd_rows,            \
+                               ctx->KsT, ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xcd_rows,            \
                                ctx->tile_counter, (unsigned)nblocks, ctx->tile_trace, ctx->tri_skip, nrows_dev);   \
     } while (0)
         // (32-deep K-steps for the 64-row tiles were measured: within 2.5 % either way, not kept)
@@ -638,7 +642,7 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
     if (finalize)
         hipLaunchKernelGGL(k_finalize, dim3((unsigned)((Wuse + 255) / 256), (unsigned)ctx->P), dim3(256), 0,
                            ctx->stream, ctx->mpart, ctx->spart, ctx->amp, ctx->noise, ctx->mean_pc, ctx->var_pc,
-                           ctx->Wcap, Wuse, (int)ctx->P, nchunk, nI64, need_var ? 1 : 0);
+                           ctx->Wld, Wuse, (int)ctx->P, nchunk, nI64, need_var ? 1 : 0);
     GPB_HIP(hipGetLastError());
     return 0;
 }
