@@ -130,7 +130,11 @@ __device__ __forceinline__ void potf2_inv_64(CholLds& s, unsigned long long* sta
             double myrinv = 0.0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const double ajj = bc16v(rd[j], j);
+                // rd[j] may have been written by the inline-asm fma just before (pivot 15: one instruction earlier):
+                // the same two wait states before a DPP read, which the compiler cannot know it owes
+                double piv = rd[j];
+                hazard_dpp_src(piv);
+                const double ajj = bc16v(piv, j);
                 if (!(ajj > 0.0) && badj < 0) badj = j;
                 const double rinv = rsqrt_nr(ajj);                 // 1 / L_jj
                 const double ld = rd[j] * rinv, lp = rp[j] * rinv; // column j of L: factor rows, panel rows

@@ -94,3 +94,46 @@ def test_fullsize_log_posterior_cfg4_against_oracle_sample():
     ins = np.isfinite(ref)
     assert np.array_equal(np.isneginf(got), ~ins) and ins.sum() == 46
     assert np.max(np.abs(got[ins] - ref[ins]) / np.abs(ref[ins])) < 1e-10
+
+
+@pytest.mark.parametrize("N", [1024, 2048])
+def test_cholesky_schedules_agree(N):
+    """the blocked Cholesky's schedules — two launches per step with the next diagonal block fused into the update
+    (default), with and without the lookahead side stream, and round 1's three-launch form — give the same factor bit
+    for bit at equal outer panel width (the side stream only touches tiles nobody else touches at that time; the pivot
+    arithmetic is round 1's), run to run; another panel width groups the trailing updates differently and agrees to
+    rounding; and the factor is correct"""
+    from gpbayestools_hic_amd import GPEngine
+    from oracle import gp_oracle as O
+    P, d = 3, 12
+    eng = GPEngine(0)
+    X, Z, th = _setup(eng, N, d, P, "RBF", seed=3 * N)
+    ref_L, ref_X = eng.get("L"), eng.get("Linv")
+    for algo, outer, look in ((1, 512, 1), (1, 512, 0), (0, 512, 0), (1, 512, 1), (1, 256, 1), (1, 256, 0), (1, 128, 1)):
+        eng.tune("chol_algo", algo); eng.tune("chol_outer", outer); eng.tune("chol_lookahead", look)
+        eng.factor()
+        L, Xi = eng.get("L"), eng.get("Linv")
+        if outer == 512:
+            assert np.array_equal(L, ref_L) and np.array_equal(Xi, ref_X), (algo, outer, look)
+        else:
+            assert np.max(np.abs(L - ref_L)) < 1e-12 * np.max(np.abs(ref_L)), (algo, outer, look)
+            assert np.max(np.abs(Xi - ref_X)) < 1e-11 * np.max(np.abs(ref_X)), (algo, outer, look)
+        if outer == 256 and look == 1:
+            L256 = L
+        if outer == 256 and look == 0:
+            assert np.array_equal(L, L256)
+    eng.tune("chol_algo", 1); eng.tune("chol_outer", 512); eng.tune("chol_lookahead", 1)
+    K = O.kernel_train(X, th[0], O.KIND_RBF, 0.1)
+    Lo = np.linalg.cholesky(K)
+    assert np.max(np.abs(ref_L[0] - Lo)) < 1e-11 * np.max(np.abs(Lo))
+    v = np.random.default_rng(0).standard_normal((N, 3))
+    assert np.max(np.abs(ref_X[0] @ (ref_L[0] @ v) - v)) < 1e-10
+    # an indefinite matrix is reported with LAPACK's info (first non-positive pivot), whatever block it falls in
+    eng.set_data(X, Z, "RBF", alpha=-1.5)
+    eng.set_theta(th)
+    info = eng.factor(raise_on_fail=False)
+    Kbad = O.kernel_train(X, th[0], O.KIND_RBF, -1.5)
+    from scipy.linalg import lapack
+    _, ref_info = lapack.dpotrf(Kbad, lower=1)
+    assert ref_info > 0 and info[0] == ref_info
+    eng.close()
