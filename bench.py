@@ -178,8 +178,8 @@ def main():
     # one GPU, so the sharded form of the C loop runs for the first time on the multi-GPU node: it is checked here
     # against the host-driven loop on a short run (every rank must reproduce the same ensemble) and dropped on ALL ranks
     # if any rank disagrees or raises.
-    loop = "gpb_emcee_run" if sampler._resident_engine() is not None else "host-driven"
-    if world > 1 and loop == "gpb_emcee_run":
+    loop = "gpb_chain_emcee_run" if sampler._resident_engine() is not None else "host-driven"
+    if world > 1 and loop == "gpb_chain_emcee_run":
         ok = True
         try:
             ref = StretchSampler(chain, nwalkers, seed=777, sharding=sharding, device=local)
@@ -189,13 +189,13 @@ def main():
             b = tst.run(X0, 2, status=10 ** 9, store=False)
             ok = bool(np.array_equal(a, b))
         except Exception as e:          # noqa: BLE001
-            print(f"rank {rank}: gpb_emcee_run self-check raised {type(e).__name__}: {e}", file=sys.stderr)
+            print(f"rank {rank}: gpb_chain_emcee_run self-check raised {type(e).__name__}: {e}", file=sys.stderr)
             ok = False
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) != 1:
             sampler._resident_engine = lambda: None
-            loop = "host-driven (gpb_emcee_run failed its self-check against it)"
+            loop = "host-driven (gpb_chain_emcee_run failed its self-check against it)"
 
     sampler.run(X0, args.warmup, status=10 ** 9, store=False)
     eng.profile(True)

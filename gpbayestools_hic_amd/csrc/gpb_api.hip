@@ -132,7 +132,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     dev_free(&ctx->tile_trace);
     dev_free(&ctx->A); dev_free(&ctx->mu); dev_free(&ctx->scale); dev_free(&ctx->C0); dev_free(&ctx->yexp);
     dev_free(&ctx->Cexp); dev_free(&ctx->mvn_ws); dev_free(&ctx->notpd); dev_free(&ctx->tile_counter);
-    dev_free(&ctx->n_nan); dev_free(&ctx->mc_ws); dev_free(&ctx->rows_live); dev_free(&ctx->cmp_idx);
+    dev_free(&ctx->n_nan); dev_free(&ctx->mc_ws); dev_free(&ctx->rows_live); dev_free(&ctx->cmp_idx); dev_free(&ctx->cmp_X);
     for (hipEvent_t e : ctx->chol_events) (void)hipEventDestroy(e);
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -182,8 +182,8 @@ extern "C" int gpb_gp_set(gpb_ctx* ctx, int64_t N, int64_t d, int64_t P, const d
     const int64_t Np = ctx->Np;
     // workspaces sized by (Np, P) are stale now
     dev_free(&ctx->KsT); dev_free(&ctx->mpart); dev_free(&ctx->spart); dev_free(&ctx->mean_pc);
-    dev_free(&ctx->var_pc); dev_free(&ctx->Xs); dev_free(&ctx->estd); dev_free(&ctx->cmp_idx);
-    ctx->Wcap = 0;
+    dev_free(&ctx->var_pc); dev_free(&ctx->Xs); dev_free(&ctx->estd); dev_free(&ctx->cmp_idx); dev_free(&ctx->cmp_X);
+    ctx->Wcap = 0; ctx->cmp_X_cap = 0;
     int rc;
     if ((rc = dev_alloc(ctx, &ctx->X, Np * dpad))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->Xsc, P * Np * dpad))) return rc;
@@ -593,8 +593,8 @@ extern "C" int gpb_logpost(gpb_ctx* ctx, const double* Xs_dev, int64_t W, double
     const bool fused = loglike_fuses_finalize(ctx, W);
     if (!accumulate && compaction_applies(ctx)) {
         // the rows inside the prior box only, as the reference does (src/mcmc.py:194-203, 275-283); no host round trip
-        if ((rc = launch_compact(ctx, Xs_dev, W, lo_dev, hi_dev, outside_value, ll_dev))) return rc;
-        if ((rc = launch_predict(ctx, ctx->Xs, W, true, !fused, ctx->cmp_idx))) return rc;
+        if ((rc = launch_compact(ctx, Xs_dev, W, ctx->d, lo_dev, hi_dev, outside_value, ll_dev))) return rc;
+        if ((rc = launch_predict(ctx, ctx->cmp_X, W, true, !fused, ctx->cmp_idx))) return rc;
         return launch_loglike(ctx, W, ll_dev, false, fused, nullptr, nullptr, nullptr, outside_value, inside_const,
                               ctx->cmp_idx);
     }

@@ -63,6 +63,8 @@ struct gpb_ctx {
     double* spart = nullptr;       // [Np/64][P][Wcap]  sum-of-squares partials per 64-row block
     double* mean_pc = nullptr;     // [P][Wcap]
     double* var_pc = nullptr;      // [P][Wcap]
+    double* cmp_X = nullptr;       // the rows of the current batch inside the prior box, gathered in order [Wcap][chain ndim]
+    int64_t cmp_X_cap = 0;
     int* cmp_idx = nullptr;        // compaction of a log-posterior batch to the rows inside the prior box: [0] = count, [4..] = row indices
     int compact = 1;               // gpb_logpost / gpb_emcee_run evaluate the rows inside the box only (the reference: src/mcmc.py:278-283)
     unsigned long long* rows_live = nullptr;   // device counter: rows evaluated by compacted launches while profiling
@@ -188,9 +190,9 @@ bool loglike_fuses_finalize(const gpb_ctx* ctx, int64_t W);
 int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, bool from_partials,
                    const double* X_box = nullptr, const double* lo_dev = nullptr, const double* hi_dev = nullptr,
                    double outside = 0.0, double inside_const = 0.0, const int* cmp_dev = nullptr);
-// ll[row] = outside for the rows outside the open box; the rows inside are gathered into ctx->Xs (in order), their
+// ll[row] = outside for the rows outside the open box; the rows inside are gathered into ctx->cmp_X (in order), their
 // indices and count into ctx->cmp_idx
-int launch_compact(gpb_ctx* ctx, const double* X_dev, int64_t W, const double* lo_dev, const double* hi_dev,
+int launch_compact(gpb_ctx* ctx, const double* X_dev, int64_t W, int64_t dx, const double* lo_dev, const double* hi_dev,
                    double outside, double* ll_dev);
 int launch_mvn(gpb_ctx* ctx, const double* dY_dev, const double* cov_dev, int64_t W, int64_t M, double* ll_dev);
 bool compaction_applies(const gpb_ctx* ctx);

@@ -823,16 +823,28 @@ __global__ __launch_bounds__(256) void k_compact_gather(const double* __restrict
     }
 }
 
-int launch_compact(gpb_ctx* ctx, const double* X_dev, int64_t W, const double* lo_dev, const double* hi_dev,
+// X_dev [W][dx]: dx = the chain's number of parameters (the GP's d unless the emulator has a parameter map).  The
+// gathered rows land in ctx->cmp_X (grown on demand), indices and count in ctx->cmp_idx.
+int launch_compact(gpb_ctx* ctx, const double* X_dev, int64_t W, int64_t dx, const double* lo_dev, const double* hi_dev,
                    double outside, double* ll_dev) {
     if (W > ctx->Wcap || W >= (1ll << 31)) GPB_FAIL(GPB_E_STATE, "gpb: internal: compaction beyond the workspace");
+    if (ctx->cmp_X_cap < ctx->Wcap * dx) {
+        GPB_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->cmp_X) GPB_HIP(hipFree(ctx->cmp_X));
+        ctx->cmp_X = nullptr;
+        GPB_HIP(hipMalloc(&ctx->cmp_X, sizeof(double) * (size_t)(ctx->Wcap * dx)));
+        GPB_HIP(hipMemsetAsync(ctx->cmp_X, 0, sizeof(double) * (size_t)(ctx->Wcap * dx), ctx->stream));   // rows past the count are read (not used) by the upper-bound launches
+        ctx->cmp_X_cap = ctx->Wcap * dx;
+    }
     const unsigned nb = (unsigned)((W + 255) / 256);
     int* rank = ctx->cmp_idx + 4 + ctx->Wcap;          // [Wcap] ranks, then [Wcap / 256 + 1] workgroup counts
     int* blockcnt = rank + ctx->Wcap;
-    const size_t sh = sizeof(double) * 256 * (size_t)(ctx->d + 1);
-    hipLaunchKernelGGL(k_compact_mark, dim3(nb), dim3(256), sh, ctx->stream, X_dev, W, (int)ctx->d, lo_dev, hi_dev, outside,
+    const size_t sh = sizeof(double) * 256 * (size_t)(dx + 1);
+    if (sh > 64 * 1024)
+        GPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_compact_mark), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    hipLaunchKernelGGL(k_compact_mark, dim3(nb), dim3(256), sh, ctx->stream, X_dev, W, (int)dx, lo_dev, hi_dev, outside,
                        ll_dev, rank, blockcnt);
-    hipLaunchKernelGGL(k_compact_gather, dim3(nb), dim3(256), 0, ctx->stream, X_dev, W, (int)ctx->d, rank, blockcnt, ctx->Xs,
+    hipLaunchKernelGGL(k_compact_gather, dim3(nb), dim3(256), 0, ctx->stream, X_dev, W, (int)dx, rank, blockcnt, ctx->cmp_X,
                        ctx->cmp_idx, ctx->profile ? ctx->rows_live : nullptr);
     GPB_HIP(hipGetLastError());
     return 0;
@@ -1073,58 +1085,136 @@ __global__ void k_fill(double* __restrict__ x, int64_t n, double v) {
     if (i < n) x[i] = v;
 }
 
-extern "C" int gpb_emcee_run(gpb_ctx* ctx, double* pos_dev, double* lp_dev, int64_t nwalkers, int64_t nsteps,
-                             uint64_t seed, uint64_t step0, double a, int randomize_split, const double* lo_dev,
-                             const double* hi_dev, double outside_value, double inside_const, double* chain_dev,
-                             double* lpchain_dev, int64_t* naccept_dev) {
-    if (!ctx || !pos_dev || !lp_dev || !lo_dev || !hi_dev || nsteps < 0) return GPB_E_ARG;
-    if (nwalkers < 2 || (nwalkers & 1) || nwalkers > (1ll << 30)) GPB_FAIL(GPB_E_ARG, "gpb_emcee_run: nwalkers must be even, 2 .. 2^30");
-    if (!ctx->have_like) GPB_FAIL(GPB_E_STATE, "gpb_emcee_run before gpb_like_set");
-    if (ctx->pmap_d_in > 0) GPB_FAIL(GPB_E_STATE, "gpb_emcee_run: emulators with a parameter map take the host-driven loop");
+// ---- chains of several emulators ---------------------------------------------------------------------
+// Chain._predict concatenates the emulators' observables and the covariance is block-diagonal over them
+// (src/mcmc.py:153-166), so the log-likelihood is the sum of the emulators' blocks; all emulators see the same rows of
+// the same parameter space (those with a parameter map, src/emulator.py:492-551, through gpb_param_map).
+namespace {
+int64_t chain_ndim(const gpb_ctx* c) { return c->pmap_d_in > 0 ? c->pmap_d_in : c->d; }
+
+// every context usable by the compacted chain path?  (same device, stream and parameter space; likelihood installed;
+// a block likelihood kernel applies)
+int chain_check(gpb_ctx* const* ctxs, int E, const char* who) {
+    gpb_ctx* ctx = ctxs[0];
+    for (int e = 0; e < E; ++e) {
+        const gpb_ctx* c = ctxs[e];
+        if (!c) GPB_FAIL(GPB_E_ARG, std::string(who) + ": null context");
+        if (!c->have_like) GPB_FAIL(GPB_E_STATE, std::string(who) + " before gpb_like_set");
+        if (c->device != ctx->device || c->stream != ctx->stream)
+            GPB_FAIL(GPB_E_STATE, std::string(who) + ": the emulators' contexts must share one device and stream");
+        if (chain_ndim(c) != chain_ndim(ctx)) GPB_FAIL(GPB_E_ARG, std::string(who) + ": the emulators disagree on the number of parameters");
+        if (!compaction_applies(c))
+            GPB_FAIL(GPB_E_STATE, std::string(who) + ": needs the block likelihood kernels (PCA mode, M <= 64 or npc <= 16) for every emulator");
+    }
+    return 0;
+}
+
+// log-posterior of rows X[W][ndim] over all emulators, rows inside the box only (ctxs[0] owns the compaction)
+int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, double* ll_dev, const double* lo_dev,
+               const double* hi_dev, double outside, double inside_const) {
+    gpb_ctx* c0 = ctxs[0];
+    int rc;
+    for (int e = 0; e < E; ++e)
+        if ((rc = ensure_wcap(ctxs[e], W))) { if (e) c0->err = ctxs[e]->err; return rc; }
+    if ((rc = launch_compact(c0, X_dev, W, chain_ndim(c0), lo_dev, hi_dev, outside, ll_dev))) return rc;
+    for (int e = 0; e < E; ++e) {
+        gpb_ctx* c = ctxs[e];
+        const double* Xg = c0->cmp_X;
+        if (c->pmap_d_in > 0) {                        // this emulator's GPs see the PCA-reduced parameters
+            if ((rc = gpb_param_map(c, c0->cmp_X, W, c->Xs))) { c0->err = c->err; return rc; }
+            Xg = c->Xs;
+        }
+        const bool fused = loglike_fuses_finalize(c, W);
+        if ((rc = launch_predict(c, Xg, W, true, !fused, c0->cmp_idx)) ||
+            (rc = launch_loglike(c, W, ll_dev, e > 0, fused, nullptr, nullptr, nullptr, outside,
+                                 e == E - 1 ? inside_const : 0.0, c0->cmp_idx))) {
+            c0->err = c->err;
+            return rc;
+        }
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" int gpb_chain_supported(gpb_ctx* const* ctxs, int E) {
+    if (!ctxs || E < 1 || E > 64 || !ctxs[0]) return GPB_E_ARG;
+    for (int e = 0; e < E; ++e) {
+        const gpb_ctx* c = ctxs[e];
+        if (!c) return GPB_E_ARG;
+        if (!c->have_like || c->device != ctxs[0]->device || c->stream != ctxs[0]->stream ||
+            chain_ndim(c) != chain_ndim(ctxs[0]) || !compaction_applies(c))
+            return 0;
+    }
+    return 1;
+}
+
+extern "C" int gpb_chain_logpost(gpb_ctx* const* ctxs, int E, const double* Xs_dev, int64_t W, double* ll_dev,
+                                 const double* lo_dev, const double* hi_dev, double outside_value, double inside_const) {
+    if (!ctxs || E < 1 || E > 64 || !ctxs[0]) return GPB_E_ARG;
+    gpb_ctx* ctx = ctxs[0];
+    if (!Xs_dev || !ll_dev || !lo_dev || !hi_dev || W < 0) GPB_FAIL(GPB_E_ARG, "gpb_chain_logpost: null pointer or negative size");
+    int rc = chain_check(ctxs, E, "gpb_chain_logpost");
+    if (rc) return rc;
+    if (W == 0) return 0;
     GPB_HIP(hipSetDevice(ctx->device));
-    const int64_t nh = nwalkers / 2, d = ctx->d;
+    return chain_rows(ctxs, E, Xs_dev, W, ll_dev, lo_dev, hi_dev, outside_value, inside_const);
+}
+
+extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev, double* lp_dev, int64_t nwalkers,
+                                   int64_t nsteps, uint64_t seed, uint64_t step0, double a, int randomize_split,
+                                   const double* lo_dev, const double* hi_dev, double outside_value, double inside_const,
+                                   double* chain_dev, double* lpchain_dev, int64_t* naccept_dev) {
+    if (!ctxs || E < 1 || E > 64 || !ctxs[0]) return GPB_E_ARG;
+    gpb_ctx* ctx = ctxs[0];
+    if (!pos_dev || !lp_dev || !lo_dev || !hi_dev || nsteps < 0) GPB_FAIL(GPB_E_ARG, "gpb_chain_emcee_run: null pointer or negative size");
+    if (nwalkers < 2 || (nwalkers & 1) || nwalkers > (1ll << 30)) GPB_FAIL(GPB_E_ARG, "gpb_chain_emcee_run: nwalkers must be even, 2 .. 2^30");
+    // one emulator without a parameter map may also run uncompacted (tune key 27 = 0, non-PCA modes): gpb_logpost's sequence
+    const bool plain = E == 1 && ctx->pmap_d_in == 0 && !compaction_applies(ctx);
+    int rc;
+    if (plain) {
+        if (!ctx->have_like) GPB_FAIL(GPB_E_STATE, "gpb_emcee_run before gpb_like_set");
+    } else if ((rc = chain_check(ctxs, E, "gpb_chain_emcee_run"))) {
+        return rc;
+    }
+    GPB_HIP(hipSetDevice(ctx->device));
+    const int64_t nh = nwalkers / 2, d = chain_ndim(ctx);
     int R = ctx->comm ? ctx->nranks : 1;
     const int rank = ctx->comm ? ctx->rank : 0;
     // measurement hook (tune key 26): behave like ONE rank of `sim_ranks` on a single GPU — evaluate the first
     // nh / sim_ranks rows of every batch only (the other rows keep -inf: rejected) and still issue the collective
     const bool sim = ctx->sim_ranks > 1 && R == 1;
     if (sim) R = ctx->sim_ranks;
-    if (nh % R) GPB_FAIL(GPB_E_ARG, "gpb_emcee_run: half the ensemble must divide evenly over the ranks");
-    const int64_t chunk = nh / R, r0 = rank * chunk;
-    int rc = ensure_wcap(ctx, chunk);
-    if (rc) return rc;
-    if (ctx->mc_cap < nh) {                            // proposal workspace: q[nh][d], factor[nh], lpq[nh]
+    if (nh % R) GPB_FAIL(GPB_E_ARG, "gpb_chain_emcee_run: half the ensemble must divide evenly over the ranks");
+    const int64_t chunk = nh / R, r0 = sim ? 0 : rank * chunk;
+    if ((rc = ensure_wcap(ctx, chunk))) return rc;
+    if (ctx->mc_cap < nh * (d + 2)) {                  // proposal workspace: q[nh][d], factor[nh], lpq[nh]
         GPB_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->mc_ws) GPB_HIP(hipFree(ctx->mc_ws));
         ctx->mc_ws = nullptr;
         GPB_HIP(hipMalloc(&ctx->mc_ws, sizeof(double) * (size_t)(nh * (d + 2))));
-        ctx->mc_cap = nh;
+        ctx->mc_cap = nh * (d + 2);
     }
     double* q = ctx->mc_ws;
     double* factor = q + nh * d;
     double* lpq = factor + nh;
     const int hb = half_bits(nwalkers), rnd = randomize_split ? 1 : 0;
     const dim3 g32((unsigned)((nh * 32 + 255) / 256));
-    const bool fused = loglike_fuses_finalize(ctx, chunk);
+    const bool fused = plain && loglike_fuses_finalize(ctx, chunk);
     if (sim) hipLaunchKernelGGL(k_fill, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, ctx->stream, lpq, nh, -INFINITY);
     for (int64_t n = 0; n < nsteps; ++n) {
         const uint32_t step = (uint32_t)(step0 + (uint64_t)n);
         for (int half = 0; half < 2; ++half) {
             hipLaunchKernelGGL(k_propose, g32, dim3(256), 0, ctx->stream, pos_dev, nh, (int)d, half, seed, step, a, q, factor,
                                hb, rnd);
-            // this rank's rows of the batch: K*^T + mean partials, V = L^-1 K*^T with the fused sum of squares, block
-            // log-likelihood + prior box + constant (gpb_logpost's sequence)
-            if (compaction_applies(ctx)) {
-                if ((rc = launch_compact(ctx, q + r0 * d, chunk, lo_dev, hi_dev, outside_value, lpq + r0))) return rc;
-                if ((rc = launch_predict(ctx, ctx->Xs, chunk, true, !fused, ctx->cmp_idx))) return rc;
-                if ((rc = launch_loglike(ctx, chunk, lpq + r0, false, fused, nullptr, nullptr, nullptr, outside_value,
-                                         inside_const, ctx->cmp_idx)))
-                    return rc;
-            } else {
+            // this rank's rows of the batch: [compaction to the rows inside the box,] per emulator K*^T + mean partials,
+            // V = L^-1 K*^T with the fused sum of squares, block log-likelihood (+ prior box + constant)
+            if (plain) {
                 if ((rc = launch_predict(ctx, q + r0 * d, chunk, true, !fused))) return rc;
                 if ((rc = launch_loglike(ctx, chunk, lpq + r0, false, fused, q + r0 * d, lo_dev, hi_dev, outside_value,
                                          inside_const)))
                     return rc;
+            } else if ((rc = chain_rows(ctxs, E, q + r0 * d, chunk, lpq + r0, lo_dev, hi_dev, outside_value, inside_const))) {
+                return rc;
             }
             if (sim ? ctx->comm != nullptr : R > 1)                      // in place, on this stream
                 if ((rc = gpb_dist_allgather(ctx, lpq + r0, lpq, chunk))) return rc;
@@ -1139,6 +1229,18 @@ extern "C" int gpb_emcee_run(gpb_ctx* ctx, double* pos_dev, double* lp_dev, int6
     }
     GPB_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int gpb_emcee_run(gpb_ctx* ctx, double* pos_dev, double* lp_dev, int64_t nwalkers, int64_t nsteps,
+                             uint64_t seed, uint64_t step0, double a, int randomize_split, const double* lo_dev,
+                             const double* hi_dev, double outside_value, double inside_const, double* chain_dev,
+                             double* lpchain_dev, int64_t* naccept_dev) {
+    if (!ctx) return GPB_E_ARG;
+    if (ctx->pmap_d_in > 0 && !compaction_applies(ctx))
+        GPB_FAIL(GPB_E_STATE, "gpb_emcee_run: an emulator with a parameter map needs the block likelihood kernels");
+    gpb_ctx* one[1] = {ctx};
+    return gpb_chain_emcee_run(one, 1, pos_dev, lp_dev, nwalkers, nsteps, seed, step0, a, randomize_split, lo_dev, hi_dev,
+                               outside_value, inside_const, chain_dev, lpchain_dev, naccept_dev);
 }
 
 extern "C" int gpb_test_split_perm(gpb_ctx* ctx, int64_t n, uint64_t seed, uint64_t step, int64_t* out_dev) {

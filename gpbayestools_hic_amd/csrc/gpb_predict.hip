@@ -502,6 +502,8 @@ int ensure_wcap(gpb_ctx* ctx, int64_t W) {
     GPB_HIP(hipMalloc(&ctx->mean_pc, sizeof(double) * P * need));
     GPB_HIP(hipMalloc(&ctx->var_pc, sizeof(double) * P * need));
     if (ctx->cmp_idx) { GPB_HIP(hipFree(ctx->cmp_idx)); ctx->cmp_idx = nullptr; }
+    if (ctx->cmp_X) { GPB_HIP(hipFree(ctx->cmp_X)); ctx->cmp_X = nullptr; }
+    ctx->cmp_X_cap = 0;
     // [0] = number of rows inside the box, [4..] = their indices; then the compaction's scratch: ranks, workgroup counts
     GPB_HIP(hipMalloc(&ctx->cmp_idx, sizeof(int) * (size_t)(4 + 2 * need + need / 256 + 8)));
     ctx->Wcap = need;

@@ -164,10 +164,29 @@ class Chain:
             self._box_key = key
         return self._box_dev
 
+    use_chain_call = True                        # False: sequence the emulators from Python (A/B tests)
+
+    def _chain_contexts(self):
+        """(engines, ctypes array of their contexts) when the C ABI can evaluate the whole chain in one call
+        (gpb_chain_logpost / gpb_chain_emcee_run: rows outside the prior box skipped, one emulator after the other on
+        one stream), else None.  Call after _prepare_blocks()."""
+        from . import _native as nat
+        if not (self.use_chain_call and self._native()):
+            return None
+        engs = [e._engine_ready() for e in self.emuList]
+        for g in engs:
+            g._need_data()
+            g._track_stream()
+        arr = (nat.C.c_void_p * len(engs))(*[g.h for g in engs])
+        if engs[0].lib.gpb_chain_supported(arr, len(engs)) != 1:
+            return None
+        return engs, arr
+
     def log_prob_device(self, X_dev, out=None, outside=-np.inf, lo_dev=None, hi_dev=None):
         """Device-resident log-posterior: X_dev torch.float64 cuda [W,ndim] -> lp [W] (no host
         sync).  Used by the resident sampler; `log_posterior`/`log_likelihood` wrap it."""
         import torch
+        from . import _native as nat
         self._prepare_blocks()
         if out is None:
             out = torch.empty(X_dev.shape[0], dtype=torch.float64, device=X_dev.device)
@@ -177,6 +196,16 @@ class Chain:
         last = len(self.emuList) - 1
         if X_dev.shape[1] != self.ndim:
             raise ValueError("log_prob_device: X has %d columns, the chain has %d parameters" % (X_dev.shape[1], self.ndim))
+        cc = self._chain_contexts()
+        if cc is not None:
+            engs, arr = cc
+            e0 = engs[0]
+            X_dev = e0._dev(X_dev, (None, self.ndim), "X")
+            e0._dev(lo_dev, (self.ndim,), "lo"), e0._dev(hi_dev, (self.ndim,), "hi")
+            e0._dev(out, (X_dev.shape[0],), "out")
+            e0._ck(e0.lib.gpb_chain_logpost(arr, len(engs), nat.ptr(X_dev), X_dev.shape[0], nat.ptr(out), nat.ptr(lo_dev),
+                                            nat.ptr(hi_dev), float(outside), EXTRA_STD_CONST))
+            return out
         for i, emu in enumerate(self.emuList):      # all engines enqueue on torch's current stream: ordered
             eng = emu._engine_ready()
             mapped = getattr(emu, "parameterTrafoPCA_", False)

@@ -82,26 +82,34 @@ class StretchSampler:
 
     # ------------------------------------------------------------------ main loop
     def _resident_engine(self):
-        """The engine whose gpb_emcee_run can drive the whole loop from C (no Python per step), or None: the chain must
-        be this package's Chain with ONE emulator and no parameter map, no log-probability override, and any sharding
-        must go through the C ABI's own communicator on that engine with an even split (WalkerSharding.try_direct)."""
+        """(engine, contexts, count) when gpb_chain_emcee_run can drive the whole loop from C (no Python per step), or
+        None: the chain must be this package's Chain of native emulators (any number, with or without parameter maps),
+        no log-probability override, and any sharding must go through the C ABI's own communicator on the FIRST
+        emulator's engine with an even split (WalkerSharding.try_direct)."""
         ch = self.chain_obj
         emus = getattr(ch, "emuList", None)
-        if self._logprob_override or not emus or len(emus) != 1 or not hasattr(ch, "_prepare_blocks"):
+        if self._logprob_override or not emus or not hasattr(ch, "_prepare_blocks"):
             return None
-        emu = emus[0]
-        if not hasattr(emu, "_engine_ready") or getattr(emu, "parameterTrafoPCA_", False):
+        if not all(hasattr(e, "_engine_ready") for e in emus):
             return None
-        eng = emu._engine_ready()
+        ch._prepare_blocks()
+        eng = emus[0]._engine_ready()
         sh = self.sharding
         if sh is not None:
             if getattr(sh, "direct", None) is not eng or (self.nwalkers // 2) % sh.world:
                 return None
         elif getattr(eng, "_dist_world", 0) > 1:
             return None                    # a communicator is installed but this sampler was not told to shard
-        if eng.d != self.ndim:
+        if ch.ndim != self.ndim:
             return None
-        return eng
+        cc = ch._chain_contexts() if hasattr(ch, "_chain_contexts") else None
+        if cc is None:
+            # one emulator without a parameter map also runs uncompacted (non-PCA modes, tune("compact", 0))
+            if len(emus) != 1 or getattr(emus[0], "parameterTrafoPCA_", False) or eng.d != self.ndim:
+                return None
+            eng._track_stream()
+            cc = [eng], (nat.C.c_void_p * 1)(eng.h)
+        return eng, cc[1], len(cc[0])
 
     def _check_nan(self, eng):
         n = nat.c_i64(0)
@@ -135,13 +143,13 @@ class StretchSampler:
             if res is not None:
                 # the C ABI enqueues all m steps itself (gpb_emcee_run): propose -> GP predict -> block likelihood +
                 # prior box -> [in-stream all-gather] -> accept, no Python in between
-                self.chain_obj._prepare_blocks()
                 lo, hi = self.chain_obj._box(self.device)
-                res._ck(lib.gpb_emcee_run(res.h, nat.ptr(self.pos), nat.ptr(self.lp), nw, m, self.seed,
-                                          self._step_counter, self.a, self.randomize_split, nat.ptr(lo), nat.ptr(hi),
-                                          float("-inf"), self.chain_obj.inside_const,
-                                          nat.ptr(cd[n:n + m]) if store else None,
-                                          nat.ptr(ld[n:n + m]) if store else None, nat.ptr(self.naccept)))
+                reng, ctxs, nemu = res
+                reng._ck(lib.gpb_chain_emcee_run(ctxs, nemu, nat.ptr(self.pos), nat.ptr(self.lp), nw, m, self.seed,
+                                                 self._step_counter, self.a, self.randomize_split, nat.ptr(lo),
+                                                 nat.ptr(hi), float("-inf"), self.chain_obj.inside_const,
+                                                 nat.ptr(cd[n:n + m]) if store else None,
+                                                 nat.ptr(ld[n:n + m]) if store else None, nat.ptr(self.naccept)))
                 self._step_counter += m
             else:
                 for i in range(m):
@@ -160,7 +168,7 @@ class StretchSampler:
             n += m
             self.iterations += m
             if n % status == 0 or n == nsteps:
-                self._check_nan(res if res is not None else eng)          # synchronises: once per status line
+                self._check_nan(res[0] if res is not None else eng)          # synchronises: once per status line
                 af = self.acceptance_fraction
                 log.info("step %d: acceptance fraction: mean %.4f, std %.4f, min %.4f, max %.4f",
                          n, af.mean(), af.std(), af.min(), af.max())

@@ -197,6 +197,23 @@ int gpb_emcee_run(gpb_ctx* ctx, double* pos_dev /*[nw,d]*/, double* lp_dev /*[nw
                   const double* lo_dev /*[d]*/, const double* hi_dev /*[d]*/, double outside_value, double inside_const,
                   double* chain_dev, double* lpchain_dev, int64_t* naccept_dev /*[nw]*/);
 
+/* Chains of several emulators (Chain.emuList, src/mcmc.py:139-166): the covariance is block-diagonal over the emulators,
+ * the log-likelihood the sum of their blocks.  ctxs[0..E) are the emulators' contexts in emuList order, all on one device
+ * and stream, each with its likelihood block installed (gpb_like_set) and, for parameterTrafoPCA emulators, its
+ * parameter map (gpb_param_map_set); rows are in the chain's ORIGINAL parameters [W, ndim].
+ * gpb_chain_logpost   <- Chain.log_posterior / log_likelihood for the whole chain, rows inside the box only.
+ * gpb_chain_emcee_run <- gpb_emcee_run for such a chain (a communicator, if any, is taken from ctxs[0]).
+ * Both need the block likelihood kernels for every emulator (PCA modes with M <= 64 or npc <= 16); GPB_E_STATE
+ * otherwise (the caller then sequences gpb_loglike / gpb_box_finish itself).
+ * gpb_chain_supported: 1 when the two calls would accept these contexts as they stand, 0 when not, < 0 on bad arguments. */
+int gpb_chain_supported(gpb_ctx* const* ctxs, int E);
+int gpb_chain_logpost(gpb_ctx* const* ctxs, int E, const double* Xs_dev /*[W,ndim]*/, int64_t W, double* ll_dev /*[W]*/,
+                      const double* lo_dev, const double* hi_dev, double outside_value, double inside_const);
+int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev, double* lp_dev, int64_t nwalkers, int64_t nsteps,
+                        uint64_t seed, uint64_t step0, double a, int randomize_split,
+                        const double* lo_dev, const double* hi_dev, double outside_value, double inside_const,
+                        double* chain_dev, double* lpchain_dev, int64_t* naccept_dev);
+
 /* ---- walker sharding over RCCL (one process per GPU) ------------------------------ *
  * gpb_dist_uid: rank 0 obtains a 128-byte ncclUniqueId to broadcast out of band.
  * gpb_dist_init / gpb_dist_allgather: in-stream ncclAllGather of per-walker

@@ -135,6 +135,42 @@ def test_g5_chain_log_probabilities(tmp_path):
     assert relerr(ch2.log_posterior(Xw)[ins], g["log_posterior"][ins]) < 1e-10
 
 
+def test_g5_chain_in_one_call_equals_the_sequenced_calls(tmp_path):
+    """gpb_chain_logpost / gpb_chain_emcee_run over the two emulators of G5 (block-diagonal covariance,
+    src/mcmc.py:153-166) against the per-emulator calls sequenced from Python: identical bits, for the
+    log-probabilities and for a sampled chain"""
+    import ctypes
+    from gpbayestools_hic_amd import StretchSampler
+    g = golden("g5_chain.npz")
+    ch = _chain(tmp_path, g)
+    X = np.concatenate([g["Xw"], g["Xout"], g["Xw"][::-1]])
+    one = ch.log_posterior(X)
+    engs = [e._engine_ready() for e in ch.emuList]
+    assert engs[0].lib.gpb_chain_supported((ctypes.c_void_p * 2)(*[e.h for e in engs]), 2) == 1
+    ch.use_chain_call = False
+    assert np.array_equal(ch.log_posterior(X), one)
+    assert np.array_equal(ch.log_likelihood(X, finite=True), np.where(np.isneginf(one), -1e300, one))
+    nw = 40
+    lo, hi = ch.min, ch.max
+    X0 = lo + (hi - lo) * np.random.default_rng(8).uniform(0.2, 0.8, (nw, ch.ndim))
+    host = StretchSampler(ch, nw, seed=3)
+    assert host._resident_engine() is None                   # two emulators: only the chain call drives them from C
+    host.run(X0, 8, status=3)
+    ch.use_chain_call = True
+    res = StretchSampler(ch, nw, seed=3)
+    assert res._resident_engine()[2] == 2
+    res.run(X0, 5, status=100)
+    res.run(None, 3, status=2)
+    assert np.array_equal(res.chain, host.chain) and np.array_equal(res.lnprobability, host.lnprobability)
+    assert np.array_equal(res.naccept.cpu().numpy(), host.naccept.cpu().numpy())
+    assert np.any(res.naccept.cpu().numpy() > 0)
+    # a chain whose emulators sit on different streams or lack a likelihood block is refused, not mis-evaluated
+    from gpbayestools_hic_amd import GPEngine
+    bare = GPEngine(0)
+    assert engs[0].lib.gpb_chain_supported((ctypes.c_void_p * 2)(engs[0].h, bare.h), 2) == 0
+    bare.close()
+
+
 def test_g6_mvn_loglike_function():
     from gpbayestools_hic_amd import mvn_loglike
     g = golden("g6_mvn.npz")

@@ -168,7 +168,7 @@ def test_resident_c_loop_equals_the_host_driven_loop(tmp_path):
     X0 = synth.walkers(nw, d, seed=21)
     X0[5, 0] = 1.7                                            # a walker that starts outside the prior box
     c = StretchSampler(chain, nw, seed=5)
-    assert c._resident_engine() is emu._engine_ready()
+    assert c._resident_engine()[0] is emu._engine_ready()
     c.run(X0, 7, status=3)
     c.run(None, 6, status=100)
     h = StretchSampler(chain, nw, seed=5)
@@ -201,7 +201,7 @@ def test_resident_loop_with_a_one_rank_communicator(tmp_path):
     sh = types.SimpleNamespace(world=1, rank=0, direct=eng,
                                logprob=lambda fn, X, out: fn(X, out))
     s = StretchSampler(chain, nw, seed=9, sharding=sh)
-    assert s._resident_engine() is eng
+    assert s._resident_engine()[0] is eng
     s.run(X0, 8)
     eng.dist_finalize()
     assert np.array_equal(s.chain, ref.chain) and np.array_equal(s.lnprobability, ref.lnprobability)

@@ -122,3 +122,23 @@ def test_chain_with_parameter_pca_uses_device_map(tmp_path):
     mY, mC = chain._predict(Xw[inside], 0.0)
     ref2 = np.array([O.mvn_loglike(m - yexp, c + np.diag(err ** 2)) for m, c in zip(mY, mC)]) + O.EXTRA_STD_CONST
     assert relerr(lp[inside], ref2) < 1e-10
+    # the whole chain in one C call (gpb_chain_logpost: rows inside the box gathered, mapped, GP, likelihood) against
+    # the same calls sequenced from Python over all rows: the same bits
+    assert eng.lib.gpb_chain_supported((__import__("ctypes").c_void_p * 1)(eng.h), 1) == 1
+    chain.use_chain_call = False
+    assert np.array_equal(chain.log_posterior(Xw), lp)
+    # ... and the C-driven sampling loop over the mapped emulator against the host-driven one
+    from gpbayestools_hic_amd import StretchSampler
+    nw = 44
+    X0 = g["lo"] + (g["hi"] - g["lo"]) * np.random.default_rng(3).uniform(0.3, 0.7, (nw, len(g["lo"])))
+    X0[7, 2] = g["hi"][2] + 1.0
+    host = StretchSampler(chain, nw, seed=11)
+    assert host._resident_engine() is None
+    host.run(X0, 6, status=4)
+    chain.use_chain_call = True
+    res = StretchSampler(chain, nw, seed=11)
+    assert res._resident_engine()[0] is eng
+    res.run(X0, 6, status=5)
+    assert np.array_equal(res.chain, host.chain) and np.array_equal(res.lnprobability, host.lnprobability)
+    assert np.array_equal(res.naccept.cpu().numpy(), host.naccept.cpu().numpy())
+    assert np.isfinite(res.lnprobability).any() and np.any(res.naccept.cpu().numpy() > 0)

@@ -58,7 +58,7 @@ def main():
         row = {"ranks_simulated": world, "walkers_per_rank_per_batch": nw // 2 // world, "collective_enqueued": comm and world > 1}
         eng.tune("sim_ranks", world if world > 1 else 0)
         s = StretchSampler(chain, nw, seed=1)
-        assert s._resident_engine() is eng
+        assert s._resident_engine()[0] is eng
         s.run(X0, 3, store=False, status=10 ** 9)
         row["c_loop_ms_per_step"] = round(timed(s), 4)
         eng.tune("sim_ranks", 0)
