@@ -38,6 +38,38 @@ def build_chain(cfg, workdir=None, device=0, N=None, W=None):
     return chain, emu, info
 
 
+def build_multi_chain(specs, d, workdir=None, device=0):
+    """A chain of several emulators over one parameter space, as real analyses run it (nine emulators, sum of
+    observables ~540: RunBayesianAnalysis.ipynb:35-48; src/mcmc.py:139-166).  specs: [(N, M, P, kernel)], every
+    emulator with its own design, observables and (fixed) hyper-parameters.  Returns (chain, emulators, info)."""
+    from .emulator import Emulator
+    from .mcmc import Chain
+    workdir = workdir or tempfile.mkdtemp(prefix="gpb_multi_")
+    lo, hi = np.zeros(d), np.ones(d)
+    pf, ep = os.path.join(workdir, "par.txt"), os.path.join(workdir, "exp.pkl")
+    synth.write_parameter_file(pf, lo, hi)
+    xstar = synth.truth_point(d)
+    emus, data, yexp = [], [], []
+    for i, (N, M, P, kernel) in enumerate(specs):
+        X = synth.lhs(N, d, seed=synth.SEED + 100 + i)
+        Y = synth.observables(X, M, seed=synth.SEED + 200 + i)
+        tp = os.path.join(workdir, "train%d.pkl" % i)
+        synth.write_training_pickle(tp, X, Y, 0.01)
+        emu = Emulator(training_set_path=tp, parameter_file=pf, npc=P, device=device)
+        ktype = {"RBF": "RBF", "Matern15": "Matern", "Matern25": "Matern25"}[kernel]
+        emu.trainEmulator([True] * emu.nev, kernel_type=ktype,
+                          thetas=synth.fixed_theta(d, P, ell=1.2 + 0.1 * i, noise=0.03 + 0.01 * i))
+        yexp.append(emu.predict(xstar[None, :], return_cov=False)[0])
+        emus.append(emu)
+        data.append((X, Y))
+    yexp = np.concatenate(yexp)
+    synth.write_experiment_pickle(ep, yexp, 0.05 * np.abs(yexp))
+    chain = Chain(mcmc_path=os.path.join(workdir, "mcmc", "chain.pkl"), expdata_path=ep, model_parafile=pf,
+                  device=device)
+    chain.emuList = emus
+    return chain, emus, dict(d=d, lo=lo, hi=hi, specs=list(specs), data=data, yexp=yexp, xstar=xstar, workdir=workdir)
+
+
 def flops_per_walker(N, d, P, M, kernel="RBF"):
     """Algorithmic flops of one walker's log-posterior."""
     fpair = 3 * d + 3 if kernel == "RBF" else 3 * d + 10
