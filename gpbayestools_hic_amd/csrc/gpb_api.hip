@@ -108,6 +108,11 @@ extern "C" int gpb_ctx_create(int device, void* stream, gpb_ctx** out) {
         delete ctx;
         return GPB_E_ALLOC;
     }
+    // optional: without it the tile rule sizes compacted batches by their upper bound
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->live_hint), sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess)
+        *ctx->live_hint = 0;
+    else
+        ctx->live_hint = nullptr, (void)hipGetLastError();
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0)
         ctx->num_cu = ncu;
@@ -133,6 +138,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     dev_free(&ctx->A); dev_free(&ctx->mu); dev_free(&ctx->scale); dev_free(&ctx->C0); dev_free(&ctx->yexp);
     dev_free(&ctx->Cexp); dev_free(&ctx->mvn_ws); dev_free(&ctx->notpd); dev_free(&ctx->tile_counter);
     dev_free(&ctx->n_nan); dev_free(&ctx->mc_ws); dev_free(&ctx->rows_live); dev_free(&ctx->cmp_idx); dev_free(&ctx->cmp_X);
+    if (ctx->live_hint) (void)hipHostFree(ctx->live_hint);
     for (hipEvent_t e : ctx->chol_events) (void)hipEventDestroy(e);
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -745,6 +751,7 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 25: if (value < 0 || value > 1) return GPB_E_ARG; ctx->chol_lookahead = value; break;
         case 26: if (value < 0 || value > 64) return GPB_E_ARG; ctx->sim_ranks = value; break;
         case 27: if (value < 0 || value > 1) return GPB_E_ARG; ctx->compact = value; break;
+        case 28: if (value < 0 || value > 1) return GPB_E_ARG; ctx->tile_by_live = value; break;
         default: return GPB_E_ARG;
     }
     return 0;

@@ -63,6 +63,9 @@ struct gpb_ctx {
     double* spart = nullptr;       // [Np/64][P][Wcap]  sum-of-squares partials per 64-row block
     double* mean_pc = nullptr;     // [P][Wcap]
     double* var_pc = nullptr;      // [P][Wcap]
+    unsigned long long* live_hint = nullptr;   // pinned host memory: (batch rows << 32) | live rows of the last finished compaction
+    gpb_ctx* hint_from = nullptr;  // whose live_hint sizes this context's tile rule (the chain's first emulator compacts)
+    int tile_by_live = 1;          // tune key 28
     double* cmp_X = nullptr;       // the rows of the current batch inside the prior box, gathered in order [Wcap][chain ndim]
     int64_t cmp_X_cap = 0;
     int* cmp_idx = nullptr;        // compaction of a log-posterior batch to the rows inside the prior box: [0] = count, [4..] = row indices

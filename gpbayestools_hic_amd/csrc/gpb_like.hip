@@ -796,7 +796,8 @@ __global__ __launch_bounds__(256) void k_compact_mark(const double* __restrict__
 __global__ __launch_bounds__(256) void k_compact_gather(const double* __restrict__ X, int64_t W, int d,
                                                         const int* __restrict__ rank, const int* __restrict__ blockcnt,
                                                         double* __restrict__ Xc, int* __restrict__ cmp,
-                                                        unsigned long long* __restrict__ rows_live) {
+                                                        unsigned long long* __restrict__ rows_live,
+                                                        unsigned long long* __restrict__ hint) {
     __shared__ int s_base;
     __shared__ int row_of[256];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -819,6 +820,8 @@ __global__ __launch_bounds__(256) void k_compact_gather(const double* __restrict
     }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
         cmp[0] = base + cnt;
+        if (hint) __hip_atomic_store(hint, ((unsigned long long)W << 32) | (unsigned long long)(base + cnt), __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_SYSTEM);        // for the host's tile-shape rule, read without a sync
         if (rows_live) atomicAdd(rows_live, (unsigned long long)(base + cnt));
     }
 }
@@ -845,7 +848,8 @@ int launch_compact(gpb_ctx* ctx, const double* X_dev, int64_t W, int64_t dx, con
     hipLaunchKernelGGL(k_compact_mark, dim3(nb), dim3(256), sh, ctx->stream, X_dev, W, (int)dx, lo_dev, hi_dev, outside,
                        ll_dev, rank, blockcnt);
     hipLaunchKernelGGL(k_compact_gather, dim3(nb), dim3(256), 0, ctx->stream, X_dev, W, (int)dx, rank, blockcnt, ctx->cmp_X,
-                       ctx->cmp_idx, ctx->profile ? ctx->rows_live : nullptr);
+                       ctx->cmp_idx, ctx->profile ? ctx->rows_live : nullptr, ctx->live_hint);
+    ctx->hint_from = ctx;
     GPB_HIP(hipGetLastError());
     return 0;
 }
@@ -1120,6 +1124,7 @@ int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, doub
     for (int e = 0; e < E; ++e) {
         gpb_ctx* c = ctxs[e];
         const double* Xg = c0->cmp_X;
+        c->hint_from = c0;
         if (c->pmap_d_in > 0) {                        // this emulator's GPs see the PCA-reduced parameters
             if ((rc = gpb_param_map(c, c0->cmp_X, W, c->Xs))) { c0->err = c->err; return rc; }
             Xg = c->Xs;

@@ -577,8 +577,23 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
         // MFMAs per wave between barriers) from 3.75 tiles per CU on, 64x128 (32 MFMAs) and 64x64 (16) from 5 per
         // CU, else 64x32.  Fewer, larger tiles leave CUs idle behind the heaviest triangular row block; more,
         // smaller ones pay more barriers and operand traffic per MFMA.
-        const int64_t tiles128 = ctx->P * ((ctx->Np + 127) / 128) * (Wuse / 128);
-        const int64_t tiles64x128 = ctx->P * nI64 * (Wuse / 128), tiles64 = ctx->P * nI64 * (Wuse / 64);
+        // A compacted batch is launched for its upper bound W, but the tiles that exist are those of the rows inside
+        // the prior box.  Their number is only known on the device; the last compaction the device has FINISHED left
+        // its (live rows, batch rows) in pinned host memory (k_compact_gather), and that fraction — a few launches
+        // old, since the host enqueues ahead — sizes the tile counts of the rule.  Any shape gives the same bits, so a
+        // stale fraction costs time at worst.  (cfg 4 sharded 2-way: 1024-row batches with ~495 live rows ran 128x128
+        // tiles at 2.5 per CU, 436 us; with the rule fed the live count 64x128.)
+        int64_t Wsel = Wuse;
+        if (nrows_dev && ctx->tile_by_live && ctx->hint_from && ctx->hint_from->live_hint) {
+            const unsigned long long h = __atomic_load_n(ctx->hint_from->live_hint, __ATOMIC_RELAXED);
+            const int64_t cnt = (int64_t)(h & 0xffffffffull), of = (int64_t)(h >> 32);
+            if (of > 0 && cnt <= of) {
+                const int64_t est = (int64_t)((double)cnt / (double)of * (double)W * 1.03) + 8;
+                Wsel = est < 64 ? 64 : (est > Wuse ? Wuse : est);
+            }
+        }
+        const int64_t tiles128 = ctx->P * ((ctx->Np + 127) / 128) * ((Wsel + 127) / 128);
+        const int64_t tiles64x128 = ctx->P * nI64 * ((Wsel + 127) / 128), tiles64 = ctx->P * nI64 * ((Wsel + 63) / 64);
         int T = 64, TN = 32;
         if (tiles128 * 256 >= ctx->tile_switch * ctx->num_cu) T = TN = 128;
         else if (tiles64x128 * 256 >= ctx->mid_switch * ctx->num_cu) TN = 128;

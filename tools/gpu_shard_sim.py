@@ -5,7 +5,7 @@ does — and, with a one-rank RCCL communicator installed, still enqueues the tw
 (ncclAllGather on the kernels' stream: launch and protocol cost without a wire).  Also: the same share through the
 host-driven loop (Python enqueues every kernel), to show what the C loop removes.
 
-    python tools/gpu_shard_sim.py [R ...]          # default 1 2 4 8
+    python tools/gpu_shard_sim.py [R ...] [--c-only] [--cfg=5]         # default 1 2 4 8
 """
 import json
 import os
@@ -43,11 +43,21 @@ def main():
     from gpbayestools_hic_amd import synth
     from gpbayestools_hic_amd.sampler import StretchSampler
     from gpbayestools_hic_amd.workload import build_chain
-    chain, emu, info = build_chain(4)
+    cfg = 4
+    for a in sys.argv[1:]:
+        if a.startswith("--cfg="):
+            cfg = int(a[6:])
+    chain, emu, info = build_chain(cfg)
+    for a in sys.argv[1:]:
+        if a.startswith("--tune="):                  # e.g. --tune=tile_by_live:0
+            k, v = a[7:].split(":")
+            emu._engine_ready().tune(k, int(v))
+            print(json.dumps({"tune": {k: int(v)}}), flush=True)
     eng = emu._engine_ready()
     nw = 2 * info["W"]
     X0 = synth.walkers(nw, info["d"])
-    worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+    c_only = "--c-only" in sys.argv
+    worlds = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [1, 2, 4, 8]
     comm = False
     try:
         eng.dist_init(0, 1, eng.dist_uid())          # one-rank communicator: the collective is enqueued for real
@@ -55,13 +65,23 @@ def main():
     except Exception as e:                           # librccl missing: time without the collective and say so
         print(json.dumps({"warning": "no RCCL communicator: %s" % e}), flush=True)
     for world in worlds:
-        row = {"ranks_simulated": world, "walkers_per_rank_per_batch": nw // 2 // world, "collective_enqueued": comm and world > 1}
+        row = {"config": cfg, "walkers": nw, "ranks_simulated": world, "walkers_per_rank_per_batch": nw // 2 // world, "collective_enqueued": comm and world > 1}
         eng.tune("sim_ranks", world if world > 1 else 0)
         s = StretchSampler(chain, nw, seed=1)
         assert s._resident_engine()[0] is eng
         s.run(X0, 3, store=False, status=10 ** 9)
         row["c_loop_ms_per_step"] = round(timed(s), 4)
+        eng.profile(True)                                # a few more steps with the live-row counter and event timing on
+        s.run(None, 5, store=False, status=10 ** 9)
+        n_l, ms_l, units = eng.profile_read()
+        eng.profile(False)
+        P = info["P"]
+        row["rows_inside_box_fraction"] = round(units / (n_l * P * (nw // 2 // world)), 3)
+        row["k_predict_us_per_launch"] = round(ms_l / n_l * 1e3, 1)
         eng.tune("sim_ranks", 0)
+        if c_only:
+            print(json.dumps(row), flush=True)
+            continue
         s2 = StretchSampler(chain, nw, seed=1, sharding=FakeShard(world) if world > 1 else None)
         s2._resident_engine = lambda: None            # force the host-driven loop
         s2.run(X0, 3, store=False, status=10 ** 9)
