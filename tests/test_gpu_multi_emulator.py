@@ -65,3 +65,77 @@ def test_nine_emulator_chain_against_the_oracle(tmp_path):
     assert np.array_equal(s.chain[:, -1], Xf)                     # same decisions => same positions, bit for bit
     fin = np.isfinite(lp)
     assert relerr(s.lnprobability[:, -1][fin], lp[fin]) < 1e-10
+
+
+def test_mixed_chain_mapped_and_plain_emulators_and_argument_checks(tmp_path):
+    """a parameterTrafoPCA emulator (GPs over PCA-reduced parameters, src/emulator.py:492-551) and a plain one over the
+    same 20 model parameters in ONE chain: gpb_chain_logpost maps the gathered rows for the first and feeds them as
+    they are to the second; same bits as the per-emulator calls from Python.  Then the calls' argument checks."""
+    import ctypes
+    import torch
+    from conftest import golden
+    from gpbayestools_hic_amd import Chain, Emulator, GPEngine, StretchSampler, synth
+    from gpbayestools_hic_amd import _native as nat
+    g = golden("g7_param_pca.npz")
+    d = len(g["lo"])
+    tp, pf, ep = str(tmp_path / "t.pkl"), str(tmp_path / "p.txt"), str(tmp_path / "e.pkl")
+    synth.write_training_pickle(tp, g["X"], g["Y"], 0.01)
+    synth.write_parameter_file(pf, g["lo"], g["hi"])
+    mapped = Emulator(training_set_path=tp, parameter_file=pf, npc=int(g["npc"]), parameterTrafoPCA=True)
+    mapped.trainEmulator([True] * mapped.nev, thetas=g["thetas"])
+    X2 = synth.lhs(90, d, seed=9, lo=g["lo"], hi=g["hi"])
+    Y2 = synth.observables((X2 - g["lo"]) / (g["hi"] - g["lo"]), 24, seed=10)
+    tp2 = str(tmp_path / "t2.pkl")
+    synth.write_training_pickle(tp2, X2, Y2, 0.01)
+    plain = Emulator(training_set_path=tp2, parameter_file=pf, npc=5)
+    plain.trainEmulator([True] * plain.nev, thetas=synth.fixed_theta(d, 5, ell=2.0))
+    x0 = 0.5 * (g["lo"] + g["hi"])
+    yexp = np.concatenate([mapped.predict(x0[None], return_cov=False)[0], plain.predict(x0[None], return_cov=False)[0]])
+    synth.write_experiment_pickle(ep, yexp, 0.05 * np.abs(yexp))
+    chain = Chain(mcmc_path=str(tmp_path / "mcmc" / "c.pkl"), expdata_path=ep, model_parafile=pf)
+    chain.emuList = [mapped, plain]
+    X = g["lo"] + (g["hi"] - g["lo"]) * np.random.default_rng(5).uniform(-0.02, 1.02, (300, d))
+    one = chain.log_posterior(X)
+    ins = np.all((X > g["lo"]) & (X < g["hi"]), axis=1)
+    assert 0 < ins.sum() < 300 and np.array_equal(np.isfinite(one), ins)
+    chain.use_chain_call = False
+    assert np.array_equal(chain.log_posterior(X), one)
+    chain.use_chain_call = True
+    # and in the other order (the plain emulator's context then owns the compaction)
+    chain.emuList = [plain, mapped]
+    chain.expdata = np.concatenate([chain.expdata[:, -24:], chain.expdata[:, :-24]], axis=1)
+    n = chain.expdata_cov.shape[0]
+    perm = np.r_[n - 24:n, 0:n - 24]
+    chain.expdata_cov = chain.expdata_cov[np.ix_(perm, perm)]
+    swapped = chain.log_posterior(X)
+    assert np.array_equal(np.isfinite(swapped), ins)
+    assert np.allclose(swapped[ins], one[ins], rtol=1e-12, atol=0)      # the blocks are summed in the other order
+    s = StretchSampler(chain, 24, seed=2)
+    assert s._resident_engine()[2] == 2
+    s.run(x0 + 0.01 * (g["hi"] - g["lo"]) * np.random.default_rng(6).standard_normal((24, d)), 3, status=10)
+    assert np.isfinite(s.lnprobability).all()
+
+    # ---- argument checks of the chain calls
+    e1, e2 = plain._engine_ready(), mapped._engine_ready()
+    lib = e1.lib
+    arr = (ctypes.c_void_p * 2)(e1.h, e2.h)
+    Xd = torch.as_tensor(np.ascontiguousarray(X), device="cuda")
+    out = torch.empty(len(X), dtype=torch.float64, device="cuda")
+    lo, hi = chain._box(Xd.device)
+    call = lambda a, E, W=len(X): lib.gpb_chain_logpost(a, E, nat.ptr(Xd), W, nat.ptr(out), nat.ptr(lo), nat.ptr(hi),
+                                                        float("-inf"), 0.0)
+    assert call(arr, 2) == 0 and call(arr, 2, 0) == 0                  # an empty batch is a no-op
+    assert call(arr, 0) != 0 and call(None, 2) != 0 and call(arr, 65) != 0
+    assert call((ctypes.c_void_p * 2)(e1.h, None), 2) != 0             # a null context in the list
+    assert lib.gpb_chain_logpost(arr, 2, None, 5, nat.ptr(out), nat.ptr(lo), nat.ptr(hi), 0.0, 0.0) != 0
+    assert call(arr, 2, -1) != 0
+    other = GPEngine(0)                                                # fitted, but over 3 parameters and no likelihood
+    other.set_data(synth.lhs(64, 3), np.random.default_rng(0).standard_normal((2, 64)), "RBF", 0.1)
+    other.set_theta(synth.fixed_theta(3, 2))
+    other.factor()
+    bad = (ctypes.c_void_p * 2)(e1.h, other.h)
+    assert lib.gpb_chain_supported(bad, 2) == 0 and call(bad, 2) != 0
+    assert b"gpb_like_set" in lib.gpb_last_error(e1.h)
+    assert lib.gpb_chain_emcee_run(arr, 2, nat.ptr(Xd), nat.ptr(out), 7, 1, 1, 0, 2.0, 1, nat.ptr(lo), nat.ptr(hi),
+                                   float("-inf"), 0.0, None, None, None) != 0       # odd number of walkers
+    other.close()
