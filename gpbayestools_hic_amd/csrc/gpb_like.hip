@@ -798,21 +798,43 @@ __global__ __launch_bounds__(256) void k_compact_gather(const double* __restrict
                                                         double* __restrict__ Xc, int* __restrict__ cmp,
                                                         unsigned long long* __restrict__ rows_live,
                                                         unsigned long long* __restrict__ hint) {
-    __shared__ int s_base;
+    __shared__ int s_base, s_cnt;
     __shared__ int row_of[256];
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t w0 = (int64_t)blockIdx.x * 256, nrow = imin64(256, W - w0);
-    if (tid < 64) {                                    // fixed-order sum of the counts before this workgroup
+    int r;
+    if (blockcnt) {
+        if (tid < 64) {                                // fixed-order sum of the counts before this workgroup
+            int s = 0;
+            for (int b = lane; b < (int)blockIdx.x; b += 64) s += blockcnt[b];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) { s_base = s; s_cnt = blockcnt[blockIdx.x]; }
+        }
+        r = tid < nrow ? rank[w0 + tid] : -1;
+    } else {
+        // rank[] holds 0/1 flags (written by k_propose; batches of a few thousand rows): the live rows before this
+        // workgroup are counted from the flags themselves (integers: any order), the rank inside it by ballots
         int s = 0;
-        for (int b = lane; b < (int)blockIdx.x; b += 64) s += blockcnt[b];
+        for (int64_t w = tid; w < w0; w += 256) s += rank[w];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) s_base = s;
+        const bool in = tid < nrow && rank[w0 + tid] != 0;
+        const unsigned long long m = __ballot(in);
+        __syncthreads();                               // (wsum is free: first use)
+        if (lane == 0) { wsum[wave] = __popcll(m); row_of[wave] = s; }     // row_of[0..3] borrowed for the partial sums
+        __syncthreads();
+        int off = 0;
+        for (int i = 0; i < wave; ++i) off += wsum[i];
+        r = in ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+        const int b4 = row_of[0] + row_of[1] + row_of[2] + row_of[3], c4 = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();                               // everyone has read row_of[0..3] before it is reused below
+        if (tid == 0) { s_base = b4; s_cnt = c4; }
     }
-    const int r = tid < nrow ? rank[w0 + tid] : -1;
     if (r >= 0) row_of[r] = tid;
     __syncthreads();
-    const int base = s_base, cnt = blockcnt[blockIdx.x];
+    const int base = s_base, cnt = s_cnt;
     if (r >= 0) cmp[4 + base + r] = (int)(w0 + tid);
     for (int64_t e = tid; e < (int64_t)cnt * d; e += 256) {
         const int s = (int)(e / d), k = (int)(e % d);
@@ -829,7 +851,7 @@ __global__ __launch_bounds__(256) void k_compact_gather(const double* __restrict
 // X_dev [W][dx]: dx = the chain's number of parameters (the GP's d unless the emulator has a parameter map).  The
 // gathered rows land in ctx->cmp_X (grown on demand), indices and count in ctx->cmp_idx.
 int launch_compact(gpb_ctx* ctx, const double* X_dev, int64_t W, int64_t dx, const double* lo_dev, const double* hi_dev,
-                   double outside, double* ll_dev) {
+                   double outside, double* ll_dev, bool premarked) {
     if (W > ctx->Wcap || W >= (1ll << 31)) GPB_FAIL(GPB_E_STATE, "gpb: internal: compaction beyond the workspace");
     if (ctx->cmp_X_cap < ctx->Wcap * dx) {
         GPB_HIP(hipStreamSynchronize(ctx->stream));
@@ -843,11 +865,14 @@ int launch_compact(gpb_ctx* ctx, const double* X_dev, int64_t W, int64_t dx, con
     int* rank = ctx->cmp_idx + 4 + ctx->Wcap;          // [Wcap] ranks, then [Wcap / 256 + 1] workgroup counts
     int* blockcnt = rank + ctx->Wcap;
     const size_t sh = sizeof(double) * 256 * (size_t)(dx + 1);
-    if (sh > 64 * 1024)
+    if (sh > 64 * 1024 && !premarked)
         GPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_compact_mark), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    hipLaunchKernelGGL(k_compact_mark, dim3(nb), dim3(256), sh, ctx->stream, X_dev, W, (int)dx, lo_dev, hi_dev, outside,
-                       ll_dev, rank, blockcnt);
-    hipLaunchKernelGGL(k_compact_gather, dim3(nb), dim3(256), 0, ctx->stream, X_dev, W, (int)dx, rank, blockcnt, ctx->cmp_X,
+    // premarked: k_propose has left 0/1 flags in rank[] and `outside` in ll (see there)
+    if (!premarked)
+        hipLaunchKernelGGL(k_compact_mark, dim3(nb), dim3(256), sh, ctx->stream, X_dev, W, (int)dx, lo_dev, hi_dev, outside,
+                           ll_dev, rank, blockcnt);
+    hipLaunchKernelGGL(k_compact_gather, dim3(nb), dim3(256), 0, ctx->stream, X_dev, W, (int)dx, rank,
+                       premarked ? nullptr : blockcnt, ctx->cmp_X,
                        ctx->cmp_idx, ctx->profile ? ctx->rows_live : nullptr, ctx->live_hint);
     ctx->hint_from = ctx;
     GPB_HIP(hipGetLastError());
@@ -932,9 +957,15 @@ __device__ __forceinline__ SplitPerm make_perm(uint64_t seed, uint32_t step, int
     return SplitPerm{(uint32_t)n, (uint32_t)hb, k.x, k.y, (uint32_t)randomize};
 }
 
+// lo != nullptr (the C-driven loop over a compacted chain): the prior-box test of the rows [r0, r0 + chunk) — this
+// rank's rows of the batch — is taken here, on the proposal still in registers: flags[k - r0] = 1 inside / 0 outside
+// (strict inequalities, src/mcmc.py:275) and ll[k] = outside for the rows outside; k_compact_gather then ranks the
+// flags itself and k_compact_mark's launch is saved (7.6 of a sharded half-step's 166 us).
 __global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, int half, uint64_t seed,
                           uint32_t step, double a, double* __restrict__ q, double* __restrict__ factor, int hb,
-                          int randomize) {
+                          int randomize, const double* __restrict__ lo = nullptr, const double* __restrict__ hi = nullptr,
+                          double outside = 0.0, double* __restrict__ ll = nullptr, int* __restrict__ flags = nullptr,
+                          int64_t r0 = 0, int64_t chunk = 0) {
     // 32 lanes per walker (one parameter each): these kernels sit between the log-probability batches of a
     // step, so they are organised for latency, not for thread economy — every lane redoes the walker's draws
 #pragma clang fp contract(off)       // emcee's arithmetic rounds every product: no fused multiply-adds in here
@@ -952,8 +983,21 @@ __global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, 
     const int64_t j = (int64_t)(((uint64_t)r.z * (uint64_t)nhalf) >> 32);
     const double* s = pos + pi(2 * k + half) * d;
     const double* c = pos + pi(2 * j + (1 - half)) * d;
-    for (int t = t0; t < d; t += 32) q[k * d + t] = c[t] - (c[t] - s[t]) * zz;
+    int ok = 1;
+    for (int t = t0; t < d; t += 32) {
+        const double v = c[t] - (c[t] - s[t]) * zz;
+        q[k * d + t] = v;
+        if (lo) ok &= (int)(v > lo[t]) & (int)(v < hi[t]);
+    }
     if (t0 == 0) factor[k] = (d - 1.0) * log(zz);
+    if (lo) {                                          // wave-uniform; a walker's 32 lanes are one half of a wave
+        const unsigned long long out = __ballot(!ok);
+        const bool in = (((threadIdx.x & 32) ? (out >> 32) : out) & 0xffffffffull) == 0ull;
+        if (t0 == 0 && k >= r0 && k < r0 + chunk) {
+            flags[k - r0] = in ? 1 : 0;
+            if (!in) ll[k] = outside;
+        }
+    }
 }
 __global__ void k_accept(double* __restrict__ pos, double* __restrict__ lp, int64_t nhalf, int d, int half,
                          uint64_t seed, uint32_t step, const double* __restrict__ q,
@@ -1045,7 +1089,8 @@ extern "C" int gpb_stretch_propose(gpb_ctx* ctx, const double* pos_dev, int64_t 
         return GPB_E_ARG;
     const int64_t nh = nwalkers / 2;
     hipLaunchKernelGGL(k_propose, dim3((unsigned)((nh * 32 + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev, nh, (int)d,
-                       half, seed, (uint32_t)step, a, q_dev, factor_dev, half_bits(nwalkers), randomize_split ? 1 : 0);
+                       half, seed, (uint32_t)step, a, q_dev, factor_dev, half_bits(nwalkers), randomize_split ? 1 : 0,
+                       (const double*)nullptr, (const double*)nullptr, 0.0, (double*)nullptr, (int*)nullptr, (int64_t)0, (int64_t)0);
     GPB_HIP(hipGetLastError());
     return 0;
 }
@@ -1115,12 +1160,12 @@ int chain_check(gpb_ctx* const* ctxs, int E, const char* who) {
 
 // log-posterior of rows X[W][ndim] over all emulators, rows inside the box only (ctxs[0] owns the compaction)
 int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, double* ll_dev, const double* lo_dev,
-               const double* hi_dev, double outside, double inside_const) {
+               const double* hi_dev, double outside, double inside_const, bool premarked = false) {
     gpb_ctx* c0 = ctxs[0];
     int rc;
     for (int e = 0; e < E; ++e)
         if ((rc = ensure_wcap(ctxs[e], W))) { if (e) c0->err = ctxs[e]->err; return rc; }
-    if ((rc = launch_compact(c0, X_dev, W, chain_ndim(c0), lo_dev, hi_dev, outside, ll_dev))) return rc;
+    if ((rc = launch_compact(c0, X_dev, W, chain_ndim(c0), lo_dev, hi_dev, outside, ll_dev, premarked))) return rc;
     for (int e = 0; e < E; ++e) {
         gpb_ctx* c = ctxs[e];
         const double* Xg = c0->cmp_X;
@@ -1191,7 +1236,8 @@ extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev,
     if (sim) R = ctx->sim_ranks;
     if (nh % R) GPB_FAIL(GPB_E_ARG, "gpb_chain_emcee_run: half the ensemble must divide evenly over the ranks");
     const int64_t chunk = nh / R, r0 = sim ? 0 : rank * chunk;
-    if ((rc = ensure_wcap(ctx, chunk))) return rc;
+    for (int e = 0; e < E; ++e)                        // all workspaces now: the loop below holds pointers into them
+        if ((rc = ensure_wcap(ctxs[e], chunk))) { if (e) ctx->err = ctxs[e]->err; return rc; }
     if (ctx->mc_cap < nh * (d + 2)) {                  // proposal workspace: q[nh][d], factor[nh], lpq[nh]
         GPB_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->mc_ws) GPB_HIP(hipFree(ctx->mc_ws));
@@ -1205,12 +1251,20 @@ extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev,
     const int hb = half_bits(nwalkers), rnd = randomize_split ? 1 : 0;
     const dim3 g32((unsigned)((nh * 32 + 255) / 256));
     const bool fused = plain && loglike_fuses_finalize(ctx, chunk);
+    // the gather kernel counts the flags in front of each of its workgroups itself: fine for a rank's rows of an
+    // ensemble, quadratic for very large batches, which keep the marking kernel with its per-workgroup counts
+    const bool premark = !plain && ctx->premark && chunk <= 16384;
     if (sim) hipLaunchKernelGGL(k_fill, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, ctx->stream, lpq, nh, -INFINITY);
     for (int64_t n = 0; n < nsteps; ++n) {
         const uint32_t step = (uint32_t)(step0 + (uint64_t)n);
         for (int half = 0; half < 2; ++half) {
-            hipLaunchKernelGGL(k_propose, g32, dim3(256), 0, ctx->stream, pos_dev, nh, (int)d, half, seed, step, a, q, factor,
-                               hb, rnd);
+            if (premark)       // the proposal kernel also takes the prior-box test of this rank's rows
+                hipLaunchKernelGGL(k_propose, g32, dim3(256), 0, ctx->stream, pos_dev, nh, (int)d, half, seed, step, a, q,
+                                   factor, hb, rnd, lo_dev, hi_dev, outside_value, lpq, ctx->cmp_idx + 4 + ctx->Wcap, r0, chunk);
+            else
+                hipLaunchKernelGGL(k_propose, g32, dim3(256), 0, ctx->stream, pos_dev, nh, (int)d, half, seed, step, a, q,
+                                   factor, hb, rnd, (const double*)nullptr, (const double*)nullptr, 0.0, (double*)nullptr,
+                                   (int*)nullptr, (int64_t)0, (int64_t)0);
             // this rank's rows of the batch: [compaction to the rows inside the box,] per emulator K*^T + mean partials,
             // V = L^-1 K*^T with the fused sum of squares, block log-likelihood (+ prior box + constant)
             if (plain) {
@@ -1218,7 +1272,8 @@ extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev,
                 if ((rc = launch_loglike(ctx, chunk, lpq + r0, false, fused, q + r0 * d, lo_dev, hi_dev, outside_value,
                                          inside_const)))
                     return rc;
-            } else if ((rc = chain_rows(ctxs, E, q + r0 * d, chunk, lpq + r0, lo_dev, hi_dev, outside_value, inside_const))) {
+            } else if ((rc = chain_rows(ctxs, E, q + r0 * d, chunk, lpq + r0, lo_dev, hi_dev, outside_value, inside_const,
+                                        premark))) {
                 return rc;
             }
             if (sim ? ctx->comm != nullptr : R > 1)                      // in place, on this stream

@@ -66,7 +66,8 @@ int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
  * of a rank's share of a sharded step (tools/gpu_shard_sim.py); 27 = gpb_logpost / gpb_emcee_run evaluate the rows inside
  * the prior box only (1, default) or every row (0: A/B measurements; same results); 28 = the tile-shape rule of a
  * compacted batch counts the tiles of the LIVE rows, estimated from the last finished compaction (1, default), or of
- * the whole batch (0); same results either way. */
+ * the whole batch (0); same results either way; 29 = gpb_chain_emcee_run's proposal kernel also takes the prior-box test of
+ * the rank's rows (1, default; saves the marking kernel's launch) or leaves it to the compaction's own kernel (0). */
 int gpb_debug_tune(gpb_ctx* ctx, int key, int value);
 /* debug hook: per-tile placement and timing of the predict kernel.  capacity > 0 arms (and clears) a trace of
  * that many records, 0 disarms; read copies up to max_records records of 8 uint32 {HW_ID register, XCC_ID,
