@@ -752,7 +752,7 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 26: if (value < 0 || value > 64) return GPB_E_ARG; ctx->sim_ranks = value; break;
         case 27: if (value < 0 || value > 1) return GPB_E_ARG; ctx->compact = value; break;
         case 28: if (value < 0 || value > 1) return GPB_E_ARG; ctx->tile_by_live = value; break;
-        case 29: if (value < 0 || value > 1) return GPB_E_ARG; ctx->premark = value; break;
+        case 29: if (value < 0 || value > 2) return GPB_E_ARG; ctx->premark = value; break;
         default: return GPB_E_ARG;
     }
     return 0;

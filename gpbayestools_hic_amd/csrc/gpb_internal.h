@@ -66,7 +66,7 @@ struct gpb_ctx {
     unsigned long long* live_hint = nullptr;   // pinned host memory: (batch rows << 32) | live rows of the last finished compaction
     gpb_ctx* hint_from = nullptr;  // whose live_hint sizes this context's tile rule (the chain's first emulator compacts)
     int tile_by_live = 1;          // tune key 28
-    int premark = 1;               // tune key 29: the C-driven loop's proposal kernel takes the prior-box test
+    int premark = 2;               // tune key 29: the C-driven loop's proposal kernel takes the prior-box test (1) and gathers the rows inside (2)
     double* cmp_X = nullptr;       // the rows of the current batch inside the prior box, gathered in order [Wcap][chain ndim]
     int64_t cmp_X_cap = 0;
     int* cmp_idx = nullptr;        // compaction of a log-posterior batch to the rows inside the prior box: [0] = count, [4..] = row indices
@@ -197,7 +197,8 @@ int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, boo
 // ll[row] = outside for the rows outside the open box; the rows inside are gathered into ctx->cmp_X (in order), their
 // indices and count into ctx->cmp_idx
 int launch_compact(gpb_ctx* ctx, const double* X_dev, int64_t W, int64_t dx, const double* lo_dev, const double* hi_dev,
-                   double outside, double* ll_dev, bool premarked = false);
+                   double outside, double* ll_dev, int premarked = 0);
+int ensure_cmp_rows(gpb_ctx* ctx, int64_t dx);
 int launch_mvn(gpb_ctx* ctx, const double* dY_dev, const double* cov_dev, int64_t W, int64_t M, double* ll_dev);
 bool compaction_applies(const gpb_ctx* ctx);
 // test hooks

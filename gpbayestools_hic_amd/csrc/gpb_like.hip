@@ -851,16 +851,12 @@ __global__ __launch_bounds__(256) void k_compact_gather(const double* __restrict
 // X_dev [W][dx]: dx = the chain's number of parameters (the GP's d unless the emulator has a parameter map).  The
 // gathered rows land in ctx->cmp_X (grown on demand), indices and count in ctx->cmp_idx.
 int launch_compact(gpb_ctx* ctx, const double* X_dev, int64_t W, int64_t dx, const double* lo_dev, const double* hi_dev,
-                   double outside, double* ll_dev, bool premarked) {
+                   double outside, double* ll_dev, int premarked) {
     if (W > ctx->Wcap || W >= (1ll << 31)) GPB_FAIL(GPB_E_STATE, "gpb: internal: compaction beyond the workspace");
-    if (ctx->cmp_X_cap < ctx->Wcap * dx) {
-        GPB_HIP(hipStreamSynchronize(ctx->stream));
-        if (ctx->cmp_X) GPB_HIP(hipFree(ctx->cmp_X));
-        ctx->cmp_X = nullptr;
-        GPB_HIP(hipMalloc(&ctx->cmp_X, sizeof(double) * (size_t)(ctx->Wcap * dx)));
-        GPB_HIP(hipMemsetAsync(ctx->cmp_X, 0, sizeof(double) * (size_t)(ctx->Wcap * dx), ctx->stream));   // rows past the count are read (not used) by the upper-bound launches
-        ctx->cmp_X_cap = ctx->Wcap * dx;
-    }
+    int rc = ensure_cmp_rows(ctx, dx);
+    if (rc) return rc;
+    ctx->hint_from = ctx;
+    if (premarked == 2) return 0;                      // k_propose has gathered the rows as well
     const unsigned nb = (unsigned)((W + 255) / 256);
     int* rank = ctx->cmp_idx + 4 + ctx->Wcap;          // [Wcap] ranks, then [Wcap / 256 + 1] workgroup counts
     int* blockcnt = rank + ctx->Wcap;
@@ -874,8 +870,20 @@ int launch_compact(gpb_ctx* ctx, const double* X_dev, int64_t W, int64_t dx, con
     hipLaunchKernelGGL(k_compact_gather, dim3(nb), dim3(256), 0, ctx->stream, X_dev, W, (int)dx, rank,
                        premarked ? nullptr : blockcnt, ctx->cmp_X,
                        ctx->cmp_idx, ctx->profile ? ctx->rows_live : nullptr, ctx->live_hint);
-    ctx->hint_from = ctx;
     GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+// the buffer of gathered rows [Wcap][dx], grown on demand
+int ensure_cmp_rows(gpb_ctx* ctx, int64_t dx) {
+    if (ctx->cmp_X_cap < ctx->Wcap * dx) {
+        GPB_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->cmp_X) GPB_HIP(hipFree(ctx->cmp_X));
+        ctx->cmp_X = nullptr;
+        GPB_HIP(hipMalloc(&ctx->cmp_X, sizeof(double) * (size_t)(ctx->Wcap * dx)));
+        GPB_HIP(hipMemsetAsync(ctx->cmp_X, 0, sizeof(double) * (size_t)(ctx->Wcap * dx), ctx->stream));   // rows past the count are read (not used) by the upper-bound launches
+        ctx->cmp_X_cap = ctx->Wcap * dx;
+    }
     return 0;
 }
 
@@ -965,7 +973,7 @@ __global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, 
                           uint32_t step, double a, double* __restrict__ q, double* __restrict__ factor, int hb,
                           int randomize, const double* __restrict__ lo = nullptr, const double* __restrict__ hi = nullptr,
                           double outside = 0.0, double* __restrict__ ll = nullptr, int* __restrict__ flags = nullptr,
-                          int64_t r0 = 0, int64_t chunk = 0) {
+                          int64_t r0 = 0, int64_t chunk = 0, double* __restrict__ Xc = nullptr, int* __restrict__ cmp = nullptr) {
     // 32 lanes per walker (one parameter each): these kernels sit between the log-probability batches of a
     // step, so they are organised for latency, not for thread economy — every lane redoes the walker's draws
 #pragma clang fp contract(off)       // emcee's arithmetic rounds every product: no fused multiply-adds in here
@@ -984,18 +992,37 @@ __global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, 
     const double* s = pos + pi(2 * k + half) * d;
     const double* c = pos + pi(2 * j + (1 - half)) * d;
     int ok = 1;
+    double v2[2] = {0.0, 0.0};                         // d <= 64 (gpb_gp_set): at most two parameters per lane
+    int nv = 0;
     for (int t = t0; t < d; t += 32) {
         const double v = c[t] - (c[t] - s[t]) * zz;
         q[k * d + t] = v;
         if (lo) ok &= (int)(v > lo[t]) & (int)(v < hi[t]);
+        if (nv < 2) v2[nv] = v;
+        ++nv;
     }
     if (t0 == 0) factor[k] = (d - 1.0) * log(zz);
     if (lo) {                                          // wave-uniform; a walker's 32 lanes are one half of a wave
         const unsigned long long out = __ballot(!ok);
         const bool in = (((threadIdx.x & 32) ? (out >> 32) : out) & 0xffffffffull) == 0ull;
-        if (t0 == 0 && k >= r0 && k < r0 + chunk) {
-            flags[k - r0] = in ? 1 : 0;
+        const bool mine = k >= r0 && k < r0 + chunk;
+        if (t0 == 0 && mine) {
+            if (flags) flags[k - r0] = in ? 1 : 0;
             if (!in) ll[k] = outside;
+        }
+        if (Xc) {
+            // ... and gathers the rows inside the box itself: a slot from a counter (cmp[0], zeroed by k_accept), in
+            // whatever order the walkers arrive — a row's result does not depend on its place in the batch
+            int slot = -1;
+            if (t0 == 0 && mine && in) {
+                slot = atomicAdd(cmp, 1);
+                cmp[4 + slot] = (int)(k - r0);
+            }
+            slot = __shfl(slot, (int)(threadIdx.x & 32), 64);
+            if (slot >= 0) {
+                if (t0 < d) Xc[(int64_t)slot * d + t0] = v2[0];
+                if (t0 + 32 < d) Xc[(int64_t)slot * d + t0 + 32] = v2[1];
+            }
         }
     }
 }
@@ -1003,13 +1030,24 @@ __global__ void k_accept(double* __restrict__ pos, double* __restrict__ lp, int6
                          uint64_t seed, uint32_t step, const double* __restrict__ q,
                          const double* __restrict__ factor, const double* __restrict__ lpq,
                          long long* __restrict__ naccept, int hb, int randomize,
-                         long long* __restrict__ n_nan) {
+                         long long* __restrict__ n_nan, int* __restrict__ cmp = nullptr,
+                         unsigned long long* __restrict__ hint = nullptr, int64_t W_batch = 0,
+                         unsigned long long* __restrict__ rows_live = nullptr) {
     // 32 lanes per walker, all inside one wave: every lane takes the same decision from the OLD lp[idx]
     // (the load precedes lane 0's store in program order), then moves its own parameters
 #pragma clang fp contract(off)
     const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t k = gid >> 5;
     const int t0 = (int)(gid & 31);
+    if (cmp && gid == 0) {
+        // the batch's kernels are done with the count of rows inside the box (stream order): report it (tile-shape
+        // rule of the next launches, profile counter) and re-arm the counter for the next proposal kernel
+        const int cnt = cmp[0];
+        if (hint) __hip_atomic_store(hint, ((unsigned long long)W_batch << 32) | (unsigned long long)cnt, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_SYSTEM);
+        if (rows_live) atomicAdd(rows_live, (unsigned long long)cnt);
+        cmp[0] = 0;
+    }
     if (k >= nhalf) return;
     const SplitPerm pi = make_perm(seed, step, 2 * nhalf, hb, randomize);
     const U4 r = philox(seed, (uint32_t)k, step, (uint32_t)half, 1u);
@@ -1090,7 +1128,8 @@ extern "C" int gpb_stretch_propose(gpb_ctx* ctx, const double* pos_dev, int64_t 
     const int64_t nh = nwalkers / 2;
     hipLaunchKernelGGL(k_propose, dim3((unsigned)((nh * 32 + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev, nh, (int)d,
                        half, seed, (uint32_t)step, a, q_dev, factor_dev, half_bits(nwalkers), randomize_split ? 1 : 0,
-                       (const double*)nullptr, (const double*)nullptr, 0.0, (double*)nullptr, (int*)nullptr, (int64_t)0, (int64_t)0);
+                       (const double*)nullptr, (const double*)nullptr, 0.0, (double*)nullptr, (int*)nullptr, (int64_t)0, (int64_t)0,
+                       (double*)nullptr, (int*)nullptr);
     GPB_HIP(hipGetLastError());
     return 0;
 }
@@ -1105,7 +1144,8 @@ extern "C" int gpb_stretch_accept(gpb_ctx* ctx, double* pos_dev, double* lp_dev,
     hipLaunchKernelGGL(k_accept, dim3((unsigned)((nh * 32 + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev, lp_dev, nh,
                        (int)d, half, seed, (uint32_t)step, q_dev, factor_dev, lpq_dev,
                        reinterpret_cast<long long*>(naccept_dev), half_bits(nwalkers), randomize_split ? 1 : 0,
-                       reinterpret_cast<long long*>(ctx->n_nan));
+                       reinterpret_cast<long long*>(ctx->n_nan), (int*)nullptr, (unsigned long long*)nullptr, (int64_t)0,
+                       (unsigned long long*)nullptr);
     GPB_HIP(hipGetLastError());
     return 0;
 }
@@ -1160,7 +1200,7 @@ int chain_check(gpb_ctx* const* ctxs, int E, const char* who) {
 
 // log-posterior of rows X[W][ndim] over all emulators, rows inside the box only (ctxs[0] owns the compaction)
 int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, double* ll_dev, const double* lo_dev,
-               const double* hi_dev, double outside, double inside_const, bool premarked = false) {
+               const double* hi_dev, double outside, double inside_const, int premarked = 0) {
     gpb_ctx* c0 = ctxs[0];
     int rc;
     for (int e = 0; e < E; ++e)
@@ -1254,17 +1294,26 @@ extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev,
     // the gather kernel counts the flags in front of each of its workgroups itself: fine for a rank's rows of an
     // ensemble, quadratic for very large batches, which keep the marking kernel with its per-workgroup counts
     const bool premark = !plain && ctx->premark && chunk <= 16384;
+    // ... premark 2 (default): the proposal kernel gathers the rows as well (slots from a counter that the accept kernel
+    // re-arms), no compaction kernel at all; 1: flags only, k_compact_gather follows
+    const int pre = premark ? (ctx->premark >= 2 ? 2 : 1) : 0;
+    if (pre) {
+        if ((rc = ensure_cmp_rows(ctx, d))) return rc;
+        GPB_HIP(hipMemsetAsync(ctx->cmp_idx, 0, sizeof(int), ctx->stream));
+    }
     if (sim) hipLaunchKernelGGL(k_fill, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, ctx->stream, lpq, nh, -INFINITY);
     for (int64_t n = 0; n < nsteps; ++n) {
         const uint32_t step = (uint32_t)(step0 + (uint64_t)n);
         for (int half = 0; half < 2; ++half) {
             if (premark)       // the proposal kernel also takes the prior-box test of this rank's rows
                 hipLaunchKernelGGL(k_propose, g32, dim3(256), 0, ctx->stream, pos_dev, nh, (int)d, half, seed, step, a, q,
-                                   factor, hb, rnd, lo_dev, hi_dev, outside_value, lpq, ctx->cmp_idx + 4 + ctx->Wcap, r0, chunk);
+                                   factor, hb, rnd, lo_dev, hi_dev, outside_value, lpq,
+                                   pre == 1 ? ctx->cmp_idx + 4 + ctx->Wcap : (int*)nullptr, r0, chunk,
+                                   pre == 2 ? ctx->cmp_X : (double*)nullptr, pre == 2 ? ctx->cmp_idx : (int*)nullptr);
             else
                 hipLaunchKernelGGL(k_propose, g32, dim3(256), 0, ctx->stream, pos_dev, nh, (int)d, half, seed, step, a, q,
                                    factor, hb, rnd, (const double*)nullptr, (const double*)nullptr, 0.0, (double*)nullptr,
-                                   (int*)nullptr, (int64_t)0, (int64_t)0);
+                                   (int*)nullptr, (int64_t)0, (int64_t)0, (double*)nullptr, (int*)nullptr);
             // this rank's rows of the batch: [compaction to the rows inside the box,] per emulator K*^T + mean partials,
             // V = L^-1 K*^T with the fused sum of squares, block log-likelihood (+ prior box + constant)
             if (plain) {
@@ -1273,14 +1322,16 @@ extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev,
                                          inside_const)))
                     return rc;
             } else if ((rc = chain_rows(ctxs, E, q + r0 * d, chunk, lpq + r0, lo_dev, hi_dev, outside_value, inside_const,
-                                        premark))) {
+                                        pre))) {
                 return rc;
             }
             if (sim ? ctx->comm != nullptr : R > 1)                      // in place, on this stream
                 if ((rc = gpb_dist_allgather(ctx, lpq + r0, lpq, chunk))) return rc;
             hipLaunchKernelGGL(k_accept, g32, dim3(256), 0, ctx->stream, pos_dev, lp_dev, nh, (int)d, half, seed, step, q,
                                factor, lpq, reinterpret_cast<long long*>(naccept_dev), hb, rnd,
-                               reinterpret_cast<long long*>(ctx->n_nan));
+                               reinterpret_cast<long long*>(ctx->n_nan), pre == 2 ? ctx->cmp_idx : (int*)nullptr,
+                               pre == 2 ? ctx->live_hint : (unsigned long long*)nullptr, chunk,
+                               pre == 2 && ctx->profile ? ctx->rows_live : (unsigned long long*)nullptr);
         }
         if (chain_dev || lpchain_dev)
             hipLaunchKernelGGL(k_store_step, dim3((unsigned)((nwalkers * d + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev,

@@ -238,9 +238,10 @@ def test_nan_log_probability_raises_like_emcee(tmp_path):
 
 
 def test_box_test_in_the_proposal_kernel_equals_the_marking_kernel(tmp_path):
-    """the C-driven loop's proposal kernel takes the prior-box test itself and the gather kernel ranks its flags
-    (several 256-row workgroups, the last one partial, many proposals outside the box) — same ensemble as with the
-    compaction's own marking kernel and as the host-driven loop"""
+    """the C-driven loop's proposal kernel takes the prior-box test itself and gathers the rows inside the box (slots
+    from a counter, in whatever order the walkers arrive), or leaves 0/1 flags for the gather kernel to rank (several
+    256-row workgroups, the last one partial, many proposals outside the box) — same ensemble as with the compaction's
+    own kernels and as the host-driven loop"""
     from gpbayestools_hic_amd import StretchSampler, synth
     from gpbayestools_hic_amd.workload import build_chain
     chain, emu, info = build_chain(1, workdir=str(tmp_path))
@@ -248,15 +249,15 @@ def test_box_test_in_the_proposal_kernel_equals_the_marking_kernel(tmp_path):
     nw, d = 1364, info["d"]                                   # 682 rows per batch: 2 full workgroups + 170 rows
     X0 = synth.walkers(nw, d, seed=8)
     runs = {}
-    for tag, premark, host in (("premark", 1, False), ("mark_kernel", 0, False), ("host", 1, True)):
+    for tag, premark, host in (("premark", 2, False), ("flags_only", 1, False), ("mark_kernel", 0, False), ("host", 2, True)):
         eng.tune("premark", premark)
         s = StretchSampler(chain, nw, seed=31)
         if host:
             s._resident_engine = lambda: None
         s.run(X0, 4, status=100)
         runs[tag] = (s.chain, s.lnprobability, s.naccept.cpu().numpy())
-    eng.tune("premark", 1)
-    for tag in ("mark_kernel", "host"):
+    eng.tune("premark", 2)
+    for tag in ("flags_only", "mark_kernel", "host"):
         for a, b in zip(runs["premark"], runs[tag]):
             assert np.array_equal(a, b), tag
     lnp = runs["premark"][1]
