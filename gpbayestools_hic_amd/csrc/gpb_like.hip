@@ -959,6 +959,24 @@ struct SplitPerm {
         } while (x >= n);                      // cycle walking keeps it a bijection on [0, n)
         return (int64_t)x;
     }
+    // the inverse map: rounds backwards (a round takes (L, R) to (R, L ^ F(R))), cycle walking likewise
+    __device__ __forceinline__ int64_t inv(int64_t i) const {
+        if (!on) return i;
+        const uint32_t mask = (1u << hb) - 1u;
+        uint32_t x = (uint32_t)i;
+        do {
+            uint32_t L = x >> hb, R = x & mask;
+#pragma unroll
+            for (int r = 3; r >= 0; --r) {
+                const uint32_t F = mix32(L ^ (k0 + (uint32_t)r * 0x9E3779B9u)) ^ mix32(k1 + (uint32_t)r);
+                const uint32_t t = R ^ (F & mask);
+                R = L;
+                L = t;
+            }
+            x = (L << hb) | R;
+        } while (x >= n);
+        return (int64_t)x;
+    }
 };
 __device__ __forceinline__ SplitPerm make_perm(uint64_t seed, uint32_t step, int64_t n, int hb, int randomize) {
     const U4 k = philox(seed, 0xFFFFFFFFu, step, 0u, 7u);
@@ -1066,6 +1084,110 @@ __global__ void k_accept(double* __restrict__ pos, double* __restrict__ lp, int6
             lp[idx] = lpq_k;
             if (naccept) naccept[idx] += 1;
         }
+    }
+}
+
+// The accept of one half-step and the proposal of the next in ONE launch (gpb_chain_emcee_run): a proposal needs the
+// positions AFTER the pending accept, of its own walker and of its partner; instead of waiting for another kernel to
+// have moved them, a walker group looks both walkers up — the inverse split permutation tells whether a walker is in the
+// pending half and in which slot — and takes that slot's accept decision itself (same draws, same arithmetic as the
+// group that owns the slot).  Accepted walkers are read from the pending proposals q_a, all others from pos, which this
+// kernel writes for accepted walkers only: no read of a location another group writes.  lp is ping-ponged (lp_in is
+// read by every decision, lp_out written once per walker), q / factor / lpq alternate between two sets.
+struct PendingAccept {
+    const double *q, *factor, *lpq, *lp_in;
+    uint64_t seed;
+    uint32_t step;
+    int half;
+};
+__device__ __forceinline__ bool accept_decision(const PendingAccept& A, int64_t slot, int64_t idx, double& lpq_k) {
+#pragma clang fp contract(off)
+    const U4 r = philox(A.seed, (uint32_t)slot, A.step, (uint32_t)A.half, 1u);
+    const double u = u01(r.x, r.y);
+    lpq_k = A.lpq[slot];
+    const double diff = (A.factor[slot] + lpq_k) - A.lp_in[idx];
+    return diff > log(u);                                            // as k_accept
+}
+__global__ void k_accept_propose(double* __restrict__ pos, const double* __restrict__ lp_in, double* __restrict__ lp_out,
+                                 int64_t nhalf, int d, uint64_t seed, int hb, int randomize,
+                                 int half_a, uint32_t step_a, const double* __restrict__ q_a,
+                                 const double* __restrict__ factor_a, const double* __restrict__ lpq_a,
+                                 long long* __restrict__ naccept, long long* __restrict__ n_nan, int* __restrict__ cmp_prev,
+                                 unsigned long long* __restrict__ hint, int64_t W_batch,
+                                 unsigned long long* __restrict__ rows_live,
+                                 int half_p, uint32_t step_p, double a, double* __restrict__ q_p,
+                                 double* __restrict__ factor_p, const double* __restrict__ lo,
+                                 const double* __restrict__ hi, double outside, double* __restrict__ ll, int64_t r0,
+                                 int64_t chunk, double* __restrict__ Xc, int* __restrict__ cmp) {
+#pragma clang fp contract(off)
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t k = gid >> 5;
+    const int t0 = (int)(gid & 31);
+    if (gid == 0) {                                    // as k_accept: report and re-arm the finished batch's counter
+        const int cnt = cmp_prev[0];
+        if (hint) __hip_atomic_store(hint, ((unsigned long long)W_batch << 32) | (unsigned long long)cnt, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_SYSTEM);
+        if (rows_live) atomicAdd(rows_live, (unsigned long long)cnt);
+        cmp_prev[0] = 0;
+    }
+    if (k >= nhalf) return;
+    const SplitPerm pa = make_perm(seed, step_a, 2 * nhalf, hb, randomize);
+    const PendingAccept A{q_a, factor_a, lpq_a, lp_in, seed, step_a, half_a};
+    {   // ---- the accept of slot k (k_accept, with lp written to the other buffer)
+        const int64_t idx = pa(2 * k + half_a);
+        double lpq_k;
+        const bool take = accept_decision(A, k, idx, lpq_k);
+        if (n_nan && t0 == 0 && lpq_k != lpq_k) atomicAdd(reinterpret_cast<unsigned long long*>(n_nan), 1ull);
+        if (take)
+            for (int t = t0; t < d; t += 32) pos[idx * d + t] = q_a[k * d + t];
+        if (t0 == 0) {
+            lp_out[idx] = take ? lpq_k : lp_in[idx];
+            if (take && naccept) naccept[idx] += 1;
+            const int64_t other = pa(2 * k + (1 - half_a));           // the walker of the resting half with this slot
+            lp_out[other] = lp_in[other];
+        }
+    }
+    // ---- the proposal of slot k for (step_p, half_p): k_propose on the positions after the pending accept
+    const SplitPerm pp = make_perm(seed, step_p, 2 * nhalf, hb, randomize);
+    const U4 r = philox(seed, (uint32_t)k, step_p, (uint32_t)half_p, 0u);
+    const double u = u01(r.x, r.y);
+    const double zs = (a - 1.0) * u + 1.0;
+    const double zz = (zs * zs) / a;
+    const int64_t j = (int64_t)(((uint64_t)r.z * (uint64_t)nhalf) >> 32);
+    auto current = [&](int64_t w) -> const double* {
+        const int64_t y = pa.inv(w);
+        if ((int)(y & 1) == half_a) {
+            double unused;
+            if (accept_decision(A, y >> 1, w, unused)) return q_a + (y >> 1) * d;
+        }
+        return pos + w * d;
+    };
+    const double* s = current(pp(2 * k + half_p));
+    const double* c = current(pp(2 * j + (1 - half_p)));
+    int ok = 1;
+    double v2[2] = {0.0, 0.0};
+    int nv = 0;
+    for (int t = t0; t < d; t += 32) {
+        const double v = c[t] - (c[t] - s[t]) * zz;
+        q_p[k * d + t] = v;
+        ok &= (int)(v > lo[t]) & (int)(v < hi[t]);
+        if (nv < 2) v2[nv] = v;
+        ++nv;
+    }
+    if (t0 == 0) factor_p[k] = (d - 1.0) * log(zz);
+    const unsigned long long out = __ballot(!ok);
+    const bool in = (((threadIdx.x & 32) ? (out >> 32) : out) & 0xffffffffull) == 0ull;
+    const bool mine = k >= r0 && k < r0 + chunk;
+    if (t0 == 0 && mine && !in) ll[k] = outside;
+    int slot = -1;
+    if (t0 == 0 && mine && in) {
+        slot = atomicAdd(cmp, 1);
+        cmp[4 + slot] = (int)(k - r0);
+    }
+    slot = __shfl(slot, (int)(threadIdx.x & 32), 64);
+    if (slot >= 0) {
+        if (t0 < d) Xc[(int64_t)slot * d + t0] = v2[0];
+        if (t0 + 32 < d) Xc[(int64_t)slot * d + t0 + 32] = v2[1];
     }
 }
 
@@ -1200,12 +1322,13 @@ int chain_check(gpb_ctx* const* ctxs, int E, const char* who) {
 
 // log-posterior of rows X[W][ndim] over all emulators, rows inside the box only (ctxs[0] owns the compaction)
 int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, double* ll_dev, const double* lo_dev,
-               const double* hi_dev, double outside, double inside_const, int premarked = 0) {
+               const double* hi_dev, double outside, double inside_const, int premarked = 0, const int* cmpv = nullptr) {
     gpb_ctx* c0 = ctxs[0];
     int rc;
     for (int e = 0; e < E; ++e)
         if ((rc = ensure_wcap(ctxs[e], W))) { if (e) c0->err = ctxs[e]->err; return rc; }
     if ((rc = launch_compact(c0, X_dev, W, chain_ndim(c0), lo_dev, hi_dev, outside, ll_dev, premarked))) return rc;
+    if (!cmpv) cmpv = c0->cmp_idx;                     // (count, -, -, -, indices ...) of the rows inside the box
     for (int e = 0; e < E; ++e) {
         gpb_ctx* c = ctxs[e];
         const double* Xg = c0->cmp_X;
@@ -1215,9 +1338,9 @@ int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, doub
             Xg = c->Xs;
         }
         const bool fused = loglike_fuses_finalize(c, W);
-        if ((rc = launch_predict(c, Xg, W, true, !fused, c0->cmp_idx)) ||
+        if ((rc = launch_predict(c, Xg, W, true, !fused, cmpv)) ||
             (rc = launch_loglike(c, W, ll_dev, e > 0, fused, nullptr, nullptr, nullptr, outside,
-                                 e == E - 1 ? inside_const : 0.0, c0->cmp_idx))) {
+                                 e == E - 1 ? inside_const : 0.0, cmpv))) {
             c0->err = c->err;
             return rc;
         }
@@ -1278,16 +1401,19 @@ extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev,
     const int64_t chunk = nh / R, r0 = sim ? 0 : rank * chunk;
     for (int e = 0; e < E; ++e)                        // all workspaces now: the loop below holds pointers into them
         if ((rc = ensure_wcap(ctxs[e], chunk))) { if (e) ctx->err = ctxs[e]->err; return rc; }
-    if (ctx->mc_cap < nh * (d + 2)) {                  // proposal workspace: q[nh][d], factor[nh], lpq[nh]
+    // proposal workspace: two sets of q[nh][d], factor[nh], lpq[nh] (the fused accept + proposal kernel reads one set and
+    // writes the other) and a second log-probability vector [nwalkers]
+    if (ctx->mc_cap < 2 * nh * (d + 3)) {
         GPB_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->mc_ws) GPB_HIP(hipFree(ctx->mc_ws));
         ctx->mc_ws = nullptr;
-        GPB_HIP(hipMalloc(&ctx->mc_ws, sizeof(double) * (size_t)(nh * (d + 2))));
-        ctx->mc_cap = nh * (d + 2);
+        GPB_HIP(hipMalloc(&ctx->mc_ws, sizeof(double) * (size_t)(2 * nh * (d + 3))));
+        ctx->mc_cap = 2 * nh * (d + 3);
     }
-    double* q = ctx->mc_ws;
-    double* factor = q + nh * d;
-    double* lpq = factor + nh;
+    double* qs[2] = {ctx->mc_ws, ctx->mc_ws + nh * (d + 2)};
+    double* factors[2] = {qs[0] + nh * d, qs[1] + nh * d};
+    double* lpqs[2] = {factors[0] + nh, factors[1] + nh};
+    double* lp2 = ctx->mc_ws + 2 * nh * (d + 2);
     const int hb = half_bits(nwalkers), rnd = randomize_split ? 1 : 0;
     const dim3 g32((unsigned)((nh * 32 + 255) / 256));
     const bool fused = plain && loglike_fuses_finalize(ctx, chunk);
@@ -1297,47 +1423,71 @@ extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev,
     // ... premark 2 (default): the proposal kernel gathers the rows as well (slots from a counter that the accept kernel
     // re-arms), no compaction kernel at all; 1: flags only, k_compact_gather follows
     const int pre = premark ? (ctx->premark >= 2 ? 2 : 1) : 0;
+    // ... and with that, tune key 30 (default on): the accept of a half-step and the proposal of the next are one launch
+    const bool fuse_ap = pre == 2 && ctx->fuse_accept_propose;
     if (pre) {
         if ((rc = ensure_cmp_rows(ctx, d))) return rc;
-        GPB_HIP(hipMemsetAsync(ctx->cmp_idx, 0, sizeof(int), ctx->stream));
+        GPB_HIP(hipMemsetAsync(ctx->cmp_idx, 0, 2 * sizeof(int), ctx->stream));
     }
-    if (sim) hipLaunchKernelGGL(k_fill, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, ctx->stream, lpq, nh, -INFINITY);
-    for (int64_t n = 0; n < nsteps; ++n) {
+    if (sim) hipLaunchKernelGGL(k_fill, dim3((unsigned)((2 * nh * (d + 2) + 255) / 256)), dim3(256), 0, ctx->stream, ctx->mc_ws,
+                                2 * nh * (d + 2), -INFINITY);
+    unsigned long long* const live = pre == 2 && ctx->profile ? ctx->rows_live : (unsigned long long*)nullptr;
+    double* lp_cur = lp_dev;                           // fuse_ap: lp alternates between the caller's vector and lp2
+    double* lp_alt = lp2;
+    const int64_t nhalfsteps = 2 * nsteps;
+    for (int64_t g = 0; g < nhalfsteps; ++g) {
+        const int64_t n = g >> 1;
+        const int half = (int)(g & 1), b = fuse_ap ? (int)(g & 1) : 0;
         const uint32_t step = (uint32_t)(step0 + (uint64_t)n);
-        for (int half = 0; half < 2; ++half) {
+        double *q = qs[b], *factor = factors[b], *lpq = lpqs[b];
+        // the counter + index list of this batch's rows inside the box: two views one int apart, so that the fused kernel
+        // can re-arm the finished batch's counter while it fills the next one's
+        int* cmpv = ctx->cmp_idx ? ctx->cmp_idx + b : nullptr;
+        if (!fuse_ap || g == 0) {
             if (premark)       // the proposal kernel also takes the prior-box test of this rank's rows
                 hipLaunchKernelGGL(k_propose, g32, dim3(256), 0, ctx->stream, pos_dev, nh, (int)d, half, seed, step, a, q,
                                    factor, hb, rnd, lo_dev, hi_dev, outside_value, lpq,
                                    pre == 1 ? ctx->cmp_idx + 4 + ctx->Wcap : (int*)nullptr, r0, chunk,
-                                   pre == 2 ? ctx->cmp_X : (double*)nullptr, pre == 2 ? ctx->cmp_idx : (int*)nullptr);
+                                   pre == 2 ? ctx->cmp_X : (double*)nullptr, pre == 2 ? cmpv : (int*)nullptr);
             else
                 hipLaunchKernelGGL(k_propose, g32, dim3(256), 0, ctx->stream, pos_dev, nh, (int)d, half, seed, step, a, q,
                                    factor, hb, rnd, (const double*)nullptr, (const double*)nullptr, 0.0, (double*)nullptr,
                                    (int*)nullptr, (int64_t)0, (int64_t)0, (double*)nullptr, (int*)nullptr);
-            // this rank's rows of the batch: [compaction to the rows inside the box,] per emulator K*^T + mean partials,
-            // V = L^-1 K*^T with the fused sum of squares, block log-likelihood (+ prior box + constant)
-            if (plain) {
-                if ((rc = launch_predict(ctx, q + r0 * d, chunk, true, !fused))) return rc;
-                if ((rc = launch_loglike(ctx, chunk, lpq + r0, false, fused, q + r0 * d, lo_dev, hi_dev, outside_value,
-                                         inside_const)))
-                    return rc;
-            } else if ((rc = chain_rows(ctxs, E, q + r0 * d, chunk, lpq + r0, lo_dev, hi_dev, outside_value, inside_const,
-                                        pre))) {
-                return rc;
-            }
-            if (sim ? ctx->comm != nullptr : R > 1)                      // in place, on this stream
-                if ((rc = gpb_dist_allgather(ctx, lpq + r0, lpq, chunk))) return rc;
-            hipLaunchKernelGGL(k_accept, g32, dim3(256), 0, ctx->stream, pos_dev, lp_dev, nh, (int)d, half, seed, step, q,
-                               factor, lpq, reinterpret_cast<long long*>(naccept_dev), hb, rnd,
-                               reinterpret_cast<long long*>(ctx->n_nan), pre == 2 ? ctx->cmp_idx : (int*)nullptr,
-                               pre == 2 ? ctx->live_hint : (unsigned long long*)nullptr, chunk,
-                               pre == 2 && ctx->profile ? ctx->rows_live : (unsigned long long*)nullptr);
         }
-        if (chain_dev || lpchain_dev)
+        // this rank's rows of the batch: [compaction to the rows inside the box,] per emulator K*^T + mean partials,
+        // V = L^-1 K*^T with the fused sum of squares, block log-likelihood (+ prior box + constant)
+        if (plain) {
+            if ((rc = launch_predict(ctx, q + r0 * d, chunk, true, !fused))) return rc;
+            if ((rc = launch_loglike(ctx, chunk, lpq + r0, false, fused, q + r0 * d, lo_dev, hi_dev, outside_value,
+                                     inside_const)))
+                return rc;
+        } else if ((rc = chain_rows(ctxs, E, q + r0 * d, chunk, lpq + r0, lo_dev, hi_dev, outside_value, inside_const, pre,
+                                    cmpv))) {
+            return rc;
+        }
+        if (sim ? ctx->comm != nullptr : R > 1)                      // in place, on this stream
+            if ((rc = gpb_dist_allgather(ctx, lpq + r0, lpq, chunk))) return rc;
+        if (fuse_ap && g + 1 < nhalfsteps) {
+            const int64_t g1 = g + 1;
+            hipLaunchKernelGGL(k_accept_propose, g32, dim3(256), 0, ctx->stream, pos_dev, lp_cur, lp_alt, nh, (int)d, seed, hb,
+                               rnd, half, step, q, factor, lpq, reinterpret_cast<long long*>(naccept_dev),
+                               reinterpret_cast<long long*>(ctx->n_nan), cmpv, ctx->live_hint, chunk, live,
+                               (int)(g1 & 1), (uint32_t)(step0 + (uint64_t)(g1 >> 1)), a, qs[1 - b], factors[1 - b], lo_dev,
+                               hi_dev, outside_value, lpqs[1 - b], r0, chunk, ctx->cmp_X, ctx->cmp_idx + (1 - b));
+            double* sw = lp_cur; lp_cur = lp_alt; lp_alt = sw;
+        } else {
+            hipLaunchKernelGGL(k_accept, g32, dim3(256), 0, ctx->stream, pos_dev, lp_cur, nh, (int)d, half, seed, step, q,
+                               factor, lpq, reinterpret_cast<long long*>(naccept_dev), hb, rnd,
+                               reinterpret_cast<long long*>(ctx->n_nan), pre == 2 ? cmpv : (int*)nullptr,
+                               pre == 2 ? ctx->live_hint : (unsigned long long*)nullptr, chunk, live);
+        }
+        if (half == 1 && (chain_dev || lpchain_dev))
             hipLaunchKernelGGL(k_store_step, dim3((unsigned)((nwalkers * d + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev,
-                               lp_dev, chain_dev ? chain_dev + n * nwalkers * d : nullptr,
+                               lp_cur, chain_dev ? chain_dev + n * nwalkers * d : nullptr,
                                lpchain_dev ? lpchain_dev + n * nwalkers : nullptr, nwalkers, (int)d);
     }
+    if (lp_cur != lp_dev)
+        GPB_HIP(hipMemcpyAsync(lp_dev, lp_cur, sizeof(double) * (size_t)nwalkers, hipMemcpyDeviceToDevice, ctx->stream));
     GPB_HIP(hipGetLastError());
     return 0;
 }

@@ -241,7 +241,8 @@ def test_box_test_in_the_proposal_kernel_equals_the_marking_kernel(tmp_path):
     """the C-driven loop's proposal kernel takes the prior-box test itself and gathers the rows inside the box (slots
     from a counter, in whatever order the walkers arrive), or leaves 0/1 flags for the gather kernel to rank (several
     256-row workgroups, the last one partial, many proposals outside the box) — same ensemble as with the compaction's
-    own kernels and as the host-driven loop"""
+    own kernels and as the host-driven loop; likewise with the accept of a half-step and the proposal of the next in one
+    launch (every walker group re-derives the pending accept decisions of the two walkers it reads) or in two"""
     from gpbayestools_hic_amd import StretchSampler, synth
     from gpbayestools_hic_amd.workload import build_chain
     chain, emu, info = build_chain(1, workdir=str(tmp_path))
@@ -249,16 +250,29 @@ def test_box_test_in_the_proposal_kernel_equals_the_marking_kernel(tmp_path):
     nw, d = 1364, info["d"]                                   # 682 rows per batch: 2 full workgroups + 170 rows
     X0 = synth.walkers(nw, d, seed=8)
     runs = {}
-    for tag, premark, host in (("premark", 2, False), ("flags_only", 1, False), ("mark_kernel", 0, False), ("host", 2, True)):
+    for tag, premark, host in (("premark", 2, False), ("two_launches", 2, False), ("flags_only", 1, False),
+                               ("mark_kernel", 0, False), ("host", 2, True)):
         eng.tune("premark", premark)
-        s = StretchSampler(chain, nw, seed=31)
+        eng.tune("fuse_accept_propose", 0 if tag == "two_launches" else 1)
+        s = StretchSampler(chain, nw, seed=31, randomize_split=(tag != "flags_only"))
         if host:
             s._resident_engine = lambda: None
-        s.run(X0, 4, status=100)
+        s.run(X0, 3, status=100)
+        s.run(None, 2, status=1)                              # continued, one step per C call
         runs[tag] = (s.chain, s.lnprobability, s.naccept.cpu().numpy())
     eng.tune("premark", 2)
-    for tag in ("flags_only", "mark_kernel", "host"):
+    for tag in ("two_launches", "mark_kernel", "host"):
         for a, b in zip(runs["premark"], runs[tag]):
             assert np.array_equal(a, b), tag
+    # the unshuffled split (emcee's randomize_split=False: identity permutation) through the fused launch and the host loop
+    eng.tune("premark", 2)
+    s = StretchSampler(chain, nw, seed=31, randomize_split=False)
+    s._resident_engine = lambda: None
+    s.run(X0, 3, status=100)
+    s.run(None, 2, status=1)
+    assert np.array_equal(s.chain, runs["flags_only"][0]) and np.array_equal(s.lnprobability, runs["flags_only"][1])
+    s2 = StretchSampler(chain, nw, seed=31, randomize_split=False)
+    s2.run(X0, 5, status=100)
+    assert np.array_equal(s2.chain, s.chain) and np.array_equal(s2.naccept.cpu().numpy(), s.naccept.cpu().numpy())
     lnp = runs["premark"][1]
-    assert 0 < runs["premark"][2].sum() < 4 * nw and np.isfinite(lnp).all()
+    assert 0 < runs["premark"][2].sum() < 5 * nw and np.isfinite(lnp).all()
