@@ -88,12 +88,27 @@ __global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, i
         }
     };
     fetch(chunk0);
-    for (int e = threadIdx.x; e < WT * DPAD; e += 256) {
-        const int r = e / DPAD, k = e - r * DPAD;
-        const int64_t ww = w0 + r;
-        double v = (k < d && ww < W) ? Xs[ww * d + k] / ls[p * DPAD + k] : 0.0;
-        if (DOT && k < d && ww < W) v -= muS[p * DPAD + k];
-        sx[r][k] = v;
+    {   // all of a thread's loads first, then the divisions (one loop kept load -> divide -> store per element in order)
+        constexpr int NLD = (WT * DPAD + 255) / 256;
+        double xv[NLD], lv[NLD], mv[NLD];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int e = threadIdx.x + 256 * j, r = e / DPAD, k = e - r * DPAD;
+            const bool ok = e < WT * DPAD && k < d && w0 + r < W;
+            xv[j] = ok ? Xs[(w0 + r) * d + k] : 0.0;
+            lv[j] = ok ? ls[p * DPAD + k] : 1.0;
+            mv[j] = (DOT && ok) ? muS[p * DPAD + k] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int e = threadIdx.x + 256 * j, r = e / DPAD, k = e - r * DPAD;
+            if (e < WT * DPAD) {
+                const bool ok = k < d && w0 + r < W;
+                double v = ok ? xv[j] / lv[j] : 0.0;
+                if (DOT && ok) v -= mv[j];
+                sx[r][k] = v;
+            }
+        }
     }
     __syncthreads();
     double xs[WPL][DPAD];
