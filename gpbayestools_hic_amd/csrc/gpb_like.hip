@@ -1393,12 +1393,13 @@ extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev,
     const int64_t nh = nwalkers / 2, d = chain_ndim(ctx);
     int R = ctx->comm ? ctx->nranks : 1;
     const int rank = ctx->comm ? ctx->rank : 0;
-    // measurement hook (tune key 26): behave like ONE rank of `sim_ranks` on a single GPU — evaluate the first
-    // nh / sim_ranks rows of every batch only (the other rows keep -inf: rejected) and still issue the collective
+    // measurement / test hook (tune keys 26, 32): behave like rank `sim_rank` of `sim_ranks` on a single GPU — evaluate
+    // that rank's nh / sim_ranks rows of every batch only (the other rows keep -inf: rejected) and still issue the collective
     const bool sim = ctx->sim_ranks > 1 && R == 1;
     if (sim) R = ctx->sim_ranks;
     if (nh % R) GPB_FAIL(GPB_E_ARG, "gpb_chain_emcee_run: half the ensemble must divide evenly over the ranks");
-    const int64_t chunk = nh / R, r0 = sim ? 0 : rank * chunk;
+    if (sim && ctx->sim_rank >= R) GPB_FAIL(GPB_E_ARG, "gpb_chain_emcee_run: tune key 32 (simulated rank) must be below key 26 (ranks)");
+    const int64_t chunk = nh / R, r0 = (sim ? ctx->sim_rank : rank) * chunk;
     for (int e = 0; e < E; ++e)                        // all workspaces now: the loop below holds pointers into them
         if ((rc = ensure_wcap(ctxs[e], chunk))) { if (e) ctx->err = ctxs[e]->err; return rc; }
     // proposal workspace: two sets of q[nh][d], factor[nh], lpq[nh] (the fused accept + proposal kernel reads one set and

@@ -276,3 +276,45 @@ def test_box_test_in_the_proposal_kernel_equals_the_marking_kernel(tmp_path):
     assert np.array_equal(s2.chain, s.chain) and np.array_equal(s2.naccept.cpu().numpy(), s.naccept.cpu().numpy())
     lnp = runs["premark"][1]
     assert 0 < runs["premark"][2].sum() < 5 * nw and np.isfinite(lnp).all()
+
+
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_every_ranks_share_of_the_c_loop_equals_the_host_loop_on_those_rows(tmp_path, fuse):
+    """the sharded C loop evaluates rows [r chunk, (r + 1) chunk) of every batch (offsets into the proposals, the box
+    flags, the gathered rows and the log-probability vector); played for every rank r of 3 on one GPU (the rows of
+    the other ranks stay -inf: rejected) it walks the same ensemble as the host-driven loop whose log-probability
+    evaluates exactly those rows"""
+    import torch
+    from gpbayestools_hic_amd import StretchSampler, synth
+    from gpbayestools_hic_amd.workload import build_chain
+    chain, emu, info = build_chain(1, workdir=str(tmp_path))
+    eng = emu._engine_ready()
+    R, nw = 3, 1092                                           # 546 rows per batch, 182 per rank
+    chunk = nw // 2 // R
+    X0 = synth.walkers(nw, info["d"], seed=4)
+    eng.tune("fuse_accept_propose", fuse)
+    for r in range(R):
+        eng.tune("sim_ranks", R)
+        eng.tune("sim_rank", r)
+        c = StretchSampler(chain, nw, seed=17)
+        assert c._resident_engine() is not None
+        c.run(X0, 4, status=100)
+        eng.tune("sim_ranks", 0)
+        eng.tune("sim_rank", 0)
+
+        def rows_of_rank(X_dev, out, r=r):
+            out.fill_(float("-inf"))
+            if X_dev.shape[0] == nw:                          # the starting positions: every rank evaluates them all
+                return chain.log_prob_device(X_dev, out=out)
+            sl = slice(r * chunk, (r + 1) * chunk)
+            out[sl] = chain.log_prob_device(X_dev[sl].contiguous())
+            return out
+
+        h = StretchSampler(chain, nw, seed=17, logprob_device=rows_of_rank)
+        assert h._resident_engine() is None
+        h.run(X0, 4, status=100)
+        assert np.array_equal(c.chain, h.chain), r
+        assert np.array_equal(c.lnprobability, h.lnprobability) and np.array_equal(c.naccept.cpu().numpy(), h.naccept.cpu().numpy())
+        moved = np.any(c.chain[:, -1] != X0, axis=1)
+        assert 0 < moved.sum() < nw
+    eng.tune("fuse_accept_propose", 1)
