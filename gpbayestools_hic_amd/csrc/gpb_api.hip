@@ -728,7 +728,7 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 1: if (value < 1 || value > 8) return GPB_E_ARG; ctx->wgs_per_cu64 = value; break;
         case 2: if (value != 4 && value != 8) return GPB_E_ARG; ctx->predict_waves = value; break;
         case 3: if (value < 1 || value > 4) return GPB_E_ARG; ctx->wgs_per_cu128w8 = value; break;
-        case 4: if (value < 64 || value % 64) return GPB_E_ARG; ctx->chol_outer = value; break;
+        case 4: if (value < 0 || value % 64) return GPB_E_ARG; ctx->chol_outer = value; break;
         case 5: if (value < 0 || value > 3) return GPB_E_ARG; ctx->resident_order = value; break;
         case 6: if (value < 1 || value > 10) return GPB_E_ARG; ctx->wgs_per_cu32 = value; break;
         case 7: if (value < 0) return GPB_E_ARG; ctx->narrow_switch = value; break;

@@ -154,7 +154,11 @@ int ensure_lookahead(gpb_ctx* ctx, size_t nev) {
 // per panel; the far parts of consecutive panels are ordered by the side stream itself).
 int launch_potrf_fused(gpb_ctx* ctx) {
     const int64_t Np = ctx->Np, nb = Np / 64;
-    const int64_t NBO = ctx->chol_outer;               // outer panel width (multiple of 64)
+    // outer panel width (multiple of 64).  0 = by size (tools/gpu_fit_timing.py, 10 GPs): up to N = 2048 ONE panel — every
+    // step updates the whole trailing matrix with K = 64 and no panel-end SYRK is left (0.74 -> 0.70 ms at 1024, 2.41 ->
+    // 2.28 ms at 2048: the K = 64 updates' HBM traffic is cheaper than the extra launches and the tail of a SYRK); beyond
+    // that 256 with lookahead (N = 4096: 11.7 ms; 512: 12.0; 1024: 12.5; one panel: 13.8)
+    const int64_t NBO = ctx->chol_outer > 0 ? ctx->chol_outer : (Np <= 2048 ? Np : 256);
     const unsigned P = (unsigned)ctx->P;
     const int64_t npanel = (Np + NBO - 1) / NBO;
     const bool look = ctx->chol_lookahead && npanel > 2;

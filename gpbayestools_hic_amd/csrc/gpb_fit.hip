@@ -344,7 +344,7 @@ int launch_potrf(gpb_ctx* ctx) {
     if (ctx->chol_algo == 1) return launch_potrf_fused(ctx);
     // round 1's schedule (three launches per step), kept for A/B measurements: tune key 24 = 0
     const int64_t Np = ctx->Np, nb = Np / 64;
-    const int64_t NBO = ctx->chol_outer;               // outer panel width (multiple of 64)
+    const int64_t NBO = ctx->chol_outer > 0 ? ctx->chol_outer : 512;      // outer panel width (multiple of 64)
     GPB_HIP(hipMemsetAsync(ctx->info, 0, sizeof(int) * ctx->P, ctx->stream));
     for (int64_t kb = 0; kb < nb; ++kb) {
         const int64_t c0 = kb * 64, r0 = c0 + 64;

@@ -117,7 +117,7 @@ struct gpb_ctx {
     int static64 = 1;               // 64-row predict tiles always launch as k_predict_static
     int predict_waves = 4;          // waves per k_predict tile (4 or 8)
     unsigned* tile_counter = nullptr;   // 8 ticket queues (stride 16) + done counter [128]; re-armed by the kernel
-    int64_t chol_outer = 512;      // outer panel width of the two-level blocked Cholesky
+    int64_t chol_outer = 0;        // outer panel width of the two-level blocked Cholesky (0 = chosen by size, gpb_chol.hip)
     int chol_lookahead = 1;        // far part of a panel's trailing update on a side stream, under the next panel's chain
     hipStream_t side_stream = nullptr;
     std::vector<hipEvent_t> chol_events;

@@ -108,11 +108,19 @@ def test_cholesky_schedules_agree(N):
     P, d = 3, 12
     eng = GPEngine(0)
     X, Z, th = _setup(eng, N, d, P, "RBF", seed=3 * N)
+    auto_L, auto_X = eng.get("L"), eng.get("Linv")            # the default: panel width chosen by size
+    eng.tune("chol_outer", 512)
+    eng.factor()
     ref_L, ref_X = eng.get("L"), eng.get("Linv")
-    for algo, outer, look in ((1, 512, 1), (1, 512, 0), (0, 512, 0), (1, 512, 1), (1, 256, 1), (1, 256, 0), (1, 128, 1)):
+    assert np.max(np.abs(auto_L - ref_L)) < 1e-12 * np.max(np.abs(ref_L))
+    assert np.max(np.abs(auto_X - ref_X)) < 1e-11 * np.max(np.abs(ref_X))
+    for algo, outer, look in ((1, 512, 1), (1, 512, 0), (0, 512, 0), (1, 512, 1), (1, 256, 1), (1, 256, 0), (1, 128, 1),
+                              (1, 0, 1)):
         eng.tune("chol_algo", algo); eng.tune("chol_outer", outer); eng.tune("chol_lookahead", look)
         eng.factor()
         L, Xi = eng.get("L"), eng.get("Linv")
+        if outer == 0:
+            assert np.array_equal(L, auto_L) and np.array_equal(Xi, auto_X)       # run to run
         if outer == 512:
             assert np.array_equal(L, ref_L) and np.array_equal(Xi, ref_X), (algo, outer, look)
         else:
@@ -122,7 +130,7 @@ def test_cholesky_schedules_agree(N):
             L256 = L
         if outer == 256 and look == 0:
             assert np.array_equal(L, L256)
-    eng.tune("chol_algo", 1); eng.tune("chol_outer", 512); eng.tune("chol_lookahead", 1)
+    eng.tune("chol_algo", 1); eng.tune("chol_outer", 0); eng.tune("chol_lookahead", 1)
     K = O.kernel_train(X, th[0], O.KIND_RBF, 0.1)
     Lo = np.linalg.cholesky(K)
     assert np.max(np.abs(ref_L[0] - Lo)) < 1e-11 * np.max(np.abs(Lo))

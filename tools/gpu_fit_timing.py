@@ -35,7 +35,8 @@ def main():
         eng.set_theta(synth.fixed_theta(d, P))
         row = {"N": N, "P": P}
         Ls = {}
-        for algo, outer, look in ((0, 512, 0), (1, 512, 0), (1, 512, 1), (1, 256, 0), (1, 256, 1), (1, 1024, 0)):
+        for algo, outer, look in ((0, 512, 0), (1, 512, 0), (1, 512, 1), (1, 256, 0), (1, 256, 1), (1, 1024, 0), (1, 1024, 1),
+                                  (1, 128, 0), (1, 128, 1), (1, 2048, 0), (1, 512, 1), (1, 256, 1)):
             if outer > N:
                 continue
             eng.tune("chol_algo", algo)
@@ -43,6 +44,8 @@ def main():
             eng.tune("chol_lookahead", look)
             ms = timed(eng)
             tag = f"algo{algo}_outer{outer}_look{look}"
+            while tag + "_ms" in row:
+                tag += "_again"
             row[tag + "_ms"] = round(ms, 3)
             row[tag + "_chol_equiv_tflops"] = round(P * N ** 3 / 3 / (ms * 1e-3) / 1e12, 2)
             if N <= 2048 and outer == 512 and look == (1 if algo else 0):
