@@ -609,10 +609,24 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
         }
         const int64_t tiles128 = ctx->P * ((ctx->Np + 127) / 128) * ((Wsel + 127) / 128);
         const int64_t tiles64x128 = ctx->P * nI64 * ((Wsel + 127) / 128), tiles64 = ctx->P * nI64 * ((Wsel + 63) / 64);
+        // Compacted batches have their own switch points (tools/gpu_shard_sim.py --walkers=.. --tune=force_tile:..,
+        // profiles/r02_tile_shape_sweep_compacted.txt, cfg 4 at 190 .. 2060 live rows): the larger shape pays later —
+        // 64x32 up to 9.4 tiles of 64x64 per CU (5), 64x64 up to 4.5 of 64x128 (5), 64x128 up to 12 of 128x128 (3.75).
+        const bool cmpd = nrows_dev != nullptr && ctx->tile_by_live;
+        const int64_t sw128 = cmpd ? ctx->tile_switch_c : ctx->tile_switch, swmid = cmpd ? ctx->mid_switch_c : ctx->mid_switch,
+                      swnarrow = cmpd ? ctx->narrow_switch_c : ctx->narrow_switch;
         int T = 64, TN = 32;
-        if (tiles128 * 256 >= ctx->tile_switch * ctx->num_cu) T = TN = 128;
-        else if (tiles64x128 * 256 >= ctx->mid_switch * ctx->num_cu) TN = 128;
-        else if (tiles64 * 256 >= ctx->narrow_switch * ctx->num_cu) TN = 64;
+        if (cmpd) {
+            // ... counted in fractions of a walker tile: the estimate wanders by a few rows from launch to launch, and
+            // a whole-tile count made a rank's ~495 live rows flip between 4 and 5 tiles of 128, i.e. between two shapes
+            const double f128 = (double)(ctx->P * ((ctx->Np + 127) / 128)) * (double)Wsel / 128.0 * 256.0 / ctx->num_cu;
+            const double f64 = (double)(ctx->P * nI64) * (double)Wsel / 64.0 * 256.0 / ctx->num_cu;
+            if (f128 >= (double)sw128) T = TN = 128;
+            else if (f64 * 0.5 >= (double)swmid) TN = 128;
+            else if (f64 >= (double)swnarrow) TN = 64;
+        } else if (tiles128 * 256 >= sw128 * ctx->num_cu) T = TN = 128;
+        else if (tiles64x128 * 256 >= swmid * ctx->num_cu) TN = 128;
+        else if (tiles64 * 256 >= swnarrow * ctx->num_cu) TN = 64;
         if (ctx->force_tile == 64 || ctx->force_tile == 128) T = TN = ctx->force_tile;
         if (ctx->force_tile == 32) { T = 64; TN = 32; }
         if (ctx->force_tile == 65) { T = 64; TN = 128; }        // 64 rows x 128 walkers

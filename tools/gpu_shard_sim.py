@@ -51,10 +51,16 @@ def main():
     for a in sys.argv[1:]:
         if a.startswith("--tune="):                  # e.g. --tune=tile_by_live:0
             k, v = a[7:].split(":")
-            emu._engine_ready().tune(k, int(v))
+            if k == "force_tile":                    # 0 = rule, 32 = 64x32, 64 = 64x64, 65 = 64x128, 128 = 128x128
+                emu._engine_ready().force_tile(int(v))
+            else:
+                emu._engine_ready().tune(k, int(v))
             print(json.dumps({"tune": {k: int(v)}}), flush=True)
     eng = emu._engine_ready()
     nw = 2 * info["W"]
+    for a in sys.argv[1:]:
+        if a.startswith("--walkers="):
+            nw = int(a[10:])
     X0 = synth.walkers(nw, info["d"])
     c_only = "--c-only" in sys.argv
     worlds = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [1, 2, 4, 8]
