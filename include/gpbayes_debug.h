@@ -42,7 +42,7 @@ int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
  * (-1 auto, 0 by walker tile, 1 by row block, 2 by GP, 3 by (GP, four row blocks) super-block: least
  * fabric traffic); 1 = persistent 64-tile workgroups per CU;
  * 2 = waves per tile (4 or 8); 3 = persistent workgroups per CU of the 128-tile 8-wave variant;
- * 4 = outer panel width of the blocked Cholesky; 5 = tile order when every predict tile has its own
+ * 4 = outer panel width of the blocked Cholesky (0, default: by size — one panel up to N = 2048, 256 beyond); 5 = tile order when every predict tile has its own
  * co-resident workgroup (0 ticket queues, 1 sorted, 2 snake over the CUs, 3 snake of pairs);
  * 6 = persistent 64x32-tile workgroups per CU;
  * 7 = 64x64 predict tiles when at least this many of them exist per 256 CUs, else 64x32; 8 = largest batch whose block log-likelihood
