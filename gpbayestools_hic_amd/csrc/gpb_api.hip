@@ -137,7 +137,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     dev_free(&ctx->tile_trace);
     dev_free(&ctx->A); dev_free(&ctx->mu); dev_free(&ctx->scale); dev_free(&ctx->C0); dev_free(&ctx->yexp);
     dev_free(&ctx->Cexp); dev_free(&ctx->mvn_ws); dev_free(&ctx->notpd); dev_free(&ctx->tile_counter);
-    dev_free(&ctx->n_nan); dev_free(&ctx->mc_ws); dev_free(&ctx->rows_live); dev_free(&ctx->cmp_idx); dev_free(&ctx->cmp_X);
+    dev_free(&ctx->n_nan); dev_free(&ctx->mc_ws); dev_free(&ctx->bal_ws); dev_free(&ctx->rows_live); dev_free(&ctx->cmp_idx); dev_free(&ctx->cmp_X);
     if (ctx->live_hint) (void)hipHostFree(ctx->live_hint);
     for (hipEvent_t e : ctx->chol_events) (void)hipEventDestroy(e);
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
@@ -755,6 +755,7 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 29: if (value < 0 || value > 2) return GPB_E_ARG; ctx->premark = value; break;
         case 30: if (value < 0 || value > 1) return GPB_E_ARG; ctx->fuse_accept_propose = value; break;
         case 32: if (value < 0 || value > 63) return GPB_E_ARG; ctx->sim_rank = value; break;
+        case 36: if (value < 0 || value > 2) return GPB_E_ARG; ctx->balance_shards = value; break;
         case 33: if (value < 0) return GPB_E_ARG; ctx->tile_switch_c = value; break;
         case 34: if (value < 0) return GPB_E_ARG; ctx->mid_switch_c = value; break;
         case 35: if (value < 0) return GPB_E_ARG; ctx->narrow_switch_c = value; break;

@@ -66,6 +66,9 @@ struct gpb_ctx {
     unsigned long long* live_hint = nullptr;   // pinned host memory: (batch rows << 32) | live rows of the last finished compaction
     gpb_ctx* hint_from = nullptr;  // whose live_hint sizes this context's tile rule (the chain's first emulator compacts)
     int fuse_accept_propose = 1;   // tune key 30: accept of a half-step + proposal of the next in one launch (needs premark 2)
+    int balance_shards = 1;        // tune key 36: sharded C loop takes equal slices of the ordered live-row list
+    int* bal_ws = nullptr;         // its flags / ranks / scatter lists
+    int64_t bal_cap = 0;
     int sim_rank = 0;              // tune key 32: which rank of sim_ranks the measurement hook plays
     int tile_by_live = 1;          // tune key 28
     int premark = 2;               // tune key 29: the C-driven loop's proposal kernel takes the prior-box test (1) and gathers the rows inside (2)

@@ -1026,7 +1026,7 @@ __global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, 
         const bool mine = k >= r0 && k < r0 + chunk;
         if (t0 == 0 && mine) {
             if (flags) flags[k - r0] = in ? 1 : 0;
-            if (!in) ll[k] = outside;
+            if (!in && ll) ll[k] = outside;
         }
         if (Xc) {
             // ... and gathers the rows inside the box itself: a slot from a counter (cmp[0], zeroed by k_accept), in
@@ -1044,13 +1044,33 @@ __global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, 
         }
     }
 }
+// Where the accept step finds a proposal's log-probability.  Plain: lpq[slot].  Balanced sharding (see
+// k_balance_gather): lpq is the all-gathered array of the ranks' padded slices, a proposal inside the box is found through
+// its position g in the ordered list of all live rows — slice g / per, entry g % per — and one outside the box has
+// `outside` without a memory access.
+struct LpSource {
+    const double* lpq;
+    const int* rank_of;                // null: plain
+    const int* meta;                   // [0] = live rows in the whole batch, [1] = rows per slice
+    int64_t chunk;                     // slice stride in lpq
+    double outside;
+    __device__ __forceinline__ double at(int64_t slot) const {
+        if (!rank_of) return lpq[slot];
+        const int g = rank_of[slot];
+        if (g < 0) return outside;
+        const int per = meta[1];
+        return lpq[(int64_t)(g / per) * chunk + (g % per)];
+    }
+};
+
 __global__ void k_accept(double* __restrict__ pos, double* __restrict__ lp, int64_t nhalf, int d, int half,
                          uint64_t seed, uint32_t step, const double* __restrict__ q,
                          const double* __restrict__ factor, const double* __restrict__ lpq,
                          long long* __restrict__ naccept, int hb, int randomize,
                          long long* __restrict__ n_nan, int* __restrict__ cmp = nullptr,
                          unsigned long long* __restrict__ hint = nullptr, int64_t W_batch = 0,
-                         unsigned long long* __restrict__ rows_live = nullptr) {
+                         unsigned long long* __restrict__ rows_live = nullptr, const int* __restrict__ rank_of = nullptr,
+                         const int* __restrict__ meta = nullptr, int64_t chunk = 0, double outside = 0.0) {
     // 32 lanes per walker, all inside one wave: every lane takes the same decision from the OLD lp[idx]
     // (the load precedes lane 0's store in program order), then moves its own parameters
 #pragma clang fp contract(off)
@@ -1071,7 +1091,7 @@ __global__ void k_accept(double* __restrict__ pos, double* __restrict__ lp, int6
     const U4 r = philox(seed, (uint32_t)k, step, (uint32_t)half, 1u);
     const double u = u01(r.x, r.y);
     const int64_t idx = pi(2 * k + half);
-    const double lpq_k = lpq[k];
+    const double lpq_k = LpSource{lpq, rank_of, meta, chunk, outside}.at(k);
     // emcee raises "Probability function returned NaN" at the step it happens (emcee/ensemble.py compute_log_prob);
     // here the proposal is rejected (NaN compares false) and counted, and the host raises at its next check
     if (n_nan && t0 == 0 && lpq_k != lpq_k) atomicAdd(reinterpret_cast<unsigned long long*>(n_nan), 1ull);
@@ -1095,7 +1115,8 @@ __global__ void k_accept(double* __restrict__ pos, double* __restrict__ lp, int6
 // kernel writes for accepted walkers only: no read of a location another group writes.  lp is ping-ponged (lp_in is
 // read by every decision, lp_out written once per walker), q / factor / lpq alternate between two sets.
 struct PendingAccept {
-    const double *q, *factor, *lpq, *lp_in;
+    const double *q, *factor, *lp_in;
+    LpSource lpq;
     uint64_t seed;
     uint32_t step;
     int half;
@@ -1104,7 +1125,7 @@ __device__ __forceinline__ bool accept_decision(const PendingAccept& A, int64_t 
 #pragma clang fp contract(off)
     const U4 r = philox(A.seed, (uint32_t)slot, A.step, (uint32_t)A.half, 1u);
     const double u = u01(r.x, r.y);
-    lpq_k = A.lpq[slot];
+    lpq_k = A.lpq.at(slot);
     const double diff = (A.factor[slot] + lpq_k) - A.lp_in[idx];
     return diff > log(u);                                            // as k_accept
 }
@@ -1118,7 +1139,9 @@ __global__ void k_accept_propose(double* __restrict__ pos, const double* __restr
                                  int half_p, uint32_t step_p, double a, double* __restrict__ q_p,
                                  double* __restrict__ factor_p, const double* __restrict__ lo,
                                  const double* __restrict__ hi, double outside, double* __restrict__ ll, int64_t r0,
-                                 int64_t chunk, double* __restrict__ Xc, int* __restrict__ cmp) {
+                                 int64_t chunk, double* __restrict__ Xc, int* __restrict__ cmp,
+                                 const int* __restrict__ rank_of_a, const int* __restrict__ meta_a, int64_t chunk_a,
+                                 int* __restrict__ flags_p) {
 #pragma clang fp contract(off)
     const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t k = gid >> 5;
@@ -1132,7 +1155,7 @@ __global__ void k_accept_propose(double* __restrict__ pos, const double* __restr
     }
     if (k >= nhalf) return;
     const SplitPerm pa = make_perm(seed, step_a, 2 * nhalf, hb, randomize);
-    const PendingAccept A{q_a, factor_a, lpq_a, lp_in, seed, step_a, half_a};
+    const PendingAccept A{q_a, factor_a, lp_in, LpSource{lpq_a, rank_of_a, meta_a, chunk_a, outside}, seed, step_a, half_a};
     {   // ---- the accept of slot k (k_accept, with lp written to the other buffer)
         const int64_t idx = pa(2 * k + half_a);
         double lpq_k;
@@ -1177,6 +1200,10 @@ __global__ void k_accept_propose(double* __restrict__ pos, const double* __restr
     if (t0 == 0) factor_p[k] = (d - 1.0) * log(zz);
     const unsigned long long out = __ballot(!ok);
     const bool in = (((threadIdx.x & 32) ? (out >> 32) : out) & 0xffffffffull) == 0ull;
+    if (flags_p) {                                     // balanced sharding: the flag of EVERY row, k_balance_gather does the rest
+        if (t0 == 0) flags_p[k] = in ? 1 : 0;
+        return;
+    }
     const bool mine = k >= r0 && k < r0 + chunk;
     if (t0 == 0 && mine && !in) ll[k] = outside;
     int slot = -1;
@@ -1188,6 +1215,56 @@ __global__ void k_accept_propose(double* __restrict__ pos, const double* __restr
     if (slot >= 0) {
         if (t0 < d) Xc[(int64_t)slot * d + t0] = v2[0];
         if (t0 + 32 < d) Xc[(int64_t)slot * d + t0 + 32] = v2[1];
+    }
+}
+
+// Balanced sharding of a batch over the ranks (gpb_chain_emcee_run with a communicator).  A rank's contiguous share of
+// the proposals holds a varying number of rows inside the prior box (256 proposals: 120 +- 8), and the step waits for the
+// rank with the most — which, more often than not, needs one walker tile more than the others.  Every rank knows all
+// proposals, so every rank ranks ALL live rows in order here (flags from the proposal kernel; counts of integers: any
+// order) and takes the `r`-th of R equal slices of that list: rows with rank g in [r per, (r + 1) per), per =
+// ceil(live / R), gathered into Xc.  The slices are padded to the collective's fixed size (per <= nhalf / R), so the
+// all-gather is the one of the contiguous scheme; the accept kernels find a live row's value through rank_of (LpSource).
+//   flags[nhalf] in; rank_of[nhalf] out (-1 outside the box); meta = {live, per}; cmp[0] = rows of this rank's slice,
+//   cmp[4 + i] = i (the likelihood kernel's scatter list: results land densely in the send buffer)
+__global__ __launch_bounds__(256) void k_balance_gather(const double* __restrict__ q, int64_t nhalf, int d,
+                                                        const int* __restrict__ flags, int* __restrict__ rank_of,
+                                                        int R, int r, double* __restrict__ Xc, int* __restrict__ cmp,
+                                                        int* __restrict__ meta) {
+    __shared__ int wsum[4], wbase[4], wtot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t w0 = (int64_t)blockIdx.x * 256;
+    int before = 0, total = 0;
+    for (int64_t w = tid; w < nhalf; w += 256) {
+        const int f = flags[w];
+        total += f;
+        if (w < w0) before += f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        before += __shfl_xor(before, o);
+        total += __shfl_xor(total, o);
+    }
+    const bool in = w0 + tid < nhalf && flags[w0 + tid] != 0;
+    const unsigned long long m = __ballot(in);
+    if (lane == 0) { wsum[wave] = __popcll(m); wbase[wave] = before; wtot[wave] = total; }
+    __syncthreads();
+    int off = (wbase[0] + wbase[1]) + (wbase[2] + wbase[3]);
+    const int live = (wtot[0] + wtot[1]) + (wtot[2] + wtot[3]);
+    for (int i = 0; i < wave; ++i) off += wsum[i];
+    const int g = in ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+    const int per = live > 0 ? (live + R - 1) / R : 1;
+    const int lo = r * per, hi = min(lo + per, live);
+    if (w0 + tid < nhalf) rank_of[w0 + tid] = g;
+    if (g >= lo && g < hi) {
+        const int64_t src = (w0 + tid) * d, dst = (int64_t)(g - lo) * d;
+        for (int k = 0; k < d; ++k) Xc[dst + k] = q[src + k];
+        cmp[4 + (g - lo)] = g - lo;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        cmp[0] = hi > lo ? hi - lo : 0;
+        meta[0] = live;
+        meta[1] = per;
     }
 }
 
@@ -1426,6 +1503,33 @@ extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev,
     const int pre = premark ? (ctx->premark >= 2 ? 2 : 1) : 0;
     // ... and with that, tune key 30 (default on): the accept of a half-step and the proposal of the next are one launch
     const bool fuse_ap = pre == 2 && ctx->fuse_accept_propose;
+    // sharded (or playing one rank of several): equal slices of the ordered list of ALL live rows instead of the live rows
+    // of a contiguous share (k_balance_gather; tune key 36)
+    // Worth its extra launch (k_balance_gather + the rank look-ups of the accept step: +11 us per half-step, measured) only
+    // where the ranks' live counts straddle a walker-tile boundary often: 256 proposals per rank hold 120 +- 8 live rows, so
+    // at 8 ranks three half-steps in four have a rank with a fifth 64x32 tile (+23 us, measured per tile); at 2 and 4 ranks
+    // the contiguous shares rarely differ by a tile.  1 = from 8 ranks on (default), 2 = always, 0 = never.
+    const bool balanced = pre == 2 && R > 1 && nh <= 16384 &&
+                          (ctx->balance_shards == 2 || (ctx->balance_shards == 1 && R >= 8));
+    int *bal_flags[2] = {nullptr, nullptr}, *bal_rank[2] = {nullptr, nullptr}, *bal_cmp[2] = {nullptr, nullptr},
+        *bal_meta[2] = {nullptr, nullptr};
+    if (balanced) {
+        const int64_t need = 4 * nh + 2 * (4 + chunk) + 16;
+        if (ctx->bal_cap < need) {
+            GPB_HIP(hipStreamSynchronize(ctx->stream));
+            if (ctx->bal_ws) GPB_HIP(hipFree(ctx->bal_ws));
+            ctx->bal_ws = nullptr;
+            GPB_HIP(hipMalloc(&ctx->bal_ws, sizeof(int) * (size_t)need));
+            ctx->bal_cap = need;
+        }
+        GPB_HIP(hipMemsetAsync(ctx->bal_ws, 0, sizeof(int) * (size_t)need, ctx->stream));
+        for (int b = 0; b < 2; ++b) {
+            bal_flags[b] = ctx->bal_ws + b * nh;
+            bal_rank[b] = ctx->bal_ws + 2 * nh + b * nh;
+            bal_cmp[b] = ctx->bal_ws + 4 * nh + b * (4 + chunk);
+            bal_meta[b] = ctx->bal_ws + 4 * nh + 2 * (4 + chunk) + 4 * b;
+        }
+    }
     if (pre) {
         if ((rc = ensure_cmp_rows(ctx, d))) return rc;
         GPB_HIP(hipMemsetAsync(ctx->cmp_idx, 0, 2 * sizeof(int), ctx->stream));
@@ -1443,9 +1547,13 @@ extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev,
         double *q = qs[b], *factor = factors[b], *lpq = lpqs[b];
         // the counter + index list of this batch's rows inside the box: two views one int apart, so that the fused kernel
         // can re-arm the finished batch's counter while it fills the next one's
-        int* cmpv = ctx->cmp_idx ? ctx->cmp_idx + b : nullptr;
+        int* cmpv = balanced ? bal_cmp[b] : (ctx->cmp_idx ? ctx->cmp_idx + b : nullptr);
         if (!fuse_ap || g == 0) {
-            if (premark)       // the proposal kernel also takes the prior-box test of this rank's rows
+            if (balanced)      // flags of every row; k_balance_gather ranks them and takes this rank's slice
+                hipLaunchKernelGGL(k_propose, g32, dim3(256), 0, ctx->stream, pos_dev, nh, (int)d, half, seed, step, a, q,
+                                   factor, hb, rnd, lo_dev, hi_dev, outside_value, (double*)nullptr, bal_flags[b], (int64_t)0,
+                                   nh, (double*)nullptr, (int*)nullptr);
+            else if (premark)  // the proposal kernel also takes the prior-box test of this rank's rows
                 hipLaunchKernelGGL(k_propose, g32, dim3(256), 0, ctx->stream, pos_dev, nh, (int)d, half, seed, step, a, q,
                                    factor, hb, rnd, lo_dev, hi_dev, outside_value, lpq,
                                    pre == 1 ? ctx->cmp_idx + 4 + ctx->Wcap : (int*)nullptr, r0, chunk,
@@ -1455,6 +1563,9 @@ extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev,
                                    factor, hb, rnd, (const double*)nullptr, (const double*)nullptr, 0.0, (double*)nullptr,
                                    (int*)nullptr, (int64_t)0, (int64_t)0, (double*)nullptr, (int*)nullptr);
         }
+        if (balanced)
+            hipLaunchKernelGGL(k_balance_gather, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, ctx->stream, q, nh, (int)d,
+                               bal_flags[b], bal_rank[b], R, (int)(r0 / chunk), ctx->cmp_X, cmpv, bal_meta[b]);
         // this rank's rows of the batch: [compaction to the rows inside the box,] per emulator K*^T + mean partials,
         // V = L^-1 K*^T with the fused sum of squares, block log-likelihood (+ prior box + constant)
         if (plain) {
@@ -1474,13 +1585,16 @@ extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev,
                                rnd, half, step, q, factor, lpq, reinterpret_cast<long long*>(naccept_dev),
                                reinterpret_cast<long long*>(ctx->n_nan), cmpv, ctx->live_hint, chunk, live,
                                (int)(g1 & 1), (uint32_t)(step0 + (uint64_t)(g1 >> 1)), a, qs[1 - b], factors[1 - b], lo_dev,
-                               hi_dev, outside_value, lpqs[1 - b], r0, chunk, ctx->cmp_X, ctx->cmp_idx + (1 - b));
+                               hi_dev, outside_value, lpqs[1 - b], r0, chunk, ctx->cmp_X,
+                               balanced ? bal_cmp[1 - b] : ctx->cmp_idx + (1 - b), (const int*)bal_rank[b],
+                               (const int*)bal_meta[b], chunk, bal_flags[1 - b]);
             double* sw = lp_cur; lp_cur = lp_alt; lp_alt = sw;
         } else {
             hipLaunchKernelGGL(k_accept, g32, dim3(256), 0, ctx->stream, pos_dev, lp_cur, nh, (int)d, half, seed, step, q,
                                factor, lpq, reinterpret_cast<long long*>(naccept_dev), hb, rnd,
                                reinterpret_cast<long long*>(ctx->n_nan), pre == 2 ? cmpv : (int*)nullptr,
-                               pre == 2 ? ctx->live_hint : (unsigned long long*)nullptr, chunk, live);
+                               pre == 2 ? ctx->live_hint : (unsigned long long*)nullptr, chunk, live,
+                               (const int*)bal_rank[b], (const int*)bal_meta[b], chunk, outside_value);
         }
         if (half == 1 && (chain_dev || lpchain_dev))
             hipLaunchKernelGGL(k_store_step, dim3((unsigned)((nwalkers * d + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev,

@@ -71,7 +71,9 @@ int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
  * kernel at all), or leaves both to the compaction's own kernels (0); 30 = with 29 at 2, the accept of a half-step and the
  * proposal of the next one are one launch (1, default) or two (0).  All of these give the same ensemble.  32 = which rank
  * of key 26's simulated ranks the hook plays (default 0); 33 / 34 / 35 = the tile-shape rule's switch points (128x128, 64x128,
- * 64x64; tiles per 256 CUs) for compacted batches. */
+ * 64x64; tiles per 256 CUs) for compacted batches; 36 = a sharded gpb_chain_emcee_run gives every rank an equal slice of
+ * the ordered list of all rows inside the box (2: always, 1, default: from 8 ranks on) or the rows inside the box of a
+ * contiguous share (0). */
 int gpb_debug_tune(gpb_ctx* ctx, int key, int value);
 /* debug hook: per-tile placement and timing of the predict kernel.  capacity > 0 arms (and clears) a trace of
  * that many records, 0 disarms; read copies up to max_records records of 8 uint32 {HW_ID register, XCC_ID,

@@ -278,12 +278,13 @@ def test_box_test_in_the_proposal_kernel_equals_the_marking_kernel(tmp_path):
     assert 0 < runs["premark"][2].sum() < 5 * nw and np.isfinite(lnp).all()
 
 
-@pytest.mark.parametrize("fuse", [1, 0])
-def test_every_ranks_share_of_the_c_loop_equals_the_host_loop_on_those_rows(tmp_path, fuse):
-    """the sharded C loop evaluates rows [r chunk, (r + 1) chunk) of every batch (offsets into the proposals, the box
-    flags, the gathered rows and the log-probability vector); played for every rank r of 3 on one GPU (the rows of
-    the other ranks stay -inf: rejected) it walks the same ensemble as the host-driven loop whose log-probability
-    evaluates exactly those rows"""
+@pytest.mark.parametrize("fuse,balance", [(1, 1), (0, 1), (1, 0), (0, 0)])
+def test_every_ranks_share_of_the_c_loop_equals_the_host_loop_on_those_rows(tmp_path, fuse, balance):
+    """the sharded C loop evaluates one rank's share of every batch — balanced: the r-th of R equal slices of the ordered
+    list of ALL rows inside the box (k_balance_gather; the accept kernels find a row's value through its rank in that
+    list); contiguous: the rows inside the box of proposals [r chunk, (r + 1) chunk).  Played for every rank r of 3 on one
+    GPU (the other ranks' values stay -inf: rejected) it walks the same ensemble as the host-driven loop whose
+    log-probability evaluates exactly those rows"""
     import torch
     from gpbayestools_hic_amd import StretchSampler, synth
     from gpbayestools_hic_amd.workload import build_chain
@@ -292,7 +293,10 @@ def test_every_ranks_share_of_the_c_loop_equals_the_host_loop_on_those_rows(tmp_
     R, nw = 3, 1092                                           # 546 rows per batch, 182 per rank
     chunk = nw // 2 // R
     X0 = synth.walkers(nw, info["d"], seed=4)
+    lo, hi = chain._box(torch.device("cuda", 0))
     eng.tune("fuse_accept_propose", fuse)
+    eng.tune("balance_shards", 2 if balance else 0)
+    slices = []
     for r in range(R):
         eng.tune("sim_ranks", R)
         eng.tune("sim_rank", r)
@@ -306,8 +310,17 @@ def test_every_ranks_share_of_the_c_loop_equals_the_host_loop_on_those_rows(tmp_
             out.fill_(float("-inf"))
             if X_dev.shape[0] == nw:                          # the starting positions: every rank evaluates them all
                 return chain.log_prob_device(X_dev, out=out)
-            sl = slice(r * chunk, (r + 1) * chunk)
-            out[sl] = chain.log_prob_device(X_dev[sl].contiguous())
+            if balance:
+                inside = ((X_dev > lo) & (X_dev < hi)).all(dim=1)
+                g = torch.cumsum(inside.to(torch.int64), 0) - 1
+                per = max(-(-int(inside.sum().item()) // R), 1)
+                mine = inside & (g // per == r)
+                slices.append(int(mine.sum().item()))
+                if mine.any():
+                    out[mine] = chain.log_prob_device(X_dev[mine].contiguous())
+            else:
+                sl = slice(r * chunk, (r + 1) * chunk)
+                out[sl] = chain.log_prob_device(X_dev[sl].contiguous())
             return out
 
         h = StretchSampler(chain, nw, seed=17, logprob_device=rows_of_rank)
@@ -317,4 +330,7 @@ def test_every_ranks_share_of_the_c_loop_equals_the_host_loop_on_those_rows(tmp_
         assert np.array_equal(c.lnprobability, h.lnprobability) and np.array_equal(c.naccept.cpu().numpy(), h.naccept.cpu().numpy())
         moved = np.any(c.chain[:, -1] != X0, axis=1)
         assert 0 < moved.sum() < nw
+    if balance:
+        assert max(slices) - min(s for s in slices if s) <= 60 and max(slices) <= chunk    # equal slices, within the collective's size
     eng.tune("fuse_accept_propose", 1)
+    eng.tune("balance_shards", 1)
