@@ -139,3 +139,32 @@ def test_mixed_chain_mapped_and_plain_emulators_and_argument_checks(tmp_path):
     assert lib.gpb_chain_emcee_run(arr, 2, nat.ptr(Xd), nat.ptr(out), 7, 1, 1, 0, 2.0, 1, nat.ptr(lo), nat.ptr(hi),
                                    float("-inf"), 0.0, None, None, None) != 0       # odd number of walkers
     other.close()
+
+
+@pytest.mark.parametrize("d,nws", [(40, (2, 6, 34, 130)), (33, (66,)), (3, (4, 258))])
+def test_c_loop_shapes_many_parameters_and_tiny_ensembles(tmp_path, d, nws):
+    """the C-driven loop's walker-group kernels keep one parameter per lane up to 32 and two beyond (d <= 64): chains
+    over 40, 33 and 3 parameters, ensembles from a single pair of walkers up, against the host-driven loop; and one rank's
+    balanced slice of a 2-way split on the widest"""
+    from gpbayestools_hic_amd import StretchSampler
+    from gpbayestools_hic_amd.workload import build_multi_chain
+    chain, emus, info = build_multi_chain([(72, 10, 3, "RBF"), (64, 6, 2, "Matern25")], d, workdir=str(tmp_path))
+    eng = emus[0]._engine_ready()
+    rng = np.random.default_rng(d)
+    for nw in nws:
+        X0 = np.clip(info["xstar"] + 0.2 * rng.standard_normal((nw, d)), -0.05, 1.05)      # a few walkers start outside
+        c = StretchSampler(chain, nw, seed=nw)
+        assert c._resident_engine()[2] == 2
+        c.run(X0, 5, status=2)
+        h = StretchSampler(chain, nw, seed=nw)
+        h._resident_engine = lambda: None
+        h.run(X0, 5, status=2)
+        assert np.array_equal(c.chain, h.chain) and np.array_equal(c.lnprobability, h.lnprobability), nw
+        assert np.array_equal(c.naccept.cpu().numpy(), h.naccept.cpu().numpy())
+    nw = nws[-1]
+    if nw % 4 == 0 or (nw // 2) % 2 == 0:
+        eng.tune("sim_ranks", 2); eng.tune("sim_rank", 1); eng.tune("balance_shards", 2)
+        s = StretchSampler(chain, nw, seed=1)
+        s.run(X0, 3, status=10)
+        eng.tune("sim_ranks", 0); eng.tune("sim_rank", 0); eng.tune("balance_shards", 1)
+        assert np.isfinite(s.chain).all()
