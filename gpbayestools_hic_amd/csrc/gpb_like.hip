@@ -1607,6 +1607,76 @@ extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev,
     return 0;
 }
 
+// Measurement hook: the kernels of ONE step of gpb_chain_emcee_run captured into a HIP graph and replayed `reps` times,
+// against `reps` plain calls of one step (both timed with HIP events on the context's stream).  The replay repeats the
+// same step index — the same draws — so it measures launch overhead, it does not sample; pos / lp are scratch copies.
+extern "C" int gpb_debug_graph_probe(gpb_ctx* const* ctxs, int E, const double* pos_dev, const double* lp_dev,
+                                     int64_t nwalkers, uint64_t seed, double a, const double* lo_dev, const double* hi_dev,
+                                     double outside_value, double inside_const, int reps, double* ms_plain, double* ms_graph) {
+    if (!ctxs || E < 1 || !ctxs[0] || !pos_dev || !lp_dev || !ms_plain || !ms_graph || reps < 1) return GPB_E_ARG;
+    gpb_ctx* ctx = ctxs[0];
+    GPB_HIP(hipSetDevice(ctx->device));
+    const int64_t d = chain_ndim(ctx);
+    // the legacy default stream (torch's current stream, usually) cannot be captured: a stream of the probe's own
+    hipStream_t own = nullptr, saved[64];
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    GPB_HIP(hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
+    for (int e = 0; e < E && e < 64; ++e) { saved[e] = ctxs[e]->stream; ctxs[e]->stream = own; }
+    struct Restore {
+        gpb_ctx* const* c; int E; hipStream_t* s; hipStream_t own;
+        ~Restore() { (void)hipStreamSynchronize(own); for (int e = 0; e < E && e < 64; ++e) c[e]->stream = s[e]; (void)hipStreamDestroy(own); }
+    } restore{ctxs, E, saved, own};
+    double *pos = nullptr, *lp = nullptr;
+    GPB_HIP(hipMalloc(&pos, sizeof(double) * (size_t)(nwalkers * d)));
+    GPB_HIP(hipMalloc(&lp, sizeof(double) * (size_t)nwalkers));
+    GPB_HIP(hipMemcpyAsync(pos, pos_dev, sizeof(double) * (size_t)(nwalkers * d), hipMemcpyDeviceToDevice, ctx->stream));
+    GPB_HIP(hipMemcpyAsync(lp, lp_dev, sizeof(double) * (size_t)nwalkers, hipMemcpyDeviceToDevice, ctx->stream));
+    auto one_step = [&]() {
+        return gpb_chain_emcee_run(ctxs, E, pos, lp, nwalkers, 1, seed, 0, a, 1, lo_dev, hi_dev, outside_value, inside_const,
+                                   nullptr, nullptr, nullptr);
+    };
+    int rc = 0;
+    for (int i = 0; i < 3 && !rc; ++i) rc = one_step();            // workspaces allocated, clocks up
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    float ms = 0.f;
+    if (!rc) {
+        GPB_HIP(hipEventCreate(&e0));
+        GPB_HIP(hipEventCreate(&e1));
+        GPB_HIP(hipEventRecord(e0, ctx->stream));
+        for (int i = 0; i < reps && !rc; ++i) rc = one_step();
+        GPB_HIP(hipEventRecord(e1, ctx->stream));
+        GPB_HIP(hipEventSynchronize(e1));
+        GPB_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *ms_plain = ms / reps;
+    }
+    if (!rc) {
+        GPB_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        rc = one_step();
+        hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
+        if (!rc && ce != hipSuccess) { ctx->err = std::string("graph capture: ") + hipGetErrorString(ce); rc = GPB_E_HIP; }
+    }
+    if (!rc) {
+        GPB_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        for (int i = 0; i < 3; ++i) GPB_HIP(hipGraphLaunch(exec, ctx->stream));
+        GPB_HIP(hipEventRecord(e0, ctx->stream));
+        for (int i = 0; i < reps; ++i) GPB_HIP(hipGraphLaunch(exec, ctx->stream));
+        GPB_HIP(hipEventRecord(e1, ctx->stream));
+        GPB_HIP(hipEventSynchronize(e1));
+        GPB_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *ms_graph = ms / reps;
+    }
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(pos);
+    (void)hipFree(lp);
+    return rc;
+}
+
 extern "C" int gpb_emcee_run(gpb_ctx* ctx, double* pos_dev, double* lp_dev, int64_t nwalkers, int64_t nsteps,
                              uint64_t seed, uint64_t step0, double a, int randomize_split, const double* lo_dev,
                              const double* hi_dev, double outside_value, double inside_const, double* chain_dev,

@@ -88,6 +88,12 @@ int gpb_debug_force_generic_mvn(gpb_ctx* ctx, int on);
  * pairs they processed; resets the counters. */
 int gpb_profile_enable(gpb_ctx* ctx, int on);
 int gpb_profile_read(gpb_ctx* ctx, int64_t* launches, double* total_ms, double* units);
+/* measurement hook: one step of gpb_chain_emcee_run (same arguments; pos / lp are copied, not advanced) as `reps` plain
+ * calls and as `reps` replays of its HIP graph; milliseconds per step each.  The replay repeats one step index: it
+ * measures launch overhead, it does not sample. */
+int gpb_debug_graph_probe(gpb_ctx* const* ctxs, int E, const double* pos_dev, const double* lp_dev, int64_t nwalkers,
+                          uint64_t seed, double a, const double* lo_dev, const double* hi_dev, double outside_value,
+                          double inside_const, int reps, double* ms_plain, double* ms_graph);
 /* issue-rate probe: returns measured TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64
  * (mode 0), v_fma_f64 (mode 1) or both co-issued (mode 2); mode 3: shader cycles per MFMA (one wave
  * per SIMD); mode 4: shader clock in GHz held during the dense MFMA loop. */
