@@ -107,11 +107,41 @@ __device__ __forceinline__ void acc_zero(Acc<T, NW, TN>& acc) {
 // One K-step of MFMAs from the staged tiles.  The wave's m-tile i (16 rows) starts at row m0 + MS*i of the block
 // tile: MS = 16, m0 = wave row * T/2 for the usual contiguous halves; MS = 32, m0 = wave row * 16 when the two wave
 // rows own the 16-row m-tiles alternately (TRI below).  IMIN > 0 leaves out m-tiles 0..IMIN-1.
-template <int T, int NW, int TN, int KB, int MS = 16, int IMIN = 0>
+// PIPE (the 128x128 predict tile; tune key 37 = 0 for the plain form): the fragments of the next k-group are read from LDS before the MFMAs of
+// the current one, so that their latency runs under 16 MFMAs instead of in front of them.
+template <int T, int NW, int TN, int KB, int MS = 16, int IMIN = 0, bool PIPE = false>
 __device__ __forceinline__ void tile_mma(const TileLds<T, TN, KB>& L, Acc<T, NW, TN>& acc, int lane, int m0,
                                          int n0) {
     constexpr int NI = T / 32, NJ = (2 * TN / NW) / 16;
     const int lr = lane & 15, lk = lane >> 4;
+    if constexpr (PIPE) {
+        double a[2][NI], b[2][NJ];
+#pragma unroll
+        for (int i = IMIN; i < NI; ++i) a[0][i] = L.As[lk][m0 + MS * i + lr];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[0][j] = L.Bs[lk][n0 + 16 * j + lr];
+#pragma unroll
+        for (int kk = 0; kk < KB; kk += 4) {
+            const int cur = (kk >> 2) & 1, nxt = cur ^ 1;
+            if (kk + 4 < KB) {
+#pragma unroll
+                for (int i = IMIN; i < NI; ++i) a[nxt][i] = L.As[kk + 4 + lk][m0 + MS * i + lr];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[nxt][j] = L.Bs[kk + 4 + lk][n0 + 16 * j + lr];
+            }
+#pragma unroll
+            for (int i = IMIN; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][i], b[cur][j], acc.v[i][j], 0, 0, 0);
+            // keep the order written here: the next group's LDS reads, then this group's MFMAs.  (Spreading the reads
+            // between the MFMAs, one per two, cost 28 bytes of scratch and 0.7 %; 32-deep K-steps for this tile 88 bytes
+            // and 4-5 %: profiles/r02_k_predict_inner_loop.txt)
+            __builtin_amdgcn_sched_group_barrier(0x100, NI - IMIN + NJ, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, (NI - IMIN) * NJ, 0);
+        }
+        return;
+    }
 #pragma unroll
     for (int kk = 0; kk < KB; kk += 4) {
         double a[NI], b[NJ];
@@ -140,12 +170,13 @@ __device__ __forceinline__ void tile_mma(const TileLds<T, TN, KB>& L, Acc<T, NW,
 // compile-time constant per pair and the main loop stays free of control flow.  37.5 % of the diagonal block's
 // MFMAs go (T = 128), the skipped products are exact zeros, the sums are unchanged.  Callers must read acc with
 // the same interleaved map.
-template <int T, bool A_TRANS, bool B_TRANS, int NW = 4, int TN = T, int KB = BK, bool FULL = false, bool TRI = false>
+template <int T, bool A_TRANS, bool B_TRANS, int NW = 4, int TN = T, int KB = BK, bool FULL = false, bool TRI = false,
+          bool PIPE = false>
 __device__ __forceinline__ void gemm_tile_loop(const double* __restrict__ Ag, int64_t lda,
                                                const double* __restrict__ Bg, int64_t ldb, int64_t m_base,
                                                int64_t n_base, int m_ext, int n_ext, int64_t k_begin, int64_t k_end,
                                                TileLds<T, TN, KB>& L, Acc<T, NW, TN>& acc, int64_t tri_begin = 0) {
-    static_assert(!TRI || KB == 16, "TRI pairs K-steps of 16 with 16-row m-tiles");
+    static_assert(!TRI || KB == 16 || KB == 32, "TRI covers the diagonal block 32 k at a time");
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     constexpr int WN = NW / 2, TNW = TN / WN;   // waves along n, wave tile width
@@ -177,17 +208,19 @@ __device__ __forceinline__ void gemm_tile_loop(const double* __restrict__ Ag, in
     int64_t k0 = k_begin;
     for (; k0 < k_main; k0 += KB) {
         stage(k0);
-        tile_mma<T, NW, TN, KB, MS>(L, acc, lane, m0, n0);
+        tile_mma<T, NW, TN, KB, MS, 0, PIPE>(L, acc, lane, m0, n0);
     }
     if constexpr (TRI) {
         // the diagonal block, two K-steps at a time (its extent is a multiple of 32: Np is one of 64)
 #define GPB_TRI_PAIR(Q)                                                                  \
         if (Q < T / 32 && k0 < k_end) {                                                  \
             stage(k0);                                                                   \
-            tile_mma<T, NW, TN, KB, MS, (Q < T / 32 ? Q : 0)>(L, acc, lane, m0, n0);     \
-            stage(k0 + KB);                                                              \
-            tile_mma<T, NW, TN, KB, MS, (Q < T / 32 ? Q : 0)>(L, acc, lane, m0, n0);     \
-            k0 += 2 * KB;                                                                \
+            tile_mma<T, NW, TN, KB, MS, (Q < T / 32 ? Q : 0), PIPE>(L, acc, lane, m0, n0);     \
+            if (KB == 16) {                                                              \
+                stage(k0 + KB);                                                          \
+                tile_mma<T, NW, TN, KB, MS, (Q < T / 32 ? Q : 0), PIPE>(L, acc, lane, m0, n0); \
+            }                                                                            \
+            k0 += 32;                                                                    \
         }
         GPB_TRI_PAIR(0) GPB_TRI_PAIR(1) GPB_TRI_PAIR(2) GPB_TRI_PAIR(3)
 #undef GPB_TRI_PAIR

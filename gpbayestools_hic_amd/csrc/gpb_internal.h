@@ -69,6 +69,7 @@ struct gpb_ctx {
     int balance_shards = 1;        // tune key 36: sharded C loop takes equal slices of the ordered live-row list
     int* bal_ws = nullptr;         // its flags / ranks / scatter lists
     int64_t bal_cap = 0;
+    int mma_pipe = 1;              // tune key 37: the 128x128 predict tile reads the next k-group's fragments ahead of the MFMAs
     int sim_rank = 0;              // tune key 32: which rank of sim_ranks the measurement hook plays
     int tile_by_live = 1;          // tune key 28
     int premark = 2;               // tune key 29: the C-driven loop's proposal kernel takes the prior-box test (1) and gathers the rows inside (2)

@@ -207,7 +207,7 @@ __device__ __forceinline__ void set_wave_prio(int p) {      // s_setprio takes a
     else __builtin_amdgcn_s_setprio(3);
 }
 
-template <int T, int NW, int TN, int KB>
+template <int T, int NW, int TN, int KB, bool PIPE = false>
 __device__ __forceinline__ void predict_tile(TileLds<T, TN, KB>& lds, int p, int ib, int wt, const double* __restrict__ Linv,
                                              const double* __restrict__ KsT, double* __restrict__ spart, int64_t Np,
                                              int64_t Wld, int P, int prio_levels, unsigned* __restrict__ trace,
@@ -227,8 +227,8 @@ __device__ __forceinline__ void predict_tile(TileLds<T, TN, KB>& lds, int p, int
     // Np is a multiple of 64 and the batch is padded to 128 walkers: 64-row tiles never have an edge
     // L^-1 is lower triangular: the 128x128 kernel skips the all-zero 16-row m-tiles of the diagonal block
     // (gemm_tile_loop TRI: the wave rows own the m-tiles alternately, acc.v[i] = m-tile 2i + wave row).
-    constexpr bool TRI = (NW == 4);
-    gemm_tile_loop<T, false, false, NW, TN, KB, T == 64, TRI>(Linv + (int64_t)p * Np * Np, Np,
+    constexpr bool TRI = (NW == 4);      // (K-steps of 16 or 32)
+    gemm_tile_loop<T, false, false, NW, TN, KB, T == 64, TRI, PIPE>(Linv + (int64_t)p * Np * Np, Np,
                                                               KsT + (int64_t)p * Np * Wld, Wld, mb, nb, m_ext, TN, 0,
                                                               k_end, lds, acc, tri_skip ? mb : k_end);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -385,7 +385,7 @@ __device__ __forceinline__ bool decode_tile(int xcd_mode, unsigned t, unsigned q
 // queues in LPT order, so the triangular row blocks balance dynamically whatever the dispatcher does.
 // Exit condition: every workgroup walks all eight queues once and leaves each when its ticket is past
 // the queue's length; nothing spins.
-template <int T, int NW, int TN, int KB>
+template <int T, int NW, int TN, int KB, bool PIPE = false>
 __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (T == 64 && TN == 64 && NW == 4 ? 6 : 4))) void k_predict(const double* __restrict__ Linv, const double* __restrict__ KsT,
                                                      double* __restrict__ spart, int64_t Np, int64_t Wld, int P,
                                                      int nI, int nW, int xcd_mode, unsigned* __restrict__ queue,
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (T == 64 && TN 
             if (t >= nq) break;                 // uniform: this queue is exhausted
             int p, ib, wt;
             if (!decode_tile(xcd_mode, t, qx, nI, nW, P, p, ib, wt)) continue;   // padding (uniform)
-            predict_tile<T, NW, TN, KB>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace, tri_skip);
+            predict_tile<T, NW, TN, KB, PIPE>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace, tri_skip);
         }
     }
     // the last workgroup to finish re-arms the queues for the next launch (all others are past their draws)
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (T == 64 && TN 
 // 2 = snake over the CUs (equal sums per CU), 3 = snake of neighbouring PAIRS (equal sums, and the two heaviest
 // tiles of a CU finish together).  Same tile -> queue maps as above; a separate kernel so that each has ONE
 // inlined copy of the tile body (with two copies the compiler parked the prefetch registers in scratch memory).
-template <int T, int NW, int TN, int KB>
+template <int T, int NW, int TN, int KB, bool PIPE = false>
 __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (KB == 32 ? 3 : 4))) void k_predict_static(
     const double* __restrict__ Linv, const double* __restrict__ KsT, double* __restrict__ spart, int64_t Np, int64_t Wld,
     int P, int nI, int nW, int xcd_mode, unsigned nblocks, int order, unsigned ncu_x, int prio_levels,
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (KB == 32 ? 3 :
     }
     int p, ib, wt;
     if (decode_tile(xcd_mode, t, qx, nI, nW, P, p, ib, wt))
-        predict_tile<T, NW, TN, KB>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace, tri_skip);
+        predict_tile<T, NW, TN, KB, PIPE>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace, tri_skip);
 }
 
 __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ mpart, const double* __restrict__ spart,
@@ -672,7 +672,12 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
                                ctx->tile_counter, (unsigned)nblocks, ctx->tile_trace, ctx->tri_skip, nrows_dev);   \
     } while (0)
         // (32-deep K-steps for the 64-row tiles were measured: within 2.5 % either way, not kept)
-        if (T == 128)      { if (nwv == 8) GPB_PRED(128, 8, 128, 16); else GPB_PRED(128, 4, 128, 16); }
+        if (ctx->mma_pipe && T == 128 && nwv == 4 && !resident)
+            hipLaunchKernelGGL((k_predict<128, 4, 128, 16, true>), dim3(grid), dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT,
+                               ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xcd_rows, ctx->tile_counter,
+                               (unsigned)nblocks, ctx->tile_trace, ctx->tri_skip, nrows_dev);
+
+        else if (T == 128) { if (nwv == 8) GPB_PRED(128, 8, 128, 16); else GPB_PRED(128, 4, 128, 16); }
         else if (TN == 32) GPB_PRED(64, 4, 32, 16);
         else if (TN == 128) GPB_PRED(64, 4, 128, 16);
         else if (nwv == 8) GPB_PRED(64, 8, 64, 16);
