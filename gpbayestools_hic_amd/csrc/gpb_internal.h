@@ -141,7 +141,7 @@ struct gpb_ctx {
     int force_xcd = -1;             // tuning hook: -1 auto, 0 / 1 = k_predict XCD affinity by walker tile / row block
     int64_t tile_switch = 960;      // use 128x128 tiles when at least this many of them exist per 256 CUs (measured)
     int64_t mid_switch = 1280;      // else 64x128 tiles when at least this many of THEM exist, else 64x64 / 64x32
-    int64_t tile_switch_c = 3072, mid_switch_c = 1150, narrow_switch_c = 2400;   // the same for compacted batches (tune keys 33-35)
+    int64_t tile_switch_c = 2400, mid_switch_c = 1150, narrow_switch_c = 2400;   // the same for compacted batches (tune keys 33-35)
     bool force_generic_mvn = false; // test hook: bypass the register-resident MVN fast path
     int fuse_finalize = 1;          // block log-likelihood kernels sum the predict partials themselves (P <= 32)
     int64_t mvn_wg_switch = 768;   // batches up to this size use one workgroup per walker (32 < M <= 64)

@@ -611,7 +611,7 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
         const int64_t tiles64x128 = ctx->P * nI64 * ((Wsel + 127) / 128), tiles64 = ctx->P * nI64 * ((Wsel + 63) / 64);
         // Compacted batches have their own switch points (tools/gpu_shard_sim.py --walkers=.. --tune=force_tile:..,
         // profiles/r02_tile_shape_sweep_compacted.txt, cfg 4 at 190 .. 2060 live rows): the larger shape pays later —
-        // 64x32 up to 9.4 tiles of 64x64 per CU (5), 64x64 up to 4.5 of 64x128 (5), 64x128 up to 12 of 128x128 (3.75).
+        // 64x32 up to 9.4 tiles of 64x64 per CU (5), 64x64 up to 4.5 of 64x128 (5), 64x128 up to 9.4 of 128x128 (3.75).
         const bool cmpd = nrows_dev != nullptr && ctx->tile_by_live;
         const int64_t sw128 = cmpd ? ctx->tile_switch_c : ctx->tile_switch, swmid = cmpd ? ctx->mid_switch_c : ctx->mid_switch,
                       swnarrow = cmpd ? ctx->narrow_switch_c : ctx->narrow_switch;
