@@ -75,7 +75,7 @@ def test_emulator_with_parameter_pca_gpu(tmp_path):
     emu = Emulator(training_set_path=tp, parameter_file=pf, npc=int(g["npc"]), parameterTrafoPCA=True)
     assert maxrel(emu.PCA_new_design_points, g["new_design_points"]) < 1e-10
     emu.trainEmulator([True] * emu.nev, thetas=g["thetas"])
-    assert relerr(emu.lml_, g["lml"]) < 1e-10         # measured 1e-15 (tools/gpu_param_pca_errors.py)
+    assert relerr(emu.lml_, g["lml"]) < 1e-10         # measured 1e-15 (tests/diag_param_pca_errors.py)
     mean, cov = emu.predict(g["Xs"], return_cov=True, extra_std=0.0)
     assert relerr(mean, g["mean"]) < 1e-11            # measured 6e-15
     assert maxrel(cov, g["cov"]) < 1e-10              # measured 1.4e-15
