@@ -141,10 +141,11 @@ def test_mixed_chain_mapped_and_plain_emulators_and_argument_checks(tmp_path):
     other.close()
 
 
-@pytest.mark.parametrize("d,nws", [(40, (2, 6, 34, 130)), (33, (66,)), (3, (4, 258))])
+@pytest.mark.parametrize("d,nws", [(40, (2, 6, 34, 130)), (33, (66,)), (3, (4, 258, 40000))])
 def test_c_loop_shapes_many_parameters_and_tiny_ensembles(tmp_path, d, nws):
     """the C-driven loop's walker-group kernels keep one parameter per lane up to 32 and two beyond (d <= 64): chains
-    over 40, 33 and 3 parameters, ensembles from a single pair of walkers up, against the host-driven loop; and one rank's
+    over 40, 33 and 3 parameters, ensembles from a single pair of walkers up to 40 000 (beyond 16 384 rows per batch the
+    compaction keeps its own marking kernel), against the host-driven loop; and one rank's
     balanced slice of a 2-way split on the widest"""
     from gpbayestools_hic_amd import StretchSampler
     from gpbayestools_hic_amd.workload import build_multi_chain
