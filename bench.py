@@ -11,6 +11,12 @@ A step = one emcee-equivalent stretch-move step of the whole ensemble = two half
 log-posterior batches through the HIP engine (propose -> GP predict -> fused MVN -> accept), all
 resident in HBM.  With N > 1 the 4096 walkers are sharded over the ranks (strong scaling) and each
 log-probability batch ends in one RCCL all-gather.  Prints ONE JSON line on rank 0.
+
+The timed ensemble is BURNT-IN: walkers in a small ball around theta* (what the reference's run_mcmc holds after
+re-seeding at its best points, src/mcmc.py:392-405), so that every proposal row lies inside the prior box and is
+evaluated (asserted: >= 95 % over the timed region) — `value` counts only work that was done.  The run from walkers
+spread uniformly over the box, where about half of the proposals leave the box and cost nothing (here as in the
+reference, src/mcmc.py:275-283), is reported beside it as extras.uniform_start.
 """
 import argparse
 import json
@@ -26,16 +32,18 @@ sys.path.insert(0, ROOT)
 FP64_MFMA_PEAK_TFLOPS = 78.6     # public MI355X fp64 matrix figure; the microarch guide lists no fp64 row
 
 
-def cpu_baseline(info, emu, nrows):
+def cpu_baseline(info, Xw, what):
     """The reference CPU path restated by the oracle in its *faithful* mode (full W x W predictive
-    covariance per GP as sklearn forms it, then per-row dpotrf/dpotrs), timed on the host cores for
-    ONE half-ensemble batch of `nrows` rows."""
+    covariance per GP over the rows inside the box, as sklearn forms it, then per-row dpotrf/dpotrs), timed on the
+    host cores on the half-ensemble batch `Xw` — proposal rows of the GPU run itself, so both sides see the same
+    inside / outside mix (the reference, too, evaluates only the rows inside the box: src/mcmc.py:275-283)."""
     from oracle import gp_oracle as O
     from gpbayestools_hic_amd import synth
     d, P = info["d"], info["P"]
     kind = O.KIND_NAMES[{"RBF": "RBF", "Matern": "Matern", "Matern25": "Matern25"}[info["kernel_type"]]]
     oe = O.OracleEmulator(info["X"], info["Y"], info["lo"], info["hi"], P, kind).fit(synth.fixed_theta(d, P))
-    Xw = synth.walkers(nrows, d, seed=synth.SEED + 7)
+    nrows = Xw.shape[0]
+    inside = float(np.mean(np.all((Xw > info["lo"]) & (Xw < info["hi"]), axis=1)))
     yexp = info["yexp"]
     cexp = np.diag((0.05 * np.abs(yexp)) ** 2)
     calls, t0 = 0, time.time()
@@ -51,8 +59,9 @@ def cpu_baseline(info, emu, nrows):
     except Exception:
         cores = os.cpu_count()
     return {"value": nrows * calls / dt, "unit": "walker-evals/s", "cores": cores, "kind": "port",
-            "sample": f"{calls} half-ensemble log_posterior call(s) of {nrows} rows each (faithful W x W covariance "
-                      f"per GP + per-row LAPACK MVN), {dt:.1f} s, numpy/scipy threaded BLAS"}, lp, Xw
+            "rows_inside_box_fraction": inside,
+            "sample": f"{calls} log_posterior call(s) on {what} ({nrows} rows, {inside:.3f} of them inside the prior "
+                      f"box; faithful W x W covariance per GP + per-row LAPACK MVN), {dt:.1f} s, numpy/scipy threaded BLAS"}, lp
 
 
 def extras(chain4, emu4, info4):
@@ -140,6 +149,7 @@ def main():
     ap.add_argument("--walkers", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-uniform", action="store_true", help="skip the second timed run from the uniform start")
     ap.add_argument("--cpu-rows", type=int, default=None)
     args = ap.parse_args()
 
@@ -159,7 +169,11 @@ def main():
     nwalkers = args.walkers or 2 * info["W"]
     sharding = WalkerSharding() if world > 1 else None
     sampler = StretchSampler(chain, nwalkers, seed=12345, sharding=sharding, device=local)
-    X0 = synth.walkers(nwalkers, d)
+    # burnt-in start: a ball around theta*, small enough that the stretch move (which grows a concentrated ensemble by
+    # about 1.4x per step towards the posterior's width) keeps every proposal inside the prior box over warm-up + timed steps
+    ball = float(min(1e-3, max(1e-13, 10.0 ** (-3.0 - 0.16 * (args.warmup + args.steps)))))
+    X0 = synth.walkers_ball(nwalkers, info["xstar"], ball, lo=info["lo"], hi=info["hi"])
+    X0_uniform = synth.walkers(nwalkers, d)
     eng = emu._engine_ready()
     direct_why = None
     if sharding is not None and dist.get_backend() == "nccl" and os.environ.get("GPB_DIST_DIRECT", "1") != "0":
@@ -173,44 +187,66 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def all_ranks(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
     # Which loop drives the steps: gpb_emcee_run (the C ABI enqueues every kernel and, when sharded, the in-stream
     # all-gather) or the host-driven loop (Python enqueues; the all-gather through torch.distributed).  A build box has
     # one GPU, so the sharded form of the C loop runs for the first time on the multi-GPU node: it is checked here
-    # against the host-driven loop on a short run (every rank must reproduce the same ensemble) and dropped on ALL ranks
-    # if any rank disagrees or raises.
+    # against the host-driven loop on a short run from the spread-out start (rows inside AND outside the box; every rank
+    # must reproduce the same ensemble) and dropped on ALL ranks if any rank disagrees or raises.  StretchSampler.run
+    # itself lets the ranks agree that gpb_chain_emcee_prepare succeeded everywhere before any of them enqueues a
+    # collective.
     loop = "gpb_chain_emcee_run" if sampler._resident_engine() is not None else "host-driven"
     if world > 1 and loop == "gpb_chain_emcee_run":
         ok = True
         try:
             ref = StretchSampler(chain, nwalkers, seed=777, sharding=sharding, device=local)
             ref._resident_engine = lambda: None
-            a = ref.run(X0, 2, status=10 ** 9, store=False)
+            a = ref.run(X0_uniform, 2, status=10 ** 9, store=False)
             tst = StretchSampler(chain, nwalkers, seed=777, sharding=sharding, device=local)
-            b = tst.run(X0, 2, status=10 ** 9, store=False)
-            ok = bool(np.array_equal(a, b))
+            ok = bool(np.array_equal(a, tst.run(X0_uniform, 2, status=10 ** 9, store=False)))
         except Exception as e:          # noqa: BLE001
             print(f"rank {rank}: gpb_chain_emcee_run self-check raised {type(e).__name__}: {e}", file=sys.stderr)
             ok = False
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) != 1:
+        if not all_ranks(ok):
             sampler._resident_engine = lambda: None
             loop = "host-driven (gpb_chain_emcee_run failed its self-check against it)"
 
-    sampler.run(X0, args.warmup, status=10 ** 9, store=False)
-    eng.profile(True)
-    barrier()
-    t0 = time.perf_counter()
-    sampler.run(None, args.steps, status=10 ** 9, store=False)      # continues from the resident state
-    barrier()
-    dt = time.perf_counter() - t0
-    launches, kms, units = eng.profile_read()
-    eng.profile(False)
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+    def timed_run(X_start, seed):
+        smp = sampler if seed is None else StretchSampler(chain, nwalkers, seed=seed, sharding=sharding, device=local)
+        if seed is not None and loop.startswith("host-driven"):
+            smp._resident_engine = lambda: None
+        smp.run(X_start, args.warmup, status=10 ** 9, store=False)
+        eng.profile(True)
+        barrier()
+        t0 = time.perf_counter()
+        smp.run(None, args.steps, status=10 ** 9, store=False)      # continues from the resident state
+        barrier()
+        dt = time.perf_counter() - t0
+        launches, kms, units = eng.profile_read()
+        eng.profile(False)
+        tt = torch.tensor([dt, units], dtype=torch.float64, device="cuda")
+        if world > 1:
+            mx, sm = tt.clone(), tt.clone()
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+            return smp, float(mx[0].item()), launches, kms, units, float(sm[1].item())
+        return smp, dt, launches, kms, units, units
+
+    _, dt, launches, kms, units, units_all = timed_run(X0, None)
     acc = float(sampler.acceptance_fraction.mean())
+    inside_frac = (units_all / (launches * P * (nwalkers // 2))) if launches else None      # all ranks' rows
+    if inside_frac is not None and inside_frac < 0.95:          # the same number on every rank: all leave together
+        if rank == 0:
+            print(f"bench.py: only {inside_frac:.3f} of the timed region's proposal rows lay inside the prior box; the "
+                  f"headline must be measured on a burnt-in ensemble (>= 0.95): use fewer --steps / --warmup than "
+                  f"{args.steps} / {args.warmup}", file=sys.stderr)
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(3)
     consistent = None
     if world > 1:       # replicated RNG + gathered log-probabilities: every rank must hold the same ensemble
         chk = torch.stack([sampler.pos.sum(), sampler.lp.sum()])
@@ -218,11 +254,36 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         consistent = bool(torch.equal(lo, hi))
+    import hashlib
+    checksum = hashlib.sha256(sampler.pos.cpu().numpy().tobytes() + sampler.lp.cpu().numpy().tobytes()).hexdigest()[:16]
+    # the proposal rows of the half-step that FOLLOWS the timed region (the sampler's own proposal kernel on the final
+    # ensemble): what the CPU baseline is timed on — the same inside / outside mix as the timed batches
+    Xnext = torch.empty((nwalkers // 2, d), dtype=torch.float64, device=sampler.pos.device)
+    fnext = torch.empty(nwalkers // 2, dtype=torch.float64, device=sampler.pos.device)
+    from gpbayestools_hic_amd import _native as nat
+    eng._ck(eng.lib.gpb_stretch_propose(eng.h, nat.ptr(sampler.pos), nwalkers, d, 0, sampler.seed, sampler._step_counter,
+                                        sampler.a, nat.ptr(Xnext), nat.ptr(fnext), sampler.randomize_split))
+    Xnext = Xnext.cpu().numpy()
+    # the same loop from walkers spread uniformly over the box (round 1/2's timed region): about half of the proposals
+    # leave the 20-dimensional box and are not evaluated
+    uni = None
+    if not args.no_uniform:
+        su, dtu, lu, kmsu, unitsu, units_all_u = timed_run(X0_uniform, 4242)
+        uni = {"value": nwalkers * args.steps / dtu, "unit": "walker-evals/s (proposals outside the box counted, not evaluated)",
+               "value_evaluated": units_all_u / P / dtu, "ms_per_step": dtu / args.steps * 1e3,
+               "rows_inside_box_fraction": (units_all_u / (lu * P * (nwalkers // 2))) if lu else None,
+               "acceptance_fraction": float(su.acceptance_fraction.mean()),
+               "k_predict_avg_launch_ms": kmsu / max(lu, 1),
+               "k_predict_frac_of_peak": (unitsu / max(lu, 1) * float(N) * float(N) / (kmsu / max(lu, 1) * 1e-3) / 1e12
+                                          / FP64_MFMA_PEAK_TFLOPS) if lu else None,
+               "what": "the same step loop started from walkers uniform in the prior box (SURVEY 8d's walkers)"}
+        del su
 
     if rank == 0:
         value = nwalkers * args.steps / dt
         alg_flops_per_launch = units / max(launches, 1) * float(N) * float(N)     # N^2 per (GP, walker): the trsm term
         achieved = alg_flops_per_launch / (kms / max(launches, 1) * 1e-3) / 1e12 if launches else None
+        gflop_step = flops_per_walker(N, d, P, M, info["kernel"]) * nwalkers / 1e9
         out = {
             "metric": "MCMC steps/s x walkers (walker log-posterior evaluations per second, whole job)",
             "value": value, "unit": "walker-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -230,43 +291,53 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE config {args.config}: {N} design pts x {d} params x {M} observables, "
                                    f"{P} GPs ({info['kernel']}), {nwalkers} walkers, stretch move, "
-                                   f"fixed hyper-parameters", "walkers": nwalkers,
+                                   f"fixed hyper-parameters, burnt-in ensemble (ball of relative radius {ball:.1e} "
+                                   f"around theta*)", "walkers": nwalkers,
                        "parallelism": f"walker-shard x{world}" if world > 1 else "single GPU", "step_loop": loop,
                        "allgather": None if world == 1 else (
                            "gpb_dist_allgather (ncclAllGather on the kernel stream)" if sharding.direct is not None
                            else "torch.distributed " + dist.get_backend()
                                 + (" (direct path not used: %s)" % direct_why if direct_why else ""))},
-            "acceptance_fraction": acc, "ranks_hold_identical_ensemble": consistent,
+            "acceptance_fraction": acc, "ranks_hold_identical_ensemble": consistent, "ensemble_checksum": checksum,
             # proposals outside the prior box cost nothing, here as in the reference (src/mcmc.py:275-283): share of the
-            # timed region's proposal rows (this rank's) that lay inside the box and were evaluated
-            "rows_inside_box_fraction": (units / (launches * P * (nwalkers // 2 // world))) if launches else None,
-            "gflop_per_step_algorithmic": flops_per_walker(N, d, P, M, info["kernel"]) * nwalkers / 1e9,
-            "gflop_per_step_algorithmic_note": "SURVEY 8(d)'s figure for 4096 evaluated walkers; rows outside the box are not evaluated",
+            # timed region's proposal rows that lay inside the box and were evaluated, and the rate counted on those alone
+            "rows_inside_box_fraction": inside_frac,
+            "value_evaluated": units_all / P / dt,
+            "gflop_per_step_algorithmic": gflop_step,
+            "tflops_algorithmic": gflop_step / (dt / args.steps) / 1e3 * (inside_frac or 1.0),
+            "gflop_per_step_algorithmic_note": "SURVEY 8(d)'s figure for 4096 evaluated walkers; tflops_algorithmic = that x "
+                                               "rows_inside_box_fraction / ms_per_step (<= the 78.6 TF/s fp64 peak)",
             "roofline": {"bound": "mfma", "kernel": "k_predict (V = L^-1 K*^T, fused sum of squares)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / FP64_MFMA_PEAK_TFLOPS) if achieved else None, "traffic": None,
                          "launches": launches, "avg_launch_ms": kms / max(launches, 1)},
         }
         # HBM-side traffic of the dominant kernel: PMC counters need rocprofv3, so the per-launch figure comes
-        # from the committed summary of the same command (profiles/r02_pmc_traffic.json), when it matches.
+        # from the committed summary of the same command (profiles/r03_pmc_traffic.json), when it matches.
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
                 pmc = json.load(f)
             wl = pmc["workload"]
             if (wl["config"], wl["N"], wl["P"], wl["W_per_launch"]) == (args.config, N, P, nwalkers // 2) and world == 1 \
-                    and wl.get("compacted") and out["rows_inside_box_fraction"] and out["rows_inside_box_fraction"] < 0.6:
+                    and wl.get("burnt_in"):
                 out["roofline"]["traffic"] = pmc["k_predict"]["bytes_per_launch_corrected"]
-                out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_pmc_traffic.json)"
+                out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r03_pmc_traffic.json)"
                 out["roofline"]["algorithmic_bytes"] = pmc["k_predict"]["algorithmic_bytes_per_launch"]
         except Exception:
             pass
         if world == 1 and not args.no_extras:
             out["extras"] = extras(chain, emu, info)
+        if uni is not None:
+            out.setdefault("extras", {})["uniform_start"] = uni
         if world == 1 and not args.no_cpu_baseline:
-            rows = args.cpu_rows or info["W"]
-            cb, lp_cpu, Xw = cpu_baseline(info, emu, rows)
-            lp_gpu = chain.log_posterior(Xw)
-            cb["max_rel_diff_vs_gpu"] = float(np.max(np.abs(lp_gpu - lp_cpu) / np.abs(lp_cpu)))
+            rows = min(args.cpu_rows or Xnext.shape[0], Xnext.shape[0])
+            cb, lp_cpu = cpu_baseline(info, np.ascontiguousarray(Xnext[:rows]),
+                                      "the proposal rows of the half-step that follows the GPU's timed region "
+                                      "(gpb_stretch_propose on the final ensemble)")
+            lp_gpu = chain.log_posterior(Xnext[:rows])
+            fin = np.isfinite(lp_cpu)
+            cb["max_rel_diff_vs_gpu"] = float(np.max(np.abs(lp_gpu[fin] - lp_cpu[fin]) / np.abs(lp_cpu[fin]))) if fin.any() else None
+            cb["same_rows_outside_box"] = bool(np.array_equal(fin, np.isfinite(lp_gpu)))
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:

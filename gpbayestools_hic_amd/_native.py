@@ -56,6 +56,8 @@ BOUNDARY = {
     "gpb_chain_logpost": (C.c_int, [VP, C.c_int, VP, c_i64, VP, VP, VP, C.c_double, C.c_double]),
     "gpb_chain_emcee_run": (C.c_int, [VP, C.c_int, VP, VP, c_i64, c_i64, c_u64, c_u64, C.c_double, C.c_int, VP, VP,
                                       C.c_double, C.c_double, VP, VP, VP]),
+    "gpb_chain_emcee_prepare": (C.c_int, [VP, C.c_int, c_i64]),
+    "gpb_dist_available": (C.c_int, []),
     "gpb_dist_uid": (C.c_int, [VP]),
     "gpb_dist_init": (C.c_int, [VP, C.c_int, C.c_int, VP]),
     "gpb_dist_allgather": (C.c_int, [VP, VP, VP, c_i64]),

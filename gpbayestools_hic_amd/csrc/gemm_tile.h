@@ -41,6 +41,16 @@ struct __attribute__((aligned(16))) TileLds {
     double Bs[KB][TN + 16];
 };                                       // KB=16: T=128: 36,864 B; T=64: 20,480 B; 64x32: 16,384 B
 
+// Row skew of the staged tiles: element (k, x) lives at [k][x + lds_skew(k)], inside the 16-double row pad.  The row
+// stride is 2 (T + 16) dwords = 0 (mod 32 banks), so the transposing stores of lstore_trans — a 16-lane group of
+// ds_write_b64 (32 banks) holds four x's of FOUR k rows, 4 apart — hit the same banks four times (16 LDS-array cycles per
+// instruction against the 6 of its register transfer: with 64-row tiles the LDS array, not the matrix pipe, set the
+// pace).  Shifting rows k, k+4, k+8, k+12 by 0, 4, 8, 12 doubles puts the four rows on disjoint banks; for the fragment
+// reads of a k-group (rows kk .. kk+3: one skew) it is a compile-time constant folded into the instruction's offset —
+// no extra address registers (an XOR swizzle cost 6-14 VGPRs and pushed three predict kernels into scratch).
+// Layout only: no result changes.
+__device__ __forceinline__ constexpr int lds_skew(int k) { return ((k >> 2) & 3) << 2; }
+
 // NW = waves per workgroup (4: 2x2 waves, wave tile T/2 x T/2;  8: 2x4 waves, wave tile T/2 x T/4).
 template <int T, int NW = 4, int KB = BK>
 struct Frag { d2 r[(KB * T / 2) / (64 * NW)]; };       // native vectors: HIP's double2 struct is copied with memcpy,
@@ -67,8 +77,13 @@ template <int T, int NW, int KB>
 __device__ __forceinline__ void lstore_direct(double (*S)[T + 16], const Frag<T, NW, KB>& f, int tid) {
     constexpr int TPR = T / 2, RPP = (64 * NW) / TPR;
     const int row = tid / TPR, col = (tid % TPR) * 2;
+    // lds_skew(row + RPP j) = lds_skew(row) + lds_skew(RPP j): RPP is a multiple of 4 (no carry into the skew bits) and the
+    // sum stays below 16 for every shape in use — a per-thread base plus a compile-time constant
+    static_assert(RPP % 4 == 0 && RPP * ((KB * T / 2) / (64 * NW)) == KB, "lstore_direct: rows per pass");
+    const int colk = col + lds_skew(row);
 #pragma unroll
-    for (int j = 0; j < (KB * T / 2) / (64 * NW); ++j) *reinterpret_cast<d2*>(&S[row + RPP * j][col]) = f.r[j];
+    for (int j = 0; j < (KB * T / 2) / (64 * NW); ++j)
+        *reinterpret_cast<d2*>(&S[row + RPP * j][colk + lds_skew(RPP * j)]) = f.r[j];
 }
 // logical tile[k][x] = G[(x0+x)*ld + k0+k]   (rows of G are contiguous in k): transpose on store.
 template <int T, int NW, int KB, bool FULL = false>
@@ -88,11 +103,14 @@ __device__ __forceinline__ void gload_trans(const double* __restrict__ G, int64_
 template <int T, int NW, int KB>
 __device__ __forceinline__ void lstore_trans(double (*S)[T + 16], const Frag<T, NW, KB>& f, int tid) {
     constexpr int TPX = (64 * NW) / T, KPT = KB / TPX;
+    static_assert(KPT == 2 || KPT % 4 == 0, "lstore_trans: k's per thread");
     const int x = tid / TPX, kh = (tid % TPX) * KPT;
+    const int xk = x + lds_skew(kh);
 #pragma unroll
     for (int j = 0; j < KPT / 2; ++j) {
-        S[kh + 2 * j][x] = f.r[j].x;
-        S[kh + 2 * j + 1][x] = f.r[j].y;
+        // lds_skew(kh + 2 j) = lds_skew(kh) + lds_skew(2 j) (kh is a multiple of KPT; k and k + 1 share the skew)
+        S[kh + 2 * j][xk + lds_skew(2 * j)] = f.r[j].x;
+        S[kh + 2 * j + 1][xk + lds_skew(2 * j)] = f.r[j].y;
     }
 }
 
@@ -117,17 +135,17 @@ __device__ __forceinline__ void tile_mma(const TileLds<T, TN, KB>& L, Acc<T, NW,
     if constexpr (PIPE) {
         double a[2][NI], b[2][NJ];
 #pragma unroll
-        for (int i = IMIN; i < NI; ++i) a[0][i] = L.As[lk][m0 + MS * i + lr];
+        for (int i = IMIN; i < NI; ++i) a[0][i] = L.As[lk][m0 + MS * i + lr + lds_skew(0)];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) b[0][j] = L.Bs[lk][n0 + 16 * j + lr];
+        for (int j = 0; j < NJ; ++j) b[0][j] = L.Bs[lk][n0 + 16 * j + lr + lds_skew(0)];
 #pragma unroll
         for (int kk = 0; kk < KB; kk += 4) {
             const int cur = (kk >> 2) & 1, nxt = cur ^ 1;
             if (kk + 4 < KB) {
 #pragma unroll
-                for (int i = IMIN; i < NI; ++i) a[nxt][i] = L.As[kk + 4 + lk][m0 + MS * i + lr];
+                for (int i = IMIN; i < NI; ++i) a[nxt][i] = L.As[kk + 4 + lk][m0 + MS * i + lr + lds_skew(kk + 4)];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) b[nxt][j] = L.Bs[kk + 4 + lk][n0 + 16 * j + lr];
+                for (int j = 0; j < NJ; ++j) b[nxt][j] = L.Bs[kk + 4 + lk][n0 + 16 * j + lr + lds_skew(kk + 4)];
             }
 #pragma unroll
             for (int i = IMIN; i < NI; ++i)
@@ -146,9 +164,9 @@ __device__ __forceinline__ void tile_mma(const TileLds<T, TN, KB>& L, Acc<T, NW,
     for (int kk = 0; kk < KB; kk += 4) {
         double a[NI], b[NJ];
 #pragma unroll
-        for (int i = IMIN; i < NI; ++i) a[i] = L.As[kk + lk][m0 + MS * i + lr];
+        for (int i = IMIN; i < NI; ++i) a[i] = L.As[kk + lk][m0 + MS * i + lr + lds_skew(kk)];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) b[j] = L.Bs[kk + lk][n0 + 16 * j + lr];
+        for (int j = 0; j < NJ; ++j) b[j] = L.Bs[kk + lk][n0 + 16 * j + lr + lds_skew(kk)];
 #pragma unroll
         for (int i = IMIN; i < NI; ++i)
 #pragma unroll

@@ -656,6 +656,8 @@ struct Rccl {
 constexpr int NCCL_DOUBLE = 8;   // ncclFloat64
 }  // namespace
 
+extern "C" int gpb_dist_available(void) { return g_rccl.load() ? 1 : 0; }
+
 extern "C" int gpb_dist_uid(void* uid128_host) {
     if (!uid128_host) return GPB_E_ARG;
     if (!g_rccl.load()) return GPB_E_RCCL;
@@ -757,6 +759,7 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 32: if (value < 0 || value > 63) return GPB_E_ARG; ctx->sim_rank = value; break;
         case 36: if (value < 0 || value > 2) return GPB_E_ARG; ctx->balance_shards = value; break;
         case 37: if (value < 0 || value > 1) return GPB_E_ARG; ctx->mma_pipe = value; break;
+        case 38: if (value < 0 || value > 1) return GPB_E_ARG; ctx->fold_tiles = value; break;
         case 33: if (value < 0) return GPB_E_ARG; ctx->tile_switch_c = value; break;
         case 34: if (value < 0) return GPB_E_ARG; ctx->mid_switch_c = value; break;
         case 35: if (value < 0) return GPB_E_ARG; ctx->narrow_switch_c = value; break;

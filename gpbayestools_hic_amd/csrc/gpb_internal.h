@@ -66,7 +66,7 @@ struct gpb_ctx {
     unsigned long long* live_hint = nullptr;   // pinned host memory: (batch rows << 32) | live rows of the last finished compaction
     gpb_ctx* hint_from = nullptr;  // whose live_hint sizes this context's tile rule (the chain's first emulator compacts)
     int fuse_accept_propose = 1;   // tune key 30: accept of a half-step + proposal of the next in one launch (needs premark 2)
-    int balance_shards = 1;        // tune key 36: sharded C loop takes equal slices of the ordered live-row list
+    int balance_shards = 0;        // tune key 36: sharded C loop takes equal slices of the ordered live-row list (1: from 8 ranks on, 2: always; default off)
     int* bal_ws = nullptr;         // its flags / ranks / scatter lists
     int64_t bal_cap = 0;
     int mma_pipe = 1;              // tune key 37: the 128x128 predict tile reads the next k-group's fragments ahead of the MFMAs
@@ -119,6 +119,7 @@ struct gpb_ctx {
     int wgs_per_cu64x128 = 5;       // ... for the 64x128 tile (4 resident at 128 VGPRs)
     int64_t narrow_switch = 1280;   // 64x64 tiles when at least this many of them exist per 256 CUs, else 64x32
     int static64 = 1;               // 64-row predict tiles always launch as k_predict_static
+    int fold_tiles = 0;             // tune key 38: 64x32 / 64x64 predict tiles run as folded row-block pairs (k_predict_fold; measured, not faster)
     int predict_waves = 4;          // waves per k_predict tile (4 or 8)
     unsigned* tile_counter = nullptr;   // 8 ticket queues (stride 16) + done counter [128]; re-armed by the kernel
     int64_t chol_outer = 0;        // outer panel width of the two-level blocked Cholesky (0 = chosen by size, gpb_chol.hip)

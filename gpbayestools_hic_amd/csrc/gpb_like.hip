@@ -767,19 +767,24 @@ __global__ __launch_bounds__(256) void k_compact_mark(const double* __restrict__
                                                       const double* __restrict__ lo, const double* __restrict__ hi,
                                                       double outside, double* __restrict__ ll, int* __restrict__ rank,
                                                       int* __restrict__ blockcnt) {
-    extern __shared__ double srow[];                   // [256][d + 1]
+    extern __shared__ double srow[];                   // [256][dt + 1], dt = min(d, 64): the columns go through in tiles
     __shared__ int wsum[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ldr = d + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dt = d < 64 ? d : 64, ldr = dt + 1;
     const int64_t w0 = (int64_t)blockIdx.x * 256, nrow = imin64(256, W - w0);
-    for (int64_t e = tid; e < nrow * d; e += 256) srow[(e / d) * ldr + (e % d)] = X[w0 * d + e];
-    __syncthreads();
     const bool have = tid < nrow;
     int ok = have ? 1 : 0;
-    if (have)
-        for (int k = 0; k < d; ++k) {
-            const double x = srow[tid * ldr + k];
-            ok &= (int)(x > lo[k]) & (int)(x < hi[k]);          // strict (src/mcmc.py:275); no short circuit
-        }
+    for (int k0 = 0; k0 < d; k0 += dt) {
+        const int kn = (d - k0 < dt) ? d - k0 : dt;
+        if (k0) __syncthreads();
+        for (int64_t e = tid; e < nrow * kn; e += 256) srow[(e / kn) * ldr + (e % kn)] = X[(w0 + e / kn) * d + k0 + (e % kn)];
+        __syncthreads();
+        if (have)
+            for (int k = 0; k < kn; ++k) {
+                const double x = srow[tid * ldr + k];
+                ok &= (int)(x > lo[k0 + k]) & (int)(x < hi[k0 + k]);      // strict (src/mcmc.py:275); no short circuit
+            }
+    }
     const bool in = ok != 0;
     if (have && !in) ll[w0 + tid] = outside;
     const unsigned long long m = __ballot(in);
@@ -860,7 +865,7 @@ int launch_compact(gpb_ctx* ctx, const double* X_dev, int64_t W, int64_t dx, con
     const unsigned nb = (unsigned)((W + 255) / 256);
     int* rank = ctx->cmp_idx + 4 + ctx->Wcap;          // [Wcap] ranks, then [Wcap / 256 + 1] workgroup counts
     int* blockcnt = rank + ctx->Wcap;
-    const size_t sh = sizeof(double) * 256 * (size_t)(dx + 1);
+    const size_t sh = sizeof(double) * 256 * (size_t)((dx < 64 ? dx : 64) + 1);
     if (sh > 64 * 1024 && !premarked)
         GPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_compact_mark), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     // premarked: k_propose has left 0/1 flags in rank[] and `outside` in ll (see there)
@@ -1010,7 +1015,7 @@ __global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, 
     const double* s = pos + pi(2 * k + half) * d;
     const double* c = pos + pi(2 * j + (1 - half)) * d;
     int ok = 1;
-    double v2[2] = {0.0, 0.0};                         // d <= 64 (gpb_gp_set): at most two parameters per lane
+    double v2[2] = {0.0, 0.0};                         // the first two parameters of this lane (all of them for d <= 64)
     int nv = 0;
     for (int t = t0; t < d; t += 32) {
         const double v = c[t] - (c[t] - s[t]) * zz;
@@ -1040,6 +1045,9 @@ __global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, 
             if (slot >= 0) {
                 if (t0 < d) Xc[(int64_t)slot * d + t0] = v2[0];
                 if (t0 + 32 < d) Xc[(int64_t)slot * d + t0 + 32] = v2[1];
+                // chains with more than 64 parameters (parameterTrafoPCA: the chain's ndim is the map's d_in, which only
+                // the GPs' reduced d bounds): the same arithmetic again, operation for operation
+                for (int t = t0 + 64; t < d; t += 32) Xc[(int64_t)slot * d + t] = c[t] - (c[t] - s[t]) * zz;
             }
         }
     }
@@ -1215,6 +1223,7 @@ __global__ void k_accept_propose(double* __restrict__ pos, const double* __restr
     if (slot >= 0) {
         if (t0 < d) Xc[(int64_t)slot * d + t0] = v2[0];
         if (t0 + 32 < d) Xc[(int64_t)slot * d + t0 + 32] = v2[1];
+        for (int t = t0 + 64; t < d; t += 32) Xc[(int64_t)slot * d + t] = c[t] - (c[t] - s[t]) * zz;   // ndim > 64: as k_propose
     }
 }
 
@@ -1379,6 +1388,9 @@ __global__ void k_fill(double* __restrict__ x, int64_t n, double v) {
 // the same parameter space (those with a parameter map, src/emulator.py:492-551, through gpb_param_map).
 namespace {
 int64_t chain_ndim(const gpb_ctx* c) { return c->pmap_d_in > 0 ? c->pmap_d_in : c->d; }
+// parameters of the CHAIN (a parameter map's d_in; the GPs' own d is bounded by 64 in gpb_gp_set).  The proposal kernels
+// take any number; k_compact_mark stages 256 rows of it in LDS in tiles, so the bound is only a sanity limit.
+constexpr int64_t MAX_CHAIN_NDIM = 512;
 
 // every context usable by the compacted chain path?  (same device, stream and parameter space; likelihood installed;
 // a block likelihood kernel applies)
@@ -1393,7 +1405,11 @@ int chain_check(gpb_ctx* const* ctxs, int E, const char* who) {
         if (chain_ndim(c) != chain_ndim(ctx)) GPB_FAIL(GPB_E_ARG, std::string(who) + ": the emulators disagree on the number of parameters");
         if (!compaction_applies(c))
             GPB_FAIL(GPB_E_STATE, std::string(who) + ": needs the block likelihood kernels (PCA mode, M <= 64 or npc <= 16) for every emulator");
+        if (c->pmap_d_in > 0 && c->pmap_d_out != c->d)
+            GPB_FAIL(GPB_E_STATE, std::string(who) + ": a parameter map's output must be the GPs' input");
     }
+    if (chain_ndim(ctx) > MAX_CHAIN_NDIM)
+        GPB_FAIL(GPB_E_ARG, std::string(who) + ": more than 512 chain parameters");
     return 0;
 }
 
@@ -1432,7 +1448,8 @@ extern "C" int gpb_chain_supported(gpb_ctx* const* ctxs, int E) {
         const gpb_ctx* c = ctxs[e];
         if (!c) return GPB_E_ARG;
         if (!c->have_like || c->device != ctxs[0]->device || c->stream != ctxs[0]->stream ||
-            chain_ndim(c) != chain_ndim(ctxs[0]) || !compaction_applies(c))
+            chain_ndim(c) != chain_ndim(ctxs[0]) || !compaction_applies(c) || chain_ndim(c) > MAX_CHAIN_NDIM ||
+            (c->pmap_d_in > 0 && c->pmap_d_out != c->d))
             return 0;
     }
     return 1;
@@ -1450,18 +1467,25 @@ extern "C" int gpb_chain_logpost(gpb_ctx* const* ctxs, int E, const double* Xs_d
     return chain_rows(ctxs, E, Xs_dev, W, ll_dev, lo_dev, hi_dev, outside_value, inside_const);
 }
 
-extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev, double* lp_dev, int64_t nwalkers,
-                                   int64_t nsteps, uint64_t seed, uint64_t step0, double a, int randomize_split,
-                                   const double* lo_dev, const double* hi_dev, double outside_value, double inside_const,
-                                   double* chain_dev, double* lpchain_dev, int64_t* naccept_dev) {
-    if (!ctxs || E < 1 || E > 64 || !ctxs[0]) return GPB_E_ARG;
+namespace {
+// What gpb_chain_emcee_run decides before it enqueues anything: argument checks, the share of every batch this rank
+// evaluates, which of the step's kernels are fused, and every workspace it needs — all of which can fail on ONE rank only
+// (bad state, hipMalloc).  gpb_chain_emcee_prepare runs exactly this and nothing else, so that the ranks of a sharded run
+// can agree that all of them are ready BEFORE any of them enqueues a collective the others would wait in.
+struct EmceePlan {
+    int64_t nh = 0, d = 0, chunk = 0, r0 = 0;
+    int R = 1;
+    bool sim = false, plain = false, fused = false, premark = false, fuse_ap = false, balanced = false;
+    int pre = 0;
+};
+
+int emcee_plan(gpb_ctx* const* ctxs, int E, int64_t nwalkers, EmceePlan& pl) {
     gpb_ctx* ctx = ctxs[0];
-    if (!pos_dev || !lp_dev || !lo_dev || !hi_dev || nsteps < 0) GPB_FAIL(GPB_E_ARG, "gpb_chain_emcee_run: null pointer or negative size");
     if (nwalkers < 2 || (nwalkers & 1) || nwalkers > (1ll << 30)) GPB_FAIL(GPB_E_ARG, "gpb_chain_emcee_run: nwalkers must be even, 2 .. 2^30");
     // one emulator without a parameter map may also run uncompacted (tune key 27 = 0, non-PCA modes): gpb_logpost's sequence
-    const bool plain = E == 1 && ctx->pmap_d_in == 0 && !compaction_applies(ctx);
+    pl.plain = E == 1 && ctx->pmap_d_in == 0 && !compaction_applies(ctx);
     int rc;
-    if (plain) {
+    if (pl.plain) {
         if (!ctx->have_like) GPB_FAIL(GPB_E_STATE, "gpb_emcee_run before gpb_like_set");
     } else if ((rc = chain_check(ctxs, E, "gpb_chain_emcee_run"))) {
         return rc;
@@ -1472,12 +1496,15 @@ extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev,
     const int rank = ctx->comm ? ctx->rank : 0;
     // measurement / test hook (tune keys 26, 32): behave like rank `sim_rank` of `sim_ranks` on a single GPU — evaluate
     // that rank's nh / sim_ranks rows of every batch only (the other rows keep -inf: rejected) and still issue the collective
-    const bool sim = ctx->sim_ranks > 1 && R == 1;
-    if (sim) R = ctx->sim_ranks;
+    pl.sim = ctx->sim_ranks > 1 && R == 1;
+    if (pl.sim) R = ctx->sim_ranks;
     if (nh % R) GPB_FAIL(GPB_E_ARG, "gpb_chain_emcee_run: half the ensemble must divide evenly over the ranks");
-    if (sim && ctx->sim_rank >= R) GPB_FAIL(GPB_E_ARG, "gpb_chain_emcee_run: tune key 32 (simulated rank) must be below key 26 (ranks)");
-    const int64_t chunk = nh / R, r0 = (sim ? ctx->sim_rank : rank) * chunk;
-    for (int e = 0; e < E; ++e)                        // all workspaces now: the loop below holds pointers into them
+    if (pl.sim && ctx->sim_rank >= R) GPB_FAIL(GPB_E_ARG, "gpb_chain_emcee_run: tune key 32 (simulated rank) must be below key 26 (ranks)");
+    pl.nh = nh; pl.d = d; pl.R = R;
+    pl.chunk = nh / R;
+    pl.r0 = (pl.sim ? ctx->sim_rank : rank) * pl.chunk;
+    const int64_t chunk = pl.chunk;
+    for (int e = 0; e < E; ++e)                        // all workspaces now: the loop holds pointers into them
         if ((rc = ensure_wcap(ctxs[e], chunk))) { if (e) ctx->err = ctxs[e]->err; return rc; }
     // proposal workspace: two sets of q[nh][d], factor[nh], lpq[nh] (the fused accept + proposal kernel reads one set and
     // writes the other) and a second log-probability vector [nwalkers]
@@ -1485,43 +1512,73 @@ extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev,
         GPB_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->mc_ws) GPB_HIP(hipFree(ctx->mc_ws));
         ctx->mc_ws = nullptr;
+        ctx->mc_cap = 0;
         GPB_HIP(hipMalloc(&ctx->mc_ws, sizeof(double) * (size_t)(2 * nh * (d + 3))));
         ctx->mc_cap = 2 * nh * (d + 3);
     }
-    double* qs[2] = {ctx->mc_ws, ctx->mc_ws + nh * (d + 2)};
-    double* factors[2] = {qs[0] + nh * d, qs[1] + nh * d};
-    double* lpqs[2] = {factors[0] + nh, factors[1] + nh};
-    double* lp2 = ctx->mc_ws + 2 * nh * (d + 2);
-    const int hb = half_bits(nwalkers), rnd = randomize_split ? 1 : 0;
-    const dim3 g32((unsigned)((nh * 32 + 255) / 256));
-    const bool fused = plain && loglike_fuses_finalize(ctx, chunk);
+    pl.fused = pl.plain && loglike_fuses_finalize(ctx, chunk);
     // the gather kernel counts the flags in front of each of its workgroups itself: fine for a rank's rows of an
     // ensemble, quadratic for very large batches, which keep the marking kernel with its per-workgroup counts
-    const bool premark = !plain && ctx->premark && chunk <= 16384;
+    pl.premark = !pl.plain && ctx->premark && chunk <= 16384;
     // ... premark 2 (default): the proposal kernel gathers the rows as well (slots from a counter that the accept kernel
     // re-arms), no compaction kernel at all; 1: flags only, k_compact_gather follows
-    const int pre = premark ? (ctx->premark >= 2 ? 2 : 1) : 0;
+    pl.pre = pl.premark ? (ctx->premark >= 2 ? 2 : 1) : 0;
     // ... and with that, tune key 30 (default on): the accept of a half-step and the proposal of the next are one launch
-    const bool fuse_ap = pre == 2 && ctx->fuse_accept_propose;
+    pl.fuse_ap = pl.pre == 2 && ctx->fuse_accept_propose;
     // sharded (or playing one rank of several): equal slices of the ordered list of ALL live rows instead of the live rows
     // of a contiguous share (k_balance_gather; tune key 36)
     // Worth its extra launch (k_balance_gather + the rank look-ups of the accept step: +11 us per half-step, measured) only
     // where the ranks' live counts straddle a walker-tile boundary often: 256 proposals per rank hold 120 +- 8 live rows, so
     // at 8 ranks three half-steps in four have a rank with a fifth 64x32 tile (+23 us, measured per tile); at 2 and 4 ranks
     // the contiguous shares rarely differ by a tile.  1 = from 8 ranks on (default), 2 = always, 0 = never.
-    const bool balanced = pre == 2 && R > 1 && nh <= 16384 &&
-                          (ctx->balance_shards == 2 || (ctx->balance_shards == 1 && R >= 8));
-    int *bal_flags[2] = {nullptr, nullptr}, *bal_rank[2] = {nullptr, nullptr}, *bal_cmp[2] = {nullptr, nullptr},
-        *bal_meta[2] = {nullptr, nullptr};
-    if (balanced) {
+    pl.balanced = pl.pre == 2 && R > 1 && nh <= 16384 &&
+                  (ctx->balance_shards == 2 || (ctx->balance_shards == 1 && R >= 8));
+    if (pl.balanced) {
         const int64_t need = 4 * nh + 2 * (4 + chunk) + 16;
         if (ctx->bal_cap < need) {
             GPB_HIP(hipStreamSynchronize(ctx->stream));
             if (ctx->bal_ws) GPB_HIP(hipFree(ctx->bal_ws));
             ctx->bal_ws = nullptr;
+            ctx->bal_cap = 0;
             GPB_HIP(hipMalloc(&ctx->bal_ws, sizeof(int) * (size_t)need));
             ctx->bal_cap = need;
         }
+    }
+    if (pl.pre && (rc = ensure_cmp_rows(ctx, d))) return rc;
+    return 0;
+}
+}  // namespace
+
+extern "C" int gpb_chain_emcee_prepare(gpb_ctx* const* ctxs, int E, int64_t nwalkers) {
+    if (!ctxs || E < 1 || E > 64 || !ctxs[0]) return GPB_E_ARG;
+    EmceePlan pl;
+    return emcee_plan(ctxs, E, nwalkers, pl);
+}
+
+extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev, double* lp_dev, int64_t nwalkers,
+                                   int64_t nsteps, uint64_t seed, uint64_t step0, double a, int randomize_split,
+                                   const double* lo_dev, const double* hi_dev, double outside_value, double inside_const,
+                                   double* chain_dev, double* lpchain_dev, int64_t* naccept_dev) {
+    if (!ctxs || E < 1 || E > 64 || !ctxs[0]) return GPB_E_ARG;
+    gpb_ctx* ctx = ctxs[0];
+    if (!pos_dev || !lp_dev || !lo_dev || !hi_dev || nsteps < 0) GPB_FAIL(GPB_E_ARG, "gpb_chain_emcee_run: null pointer or negative size");
+    EmceePlan pl;
+    int rc = emcee_plan(ctxs, E, nwalkers, pl);
+    if (rc) return rc;
+    const int64_t nh = pl.nh, d = pl.d, chunk = pl.chunk, r0 = pl.r0;
+    const int R = pl.R, pre = pl.pre;
+    const bool sim = pl.sim, plain = pl.plain, fused = pl.fused, premark = pl.premark, fuse_ap = pl.fuse_ap,
+               balanced = pl.balanced;
+    double* qs[2] = {ctx->mc_ws, ctx->mc_ws + nh * (d + 2)};
+    double* factors[2] = {qs[0] + nh * d, qs[1] + nh * d};
+    double* lpqs[2] = {factors[0] + nh, factors[1] + nh};
+    double* lp2 = ctx->mc_ws + 2 * nh * (d + 2);
+    const int hb = half_bits(nwalkers), rnd = randomize_split ? 1 : 0;
+    const dim3 g32((unsigned)((nh * 32 + 255) / 256));
+    int *bal_flags[2] = {nullptr, nullptr}, *bal_rank[2] = {nullptr, nullptr}, *bal_cmp[2] = {nullptr, nullptr},
+        *bal_meta[2] = {nullptr, nullptr};
+    if (balanced) {
+        const int64_t need = 4 * nh + 2 * (4 + chunk) + 16;
         GPB_HIP(hipMemsetAsync(ctx->bal_ws, 0, sizeof(int) * (size_t)need, ctx->stream));
         for (int b = 0; b < 2; ++b) {
             bal_flags[b] = ctx->bal_ws + b * nh;
@@ -1530,10 +1587,7 @@ extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev,
             bal_meta[b] = ctx->bal_ws + 4 * nh + 2 * (4 + chunk) + 4 * b;
         }
     }
-    if (pre) {
-        if ((rc = ensure_cmp_rows(ctx, d))) return rc;
-        GPB_HIP(hipMemsetAsync(ctx->cmp_idx, 0, 2 * sizeof(int), ctx->stream));
-    }
+    if (pre) GPB_HIP(hipMemsetAsync(ctx->cmp_idx, 0, 2 * sizeof(int), ctx->stream));
     if (sim) hipLaunchKernelGGL(k_fill, dim3((unsigned)((2 * nh * (d + 2) + 255) / 256)), dim3(256), 0, ctx->stream, ctx->mc_ws,
                                 2 * nh * (d + 2), -INFINITY);
     unsigned long long* const live = pre == 2 && ctx->profile ? ctx->rows_live : (unsigned long long*)nullptr;

@@ -77,6 +77,9 @@ extern "C" int gpb_param_map_set(gpb_ctx* ctx, int64_t d_in, int64_t d_out, cons
     if (!ctx) return GPB_E_ARG;
     if (d_in < 1 || d_out < 1 || n_groups < 1 || n_groups > 8 || maxpc < 1 || !col_src || !group_desc || !tables)
         GPB_FAIL(GPB_E_ARG, "gpb_param_map_set: bad sizes or null input");
+    // the map's output is the GPs' input: chain_rows writes W x d_out doubles into the [Wcap][d] staging buffer
+    if (ctx->N == 0) GPB_FAIL(GPB_E_STATE, "gpb_param_map_set before gpb_gp_set");
+    if (d_out != ctx->d) GPB_FAIL(GPB_E_ARG, "gpb_param_map_set: d_out must equal the GPs' number of inputs");
     for (int64_t j = 0; j < d_out; ++j) {
         const int s = col_src[j];
         if (s >= d_in || (s < 0 && (-1 - s) >= n_groups * maxpc)) GPB_FAIL(GPB_E_ARG, "gpb_param_map_set: bad column map");

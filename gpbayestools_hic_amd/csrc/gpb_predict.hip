@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (T == 64 && TN 
     // The ticket lives in the padding of the last A row (never touched by the loaders, the MFMA fragment reads
     // or the epilogue's scratch): the operand tiles alone are an exact fraction of the CU's 160 KB LDS, and a
     // separate 4-byte variable would cost a whole workgroup of occupancy.
-    unsigned& s_ticket = *reinterpret_cast<unsigned*>(&lds.As[KB - 1][T + 8]);
+    unsigned& s_ticket = *reinterpret_cast<unsigned*>(&lds.As[KB - 1][T + 12]);      // (the row skew uses the pad up to T + 11)
     // Eight ticket queues, one per XCD label (blockIdx % 8; workgroups with equal labels share an XCD's
     // L2 under round-robin dispatch — speed only): queue x owns the tiles b = 8 t + x, i.e. a fixed set
     // of walker tiles (or row blocks) whose operand panels stay in that XCD's L2 while its workgroups
@@ -477,6 +477,148 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (KB == 32 ? 3 :
     int p, ib, wt;
     if (decode_tile(xcd_mode, t, qx, nI, nW, P, p, ib, wt))
         predict_tile<T, NW, TN, KB, PIPE>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace, tri_skip);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Folded tiles for small walker batches (a rank's share of a sharded ensemble: 128 - 512 rows).
+// L^-1 is lower triangular, so the K loop of row block ib is 64 (ib + 1) long: one tile per workgroup leaves a CU with
+// tiles of K = 2048 ... 64, its matrix pipe shared by five, four, ... and finally ONE wave per SIMD (one wave alone
+// issues an fp64 MFMA every ~138 cycles against the pipe's 64: profiles/r01_mfma_f64_issue_rate.txt) — the heaviest
+// tile alone ran 208 of the 64x32 launch's 232 us.  Here the triangle is folded into a rectangle: a workgroup owns the
+// row blocks a AND nI - 1 - a of one (GP, walker tile) — together always nI + 1 blocks of K — and runs them as ONE
+// K loop: over k < 64 (a + 1) both blocks multiply the same staged K*^T tile (twice the MFMAs per barrier and per byte
+// of K*^T), beyond it only the heavy block goes on.  Every workgroup of the launch has the same length, five of them
+// are resident per CU from the first cycle to the last, and nothing is left to balance.  A (row block, walker) sum
+// sees exactly the MFMA sequence and the reduction tree of the one-tile kernels: same bits.
+// Units are dealt to the XCDs in contiguous ranges of (GP, a) groups (blockIdx % 8 = XCD under round-robin dispatch): the
+// nW units of a group read the same two L^-1 row panels at the same time, and an XCD sees the K*^T panels of one or two
+// GPs only — each L^-1 block leaves HBM / the Infinity Cache once.
+template <int TN>
+struct __attribute__((aligned(16))) FoldLds {
+    double Ah[BK][64 + 16];      // heavy row block  nI - 1 - a, k-major
+    double Al[BK][64 + 16];      // light row block  a
+    double Bs[BK][TN + 16];      // K*^T tile
+};
+
+template <int TN>
+__global__ __launch_bounds__(256, (TN == 32 ? 5 : 4)) void k_predict_fold(
+    const double* __restrict__ Linv, const double* __restrict__ KsT, double* __restrict__ spart, int64_t Np, int64_t Wld,
+    int P, int nI, int nW, const int* __restrict__ nrows) {
+    __shared__ FoldLds<TN> lds;
+    if (nrows) nW = (*nrows + TN - 1) / TN;            // compacted batch: the walker tiles that hold rows
+    const int nF = (nI + 1) / 2, G = P * nF;
+    const int x = blockIdx.x & 7, t = blockIdx.x >> 3;
+    const int g0 = (int)(((int64_t)x * G) / 8), g1 = (int)(((int64_t)(x + 1) * G) / 8);
+    if (nW <= 0) return;
+    const int gl = t / nW, wt = t - gl * nW;
+    const int g = g0 + gl;
+    if (g >= g1) return;                               // uniform: the whole workgroup leaves
+    const int p = g / nF, a = g - p * nF;
+    const int ibh = nI - 1 - a, ibl = a;
+    const bool fold = ibl < ibh;                       // an odd number of row blocks leaves the middle one alone
+    constexpr int NJ = TN / 32;                        // wave tile: 32 rows of each block x TN / 2 walkers
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = wm * 32, n0 = wn * (TN / 2);
+    const int lr = lane & 15, lk = lane >> 4;
+    const double* Ag = Linv + (int64_t)p * Np * Np;
+    const double* Bg = KsT + (int64_t)p * Np * Wld;
+    const int64_t mbh = (int64_t)ibh * 64, mbl = (int64_t)ibl * 64, nb = (int64_t)wt * TN;
+    const int64_t k_joint = fold ? mbl + 64 : 0, k_end = mbh + 64;
+    d4 acch[2][NJ], accl[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { acch[i][j] = d4{0.0, 0.0, 0.0, 0.0}; accl[i][j] = d4{0.0, 0.0, 0.0, 0.0}; }
+    Frag<64, 4, BK> fah, fal;
+    Frag<TN, 4, BK> fb;
+    gload_trans<64, 4, BK, true>(Ag, Np, 0, mbh, 64, fah, tid);
+    if (fold) gload_trans<64, 4, BK, true>(Ag, Np, 0, mbl, 64, fal, tid);
+    gload_direct<TN, 4, BK, true>(Bg, Wld, 0, nb, TN, fb, tid);
+    int64_t k0 = 0;
+    for (; k0 < k_joint; k0 += BK) {                   // both row blocks against the same K*^T tile
+        __syncthreads();
+        lstore_trans<64, 4, BK>(lds.Ah, fah, tid);
+        lstore_trans<64, 4, BK>(lds.Al, fal, tid);
+        lstore_direct<TN, 4, BK>(lds.Bs, fb, tid);
+        __syncthreads();
+        const int64_t kn = k0 + BK;                    // (k_end > k_joint: there is always a next step here)
+        gload_trans<64, 4, BK, true>(Ag, Np, kn, mbh, 64, fah, tid);
+        if (kn < k_joint) gload_trans<64, 4, BK, true>(Ag, Np, kn, mbl, 64, fal, tid);
+        gload_direct<TN, 4, BK, true>(Bg, Wld, kn, nb, TN, fb, tid);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            double ah[2], al[2], b[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = lds.Ah[kk + lk][m0 + 16 * i + lr + lds_skew(kk)];
+                al[i] = lds.Al[kk + lk][m0 + 16 * i + lr + lds_skew(kk)];
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[j] = lds.Bs[kk + lk][n0 + 16 * j + lr + lds_skew(kk)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acch[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[i], b[j], acch[i][j], 0, 0, 0);
+                    accl[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(al[i], b[j], accl[i][j], 0, 0, 0);
+                }
+        }
+    }
+    for (; k0 < k_end; k0 += BK) {                     // the heavy block alone
+        __syncthreads();
+        lstore_trans<64, 4, BK>(lds.Ah, fah, tid);
+        lstore_direct<TN, 4, BK>(lds.Bs, fb, tid);
+        __syncthreads();
+        const int64_t kn = k0 + BK;
+        if (kn < k_end) {
+            gload_trans<64, 4, BK, true>(Ag, Np, kn, mbh, 64, fah, tid);
+            gload_direct<TN, 4, BK, true>(Bg, Wld, kn, nb, TN, fb, tid);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            double ah[2], b[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ah[i] = lds.Ah[kk + lk][m0 + 16 * i + lr + lds_skew(kk)];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[j] = lds.Bs[kk + lk][n0 + 16 * j + lr + lds_skew(kk)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acch[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[i], b[j], acch[i][j], 0, 0, 0);
+        }
+    }
+    // sum of squares over the rows: predict_tile's tree for a 64-row block held by two wave rows (one chain over a wave's
+    // two m-tiles = 32 rows, the lane groups, then rows 0-31 + rows 32-63)
+    double* red = &lds.Bs[0][0];                       // [2 wave rows][TN]: BK * (TN + 16) doubles are plenty
+    double sh_[NJ], sl_[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        double v = 0.0, u = 0.0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v = fma(acch[i][j][r], acch[i][j][r], v); u = fma(accl[i][j][r], accl[i][j][r], u); }
+        v += __shfl_xor(v, 16); u += __shfl_xor(u, 16);
+        v += __shfl_xor(v, 32); u += __shfl_xor(u, 32);
+        sh_[j] = v; sl_[j] = u;
+    }
+    __syncthreads();                                   // all waves are done reading the operand tiles
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) red[wm * TN + n0 + 16 * j + lane] = sh_[j];
+    }
+    __syncthreads();
+    if (tid < TN) spart[((int64_t)ibh * P + p) * Wld + nb + tid] = red[tid] + red[TN + tid];
+    if (!fold) return;
+    __syncthreads();
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) red[wm * TN + n0 + 16 * j + lane] = sl_[j];
+    }
+    __syncthreads();
+    if (tid < TN) spart[((int64_t)ibl * P + p) * Wld + nb + tid] = red[tid] + red[TN + tid];
 }
 
 __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ mpart, const double* __restrict__ spart,
@@ -677,6 +819,17 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
                                ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xcd_rows, ctx->tile_counter,
                                (unsigned)nblocks, ctx->tile_trace, ctx->tri_skip, nrows_dev);
 
+        else if (ctx->fold_tiles && T == 64 && TN <= 64 && nwv == 4 && !ctx->tile_trace) {
+            // folded row-block pairs (k_predict_fold): P * ceil(nI / 2) groups in contiguous ranges per XCD, nW units each
+            const int64_t G = (int64_t)ctx->P * ((nI + 1) / 2);
+            const unsigned fgrid = (unsigned)(8 * ((G + 7) / 8) * nW);
+            if (TN == 32)
+                hipLaunchKernelGGL((k_predict_fold<32>), dim3(fgrid), dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT,
+                                   ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, nrows_dev);
+            else
+                hipLaunchKernelGGL((k_predict_fold<64>), dim3(fgrid), dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT,
+                                   ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, nrows_dev);
+        }
         else if (T == 128) { if (nwv == 8) GPB_PRED(128, 8, 128, 16); else GPB_PRED(128, 4, 128, 16); }
         else if (TN == 32) GPB_PRED(64, 4, 32, 16);
         else if (TN == 128) GPB_PRED(64, 4, 128, 16);

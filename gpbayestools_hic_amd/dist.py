@@ -51,17 +51,29 @@ class WalkerSharding:
     def enable_direct(self, engine):
         """Route the all-gather through the C ABI's own RCCL communicator (gpb_dist_*: ncclAllGather enqueued
         directly on the kernels' stream, no second stream and no event hops).  Collective: rank 0 creates the
-        ncclUniqueId, torch.distributed carries it to the others.  bench.py goes through try_direct (below)."""
-        uid = None
+        ncclUniqueId, torch.distributed carries it to the others.  ncclCommInitRank is itself collective — a rank
+        that never reaches it leaves the others blocked inside it — so the ranks first VOTE, through
+        torch.distributed, that every one of them has loaded librccl and holds the id; only a unanimous vote
+        enters gpb_dist_init.  Raises (on every rank alike) when the vote fails.  bench.py goes through
+        try_direct (below)."""
+        uid, why = None, None
         if self.rank == 0:
             try:
                 uid = engine.dist_uid()
-            except Exception:           # still take part in the broadcast: every rank must see the same outcome
-                uid = None
+            except Exception as e:      # still take part in the broadcast: every rank must see the same outcome
+                uid, why = None, "rank 0 could not create a ncclUniqueId: %s" % e
         box = [uid]
         self.dist.broadcast_object_list(box, src=0, group=self.group)
-        if box[0] is None:
-            raise RuntimeError("rank 0 could not create a ncclUniqueId (librccl not loadable?)")
+        ready = box[0] is not None and len(bytes(box[0])) == 128
+        if ready:
+            try:
+                ready = bool(engine.dist_available())
+                if not ready:
+                    why = "librccl could not be loaded on rank %d" % self.rank
+            except Exception as e:
+                ready, why = False, "%s: %s" % (type(e).__name__, e)
+        if not self._all_ok(ready):     # nobody has entered ncclCommInitRank yet: all ranks leave together
+            raise RuntimeError(why or "the direct RCCL path is not available on every rank (no communicator was created)")
         engine.dist_init(self.rank, self.world, box[0])
         self.direct = engine
         return self

@@ -333,6 +333,7 @@ class Emulator:
     # ------------------------------------------------------------------ engine lifetime
     def _new_engine(self):
         if self._engine is not None:
+            self._engine._check_pid()
             self._engine.close()
         eng = GPEngine(self.device)
         eng.set_data(self._X_train, self._Z_train, _KERNELS[self.kernel_type_][0], self.alpha)
@@ -341,7 +342,11 @@ class Emulator:
         return eng
 
     def _engine_ready(self):
-        """(Re)create the device state after unpickling / in a forked worker."""
+        """(Re)create the device state after unpickling, or in a worker forked BEFORE the parent touched the GPU.  A
+        worker forked afterwards inherits a live handle on a context that did not survive the fork (the reference's
+        pocoMC `pool=int`, src/mcmc.py:775-776,798-804): RuntimeError, before any HIP call."""
+        if self._engine is not None:
+            self._engine._check_pid()
         if self._engine is None:
             if not self._trained:
                 raise RuntimeError("Emulator is not trained")

@@ -4,6 +4,7 @@ emulator resident in HBM, plus its observable transform and likelihood block.
 Host code only moves arguments; every number is produced by the HIP kernels.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -32,14 +33,15 @@ class GPEngine:
         rc = self.lib.gpb_ctx_create(int(device), None, C.byref(h))
         if rc != 0:
             raise nat.GPBError(f"gpb_ctx_create failed ({rc})")
-        self.h = h
+        self._pid = os.getpid()          # device state does not survive a fork: see _check_pid
+        self._h = h
         self.device = int(device)
         self._follow_torch = stream == "torch"
         self._stream = None
         if self._follow_torch:
             self._track_stream()
         elif stream is not None:
-            self._ck(self.lib.gpb_ctx_set_stream(h, nat.VP(int(stream))))
+            self._ck(self.lib.gpb_ctx_set_stream(self.h, nat.VP(int(stream))))
         self.N = self.d = self.P = self.M = 0
 
     # ------------------------------------------------------------------ plumbing
@@ -48,10 +50,27 @@ class GPEngine:
             raise nat.GPBError(f"{self.lib.gpb_last_error(self.h).decode()} (code {rc})")
         return rc
 
+    def _check_pid(self):
+        """A process forked AFTER this engine was created inherits the handle but not a usable HIP context (the
+        runtime's state does not survive fork()): the reference's pocoMC `pool=int` workers are such processes
+        (src/mcmc.py:775-776, 798-804).  Raise before any HIP call is issued on the dead context."""
+        if self._pid != os.getpid():
+            raise RuntimeError(
+                "GPEngine was created in process %d, this is process %d: the GPU context does not survive a fork. "
+                "Log-probability batches are already vectorised on the device — use pool=None, or start workers with "
+                "the 'spawn' method before the parent touches the GPU" % (self._pid, os.getpid()))
+
+    @property
+    def h(self):
+        """the gpb_ctx handle every C-ABI call takes: handing it out is where the fork guard sits"""
+        self._check_pid()
+        return self._h
+
     def close(self):
-        if getattr(self, "h", None):
-            self.lib.gpb_ctx_destroy(self.h)
-            self.h = None
+        if getattr(self, "_h", None):
+            if getattr(self, "_pid", None) == os.getpid():       # never issue HIP calls on a context inherited by fork
+                self.lib.gpb_ctx_destroy(self._h)
+            self._h = None
 
     def __del__(self):
         try:
@@ -60,9 +79,11 @@ class GPEngine:
             pass
 
     def sync(self):
+        self._check_pid()
         self._ck(self.lib.gpb_sync(self.h))
 
     def _need_data(self):
+        self._check_pid()
         if self.N == 0:
             raise nat.GPBError("no GP data: call set_data / set_theta / factor first")
 
@@ -72,6 +93,7 @@ class GPEngine:
         changed since the last call (`with torch.cuda.stream(s):`, a sampler on a side stream) the context is
         re-targeted onto it (gpb_ctx_set_stream drains the old stream first, so work already enqueued is ordered
         before anything that follows)."""
+        self._check_pid()
         if not self._follow_torch:
             return
         import torch
@@ -120,6 +142,7 @@ class GPEngine:
     # ------------------------------------------------------------------ GP state
     def set_data(self, X, Z, kernel="RBF", alpha=0.1):
         """X[N,d] design, Z[P,N] targets (one row per GP)."""
+        self._check_pid()
         X, Z = nat.f64(X), nat.f64(Z)
         self.N, self.d = X.shape
         self.P = Z.shape[0]
@@ -344,6 +367,10 @@ class GPEngine:
         return rec[:n.value]
 
     # ------------------------------------------------------------------ RCCL without torch.distributed
+    def dist_available(self):
+        """True when librccl loads with the entry points gpb_dist_* use (no communicator is created)"""
+        return self.lib.gpb_dist_available() == 1
+
     def dist_uid(self):
         """128-byte ncclUniqueId (rank 0 creates it and hands it to the other ranks out of band)."""
         uid = np.zeros(128, dtype=np.uint8)
@@ -390,7 +417,7 @@ class GPEngine:
 
     def tune(self, key, value):
         """launch-geometry hook of the predict kernel: 'xcd', 'wgs64', 'waves', 'wgs128w8'."""
-        k = {"xcd": 0, "wgs64": 1, "waves": 2, "wgs128w8": 3, "chol_outer": 4, "resident": 5, "wgs32": 6, "narrow_switch": 7, "mvn_wg_switch": 8, "chol_inner_tile": 9, "tile_priority": 10, "fuse_finalize": 11, "trtri_tile": 12, "resident_occ": 13, "syrk_tile": 14, "wgs64x128": 16, "tri_skip": 17, "kcross_dot": 18, "kcross_chunks": 19, "kcross_wpl": 20, "static64": 21, "mid_switch": 22, "lowrank": 23, "chol_algo": 24, "chol_lookahead": 25, "sim_ranks": 26, "compact": 27, "tile_by_live": 28, "premark": 29, "fuse_accept_propose": 30, "sim_rank": 32, "tile_switch_c": 33, "mid_switch_c": 34, "narrow_switch_c": 35, "balance_shards": 36, "mma_pipe": 37}[key]
+        k = {"xcd": 0, "wgs64": 1, "waves": 2, "wgs128w8": 3, "chol_outer": 4, "resident": 5, "wgs32": 6, "narrow_switch": 7, "mvn_wg_switch": 8, "chol_inner_tile": 9, "tile_priority": 10, "fuse_finalize": 11, "trtri_tile": 12, "resident_occ": 13, "syrk_tile": 14, "wgs64x128": 16, "tri_skip": 17, "kcross_dot": 18, "kcross_chunks": 19, "kcross_wpl": 20, "static64": 21, "mid_switch": 22, "lowrank": 23, "chol_algo": 24, "chol_lookahead": 25, "sim_ranks": 26, "compact": 27, "tile_by_live": 28, "premark": 29, "fuse_accept_propose": 30, "sim_rank": 32, "tile_switch_c": 33, "mid_switch_c": 34, "narrow_switch_c": 35, "balance_shards": 36, "mma_pipe": 37, "fold_tiles": 38}[key]
         self._ck(self.lib.gpb_debug_tune(self.h, k, int(value)))
 
     def force_generic_mvn(self, on=True):

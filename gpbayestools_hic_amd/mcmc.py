@@ -34,6 +34,7 @@ def _utility_engine(device=0):
     global _util_engine
     if _util_engine is None:
         _util_engine = GPEngine(device)
+    _util_engine._check_pid()            # created in the parent of a fork: RuntimeError before any HIP call
     return _util_engine
 
 
@@ -318,6 +319,12 @@ class Chain:
         the likelihood callback is this class's device-backed log_likelihood(finite=True)."""
         import pocomc
         from scipy.stats import uniform
+        if pool is not None:
+            # the reference hands `pool=12` to pocoMC, whose workers are FORKED copies of this Chain
+            # (src/mcmc.py:775-776, 798-804; examples/RunBayesianAnalysis.ipynb:85).  Here the whole 8192-row batch is
+            # one device call (vectorize=True); forked workers could not use the parent's GPU context anyway.
+            log.info("run_pocoMC: pool=%r ignored — likelihood batches are already vectorised on the device", pool)
+            pool = None
         if prior is None:
             prior = pocomc.Prior([uniform(self.min[i], self.max[i] - self.min[i]) for i in range(self.ndim)])
         elif self.ndim != prior.dim:

@@ -111,11 +111,18 @@ class StretchSampler:
             cc = [eng], (nat.C.c_void_p * 1)(eng.h)
         return eng, cc[1], len(cc[0])
 
-    def _check_nan(self, eng):
+    def _nan_count(self, eng):
+        """NaN log-probabilities the accept kernels have counted since the last call (synchronises; resets the counter)"""
         n = nat.c_i64(0)
         eng._ck(eng.lib.gpb_stretch_nan_count(eng.h, nat.C.byref(n), 1))
-        if n.value:
-            raise ValueError("Probability function returned NaN")       # emcee's contract (emcee/ensemble.py)
+        return n.value
+
+    def _snapshot(self):
+        return (self.pos.clone(), self.lp.clone(), self.naccept.clone(), self.iterations, self._step_counter)
+
+    def _restore(self, snap):
+        self.pos.copy_(snap[0]); self.lp.copy_(snap[1]); self.naccept.copy_(snap[2])
+        self.iterations, self._step_counter = snap[3], snap[4]
 
     def run(self, X0, nsteps, status=None, store=True):
         """Advance `nsteps` stretch-move steps from X0[nwalkers, ndim]; returns the final positions
@@ -137,9 +144,22 @@ class StretchSampler:
         if status is None:
             status = max(nsteps // 10, 1)
         res = self._resident_engine()
+        if res is not None and self.sharding is not None:
+            # sharded C loop: whatever can fail on ONE rank (state checks, workspace allocation) is done now, and the
+            # ranks agree on the outcome BEFORE any of them enqueues the in-stream all-gathers of gpb_chain_emcee_run —
+            # a rank that failed inside that call would leave its peers waiting in a collective that never completes
+            rc = res[0].lib.gpb_chain_emcee_prepare(res[1], res[2], nw)
+            agree = getattr(self.sharding, "_all_ok", None) if getattr(self.sharding, "world", 1) > 1 else None
+            if not (agree(rc == 0) if agree is not None else rc == 0):
+                if rc != 0:
+                    res[0]._ck(rc)
+                raise RuntimeError("gpb_chain_emcee_prepare failed on another rank; no collective was enqueued")
+        ceng = res[0] if res is not None else eng
+        self._nan_count(ceng)       # the counter is per context: whatever an earlier, aborted user left behind is not ours
         n = 0
         while n < nsteps:
             m = min(status - n % status, nsteps - n)          # up to the next status line
+            snap = self._snapshot()                           # device copies (nwalkers x ndim doubles): see the NaN check below
             if res is not None:
                 # the C ABI enqueues all m steps itself (gpb_emcee_run): propose -> GP predict -> block likelihood +
                 # prior box -> [in-stream all-gather] -> accept, no Python in between
@@ -168,7 +188,15 @@ class StretchSampler:
             n += m
             self.iterations += m
             if n % status == 0 or n == nsteps:
-                self._check_nan(res[0] if res is not None else eng)          # synchronises: once per status line
+                # emcee raises "Probability function returned NaN" at the offending step with its state untouched
+                # (emcee/ensemble.py); the device loop rejects and counts such proposals and the count is read once per
+                # status block (one synchronisation): on a NaN the sampler goes back to the state in front of the block
+                bad = self._nan_count(ceng)
+                if bad:
+                    self._restore(snap)
+                    raise ValueError("Probability function returned NaN (%d proposal(s) within steps %d..%d of this run; "
+                                     "the sampler is back at its state before step %d and nothing of this call was stored)"
+                                     % (bad, n - m + 1, n, n - m + 1))
                 af = self.acceptance_fraction
                 log.info("step %d: acceptance fraction: mean %.4f, std %.4f, min %.4f, max %.4f",
                          n, af.mean(), af.std(), af.min(), af.max())

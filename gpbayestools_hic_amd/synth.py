@@ -52,6 +52,18 @@ def walkers(W, d, seed=SEED + 3, lo=None, hi=None):
     return X
 
 
+def walkers_ball(W, centre, radius=1e-3, seed=SEED + 4, lo=None, hi=None):
+    """A burnt-in ensemble: walkers in a small Gaussian ball around `centre` (what the reference's run_mcmc holds after
+    re-seeding at its best points, src/mcmc.py:392-405), kept strictly inside the box [lo, hi] (default: the unit cube)."""
+    centre = np.asarray(centre, dtype=np.float64)
+    d = centre.shape[0]
+    lo = np.zeros(d) if lo is None else np.asarray(lo, dtype=np.float64)
+    hi = np.ones(d) if hi is None else np.asarray(hi, dtype=np.float64)
+    span = hi - lo
+    X = centre + radius * span * np.random.default_rng(seed).standard_normal((W, d))
+    return np.clip(X, lo + 1e-6 * span, hi - 1e-6 * span)
+
+
 def fixed_theta(d, P, c=1.0, ell=1.5, noise=0.05):
     """Timing-run hyper-parameters: c=1, l_j=1.5, sigma_n^2=0.05."""
     th = np.concatenate([[np.log(c)], np.full(d, np.log(ell)), [np.log(noise)]])

@@ -213,12 +213,20 @@ int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev, double* lp
                         uint64_t seed, uint64_t step0, double a, int randomize_split,
                         const double* lo_dev, const double* hi_dev, double outside_value, double inside_const,
                         double* chain_dev, double* lpchain_dev, int64_t* naccept_dev);
+/* gpb_chain_emcee_prepare: everything of gpb_chain_emcee_run that can fail on one rank alone — argument and state checks,
+ * workspace allocation — and nothing that is enqueued.  A sharded caller runs it on every rank and lets the ranks agree on
+ * the outcome (an all-reduce of the return codes) BEFORE any rank calls gpb_chain_emcee_run: a rank that failed there
+ * would leave the others waiting inside the in-stream all-gather. */
+int gpb_chain_emcee_prepare(gpb_ctx* const* ctxs, int E, int64_t nwalkers);
 
 /* ---- walker sharding over RCCL (one process per GPU) ------------------------------ *
  * gpb_dist_uid: rank 0 obtains a 128-byte ncclUniqueId to broadcast out of band.
  * gpb_dist_init / gpb_dist_allgather: in-stream ncclAllGather of per-walker
  * log-posteriors (count doubles per rank) — the one exchange per log-prob batch.
  */
+/* gpb_dist_available: 1 when librccl loads with the four entry points used here (no communicator is created): ranks
+ * vote on it before gpb_dist_init, whose ncclCommInitRank is itself collective. */
+int gpb_dist_available(void);
 int gpb_dist_uid(void* uid128_host);
 int gpb_dist_init(gpb_ctx* ctx, int rank, int nranks, const void* uid128_host);
 int gpb_dist_allgather(gpb_ctx* ctx, const double* send_dev, double* recv_dev, int64_t count);

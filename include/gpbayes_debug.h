@@ -74,7 +74,8 @@ int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
  * 64x64; tiles per 256 CUs) for compacted batches; 36 = a sharded gpb_chain_emcee_run gives every rank an equal slice of
  * the ordered list of all rows inside the box (2: always, 1, default: from 8 ranks on) or the rows inside the box of a
  * contiguous share (0); 37 = the 128x128 predict tile reads the next k-group's LDS fragments before the current group's
- * MFMAs (1, default) or as the compiler orders them (0). */
+ * MFMAs (1, default) or as the compiler orders them (0); 38 = the 64x32 / 64x64 predict tiles run as folded pairs of row
+ * blocks, one equal-length K loop per workgroup (k_predict_fold: 1, default) or one tile per workgroup (0). */
 int gpb_debug_tune(gpb_ctx* ctx, int key, int value);
 /* debug hook: per-tile placement and timing of the predict kernel.  capacity > 0 arms (and clears) a trace of
  * that many records, 0 disarms; read copies up to max_records records of 8 uint32 {HW_ID register, XCC_ID,

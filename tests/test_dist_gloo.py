@@ -172,6 +172,10 @@ class _FakeDirectEngine:
         self._maybe("uid")
         return b"u" * 128
 
+    def dist_available(self):
+        self.calls.append("available")
+        return not (self.rank == self.fail_rank and self.fail_at == "available")      # librccl missing on one rank
+
     def dist_init(self, rank, world, uid):
         assert uid == b"u" * 128
         self._maybe("init")
@@ -195,8 +199,9 @@ def _many_worker(rank, world, port, q):
     g, fn = _oracle_logpost()
     res = {}
     # (scenario, failing rank, stage): every rank must come out with the SAME decision and the same numbers
-    for name, fail_rank, stage in (("ok", -1, None), ("uid", 0, "uid"), ("init", world - 1, "init"),
-                                   ("allgather", 1, "allgather"), ("wrong", world // 2, "wrong")):
+    for name, fail_rank, stage in (("ok", -1, None), ("uid", 0, "uid"), ("available", world - 2, "available"),
+                                   ("init", world - 1, "init"), ("allgather", 1, "allgather"),
+                                   ("wrong", world // 2, "wrong")):
         sh = WalkerSharding()
         eng = _FakeDirectEngine(rank, fail_rank, stage)
         why = sh.try_direct(eng)
@@ -216,7 +221,7 @@ def _many_worker(rank, world, port, q):
 def test_walker_sharding_more_ranks_and_direct_handshake(world):
     """world 4 and 8 over gloo with the CPU oracle as the evaluator: the sharded vector equals the unsharded one on
     every rank, and WalkerSharding.try_direct keeps the C-ABI collective only when it worked on ALL ranks — a rank
-    that fails at any stage (no uid, communicator refused, collective raises, collective returns wrong data) makes
+    that fails at any stage (no uid, no librccl, communicator refused, collective raises, collective returns wrong data) makes
     every rank fall back to torch.distributed, after the same number of collectives on each."""
     port = _free_port()
     ctx = mp.get_context("spawn")
@@ -232,7 +237,7 @@ def test_walker_sharding_more_ranks_and_direct_handshake(world):
     for W in (64, 37, 3):
         X = torch.from_numpy(np.ascontiguousarray(g["Xw"][:W]))
         refs[W] = fn(X, torch.empty(W, dtype=torch.float64)).numpy()
-    for name in ("ok", "uid", "init", "allgather", "wrong"):
+    for name in ("ok", "uid", "available", "init", "allgather", "wrong"):
         kept = {got[r][name][1] for r in range(world)}
         assert kept == ({True} if name == "ok" else {False}), (name, kept)       # unanimous
         for r in range(world):
@@ -248,5 +253,11 @@ def test_walker_sharding_more_ranks_and_direct_handshake(world):
             # a communicator that was built is torn down again wherever the hand-shake is called off
             built = name in ("allgather", "wrong") or (name == "init" and r != world - 1)
             assert ("finalize" in calls) == built, (name, r, calls)
+            # ncclCommInitRank is itself collective: when a rank has no id or no librccl the ranks vote BEFORE it and
+            # NO rank enters it (one alone inside it would block for good)
+            if name in ("uid", "available"):
+                assert "init" not in calls, (name, r, calls)
+            else:
+                assert "init" in calls, (name, r, calls)
     # in the good case the direct path really carried the even-split batches
     assert all("allgather" in got[r]["ok"][3] for r in range(world))

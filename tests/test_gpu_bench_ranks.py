@@ -1,0 +1,54 @@
+"""GPU tier: bench.py's N > 1 branch (SURVEY §4 tier 4).  The build box has ONE GPU, so the two ranks share it and the
+exchange is torch.distributed over gloo (GPB_DIST_BACKEND=gloo; RCCL refuses two ranks on one device): everything of the
+sharded bench except the wire runs — rendezvous, WalkerSharding, the per-rank row shares, the max-over-ranks timing, the
+consistency check — and the ensemble after the same steps must equal the single-GPU run's bit for bit."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+ARGS = ["--steps", "4", "--warmup", "2", "--no-extras", "--no-cpu-baseline"]
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _run(cmd, env):
+    r = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]              # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_on_one_gpu_equal_the_single_gpu_run():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS, env)
+    env2 = dict(env, GPB_DIST_BACKEND="gloo")
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + ARGS, env2)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert one["config"]["step_loop"] == "gpb_chain_emcee_run"
+    assert two["config"]["step_loop"] == "host-driven"               # no in-stream RCCL collective under gloo
+    assert two["config"]["parallelism"] == "walker-shard x2" and "gloo" in two["config"]["allgather"]
+    assert two["ranks_hold_identical_ensemble"] is True and one["ranks_hold_identical_ensemble"] is None
+    # replicated draws + gathered log-probabilities: the sharded ensemble IS the unsharded one
+    assert two["ensemble_checksum"] == one["ensemble_checksum"]
+    assert two["acceptance_fraction"] == one["acceptance_fraction"]
+    for out in (one, two):
+        assert out["scaling"] == "strong" and out["steps"] == 4 and out["warmup"] == 2 and out["dtype"] == "f64"
+        assert out["rows_inside_box_fraction"] >= 0.95               # burnt-in: every proposal row is evaluated ...
+        assert abs(out["value_evaluated"] / out["value"] - out["rows_inside_box_fraction"]) < 1e-9
+        assert out["tflops_algorithmic"] <= 78.6                     # ... and the headline stays under the fp64 peak
+        uni = out["extras"]["uniform_start"]
+        assert 0.3 < uni["rows_inside_box_fraction"] < 0.7 and uni["value_evaluated"] < uni["value"]
+    # both ranks evaluated half of every batch
+    assert two["roofline"]["launches"] == one["roofline"]["launches"]

@@ -162,7 +162,9 @@ def test_cfg5_run_pocomc_8192_row_likelihood_batches(cfg5, monkeypatch):
     fake = types.ModuleType("pocomc")
     fake.Sampler, fake.Prior = _RecordingSampler, _Prior
     monkeypatch.setitem(sys.modules, "pocomc", fake)
-    chain.run_pocoMC(n_effective=512, n_active=256, n_prior=8192, n_total=1000, n_evidence=0, pool=None)
+    # the reference's notebooks pass pool=12 (examples/RunBayesianAnalysis.ipynb:85): pocoMC would FORK workers that
+    # inherit this chain; here the batch is already one device call and pool=None reaches the sampler
+    chain.run_pocoMC(n_effective=512, n_active=256, n_prior=8192, n_total=1000, n_evidence=0, pool=12)
     smp = _RecordingSampler.last
     # the call shape of the reference (src/mcmc.py:798-805)
     kw = smp.kw

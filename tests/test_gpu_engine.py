@@ -324,7 +324,17 @@ def test_predict_tile_sizes_are_bit_identical(eng):
                     eng.tune("resident", order)
                     m2, v2 = eng.predict(Xs)
                     assert np.array_equal(m1, m2) and np.array_equal(v1, v2), (tile, xcd, order)
-        eng.force_tile(0); eng.tune("xcd", -1); eng.tune("resident", 2)
+        eng.tune("xcd", -1); eng.tune("resident", 2)
+        # folded pairs of row blocks (k_predict_fold, the default for the 64x32 / 64x64 shapes above) against one tile per
+        # workgroup: same MFMA sequence per (row block, walker), same tree; 7 row blocks leave the middle one unpaired
+        for tile in (32, 64):
+            eng.force_tile(tile)
+            for fold in (0, 1):
+                eng.tune("fold_tiles", fold)
+                for W in (300, 32, 1):
+                    m2, v2 = eng.predict(Xs[:W])
+                    assert np.array_equal(m1[:W], m2) and np.array_equal(v1[:W], v2), (tile, fold, W)
+        eng.force_tile(0)
 
 
 def test_predict_tile_trace_covers_every_tile_once(eng):
@@ -338,7 +348,7 @@ def test_predict_tile_trace_covers_every_tile_once(eng):
     eng.force_tile(64)
     for order in (2, 0):                                   # static snake launch / persistent ticket queues
         eng.tune("resident", order)
-        eng.tile_trace(4096)
+        eng.tile_trace(4096)                               # (an armed trace selects the one-tile-per-workgroup kernels)
         eng.predict(Xs)
         rec = eng.tile_trace_read()
         eng.tile_trace(0)

@@ -167,5 +167,60 @@ def test_c_loop_shapes_many_parameters_and_tiny_ensembles(tmp_path, d, nws):
         eng.tune("sim_ranks", 2); eng.tune("sim_rank", 1); eng.tune("balance_shards", 2)
         s = StretchSampler(chain, nw, seed=1)
         s.run(X0, 3, status=10)
-        eng.tune("sim_ranks", 0); eng.tune("sim_rank", 0); eng.tune("balance_shards", 1)
+        eng.tune("sim_ranks", 0); eng.tune("sim_rank", 0); eng.tune("balance_shards", 0)
         assert np.isfinite(s.chain).all()
+
+
+def test_chain_with_more_than_64_parameters(tmp_path):
+    """The GPs' own input dimension is bounded by 64 (gpb_gp_set), the CHAIN's is not: a parameterTrafoPCA emulator
+    (src/emulator.py:79-241, 492-551) maps d_in chain parameters to d_out GP inputs, and with one principal component
+    per group 70 parameters become 63.  The C-driven loop's proposal kernels gather the rows inside the box lane by
+    lane (two parameters per lane in registers, the rest recomputed) and the marking kernel stages its rows in column
+    tiles: same ensemble as the host-driven loop, same log-posterior as the per-emulator calls."""
+    from conftest import golden
+    from gpbayestools_hic_amd import Chain, Emulator, StretchSampler, synth
+    g = golden("g7_param_pca.npz")
+    d = 70
+    lo, hi = np.concatenate([g["lo"], np.zeros(d - 20)]), np.concatenate([g["hi"], np.ones(d - 20)])
+    X = synth.lhs(80, d, seed=5, lo=lo, hi=hi)
+    mid = 0.5 * (lo + hi)
+    for group in ([15, 16, 17, 18], [12, 13, 14], [2, 3, 4]):          # one varying parameter per group: one PC each
+        X[:, group[1:]] = mid[group[1:]]
+    Y = synth.observables((X - lo) / (hi - lo), 6, seed=11)
+    tp, pf, ep = str(tmp_path / "t.pkl"), str(tmp_path / "p.txt"), str(tmp_path / "e.pkl")
+    synth.write_training_pickle(tp, X, Y, 0.01)
+    synth.write_parameter_file(pf, lo, hi)
+    emu = Emulator(training_set_path=tp, parameter_file=pf, npc=3, parameterTrafoPCA=True)
+    assert emu.PCA_new_design_points.shape == (80, 63)
+    emu.trainEmulator([True] * emu.nev, thetas=synth.fixed_theta(63, 3, ell=3.0))
+    yexp = emu.predict(mid[None], return_cov=False)[0]
+    synth.write_experiment_pickle(ep, yexp, 0.05 * np.abs(yexp))
+    chain = Chain(mcmc_path=str(tmp_path / "mcmc" / "c.pkl"), expdata_path=ep, model_parafile=pf)
+    chain.emuList = [emu]
+    rng = np.random.default_rng(3)
+    Xq = lo + (hi - lo) * rng.uniform(-0.002, 1.002, (600, d))          # 70 parameters: ~3/4 of the rows stay inside
+    one = chain.log_posterior(Xq)
+    ins = np.all((Xq > lo) & (Xq < hi), axis=1)
+    assert 100 < ins.sum() < 590 and np.array_equal(np.isfinite(one), ins)
+    chain.use_chain_call = False
+    assert np.array_equal(chain.log_posterior(Xq), one)
+    chain.use_chain_call = True
+    # against the host arithmetic of the same emulator (Emulator.predict maps the parameters with numpy)
+    from oracle import gp_oracle as O
+    mean, cov = emu.predict(Xq[ins][:8], return_cov=True, extra_std=0.0)
+    ref = np.array([O.mvn_loglike(m - chain.expdata[0], c + chain.expdata_cov) for m, c in zip(mean, cov)]) + O.EXTRA_STD_CONST
+    assert relerr(one[ins][:8], ref) < 1e-10
+    for nw in (6, 300):
+        X0 = np.clip(mid + 0.05 * (hi - lo) * rng.standard_normal((nw, d)), lo - 0.01 * (hi - lo), hi + 0.01 * (hi - lo))
+        for premark in (2, 1, 0):
+            emu._engine_ready().tune("premark", premark)
+            c = StretchSampler(chain, nw, seed=nw)
+            assert c._resident_engine() is not None
+            c.run(X0, 4, status=2)
+            if premark == 2:
+                h = StretchSampler(chain, nw, seed=nw)
+                h._resident_engine = lambda: None
+                h.run(X0, 4, status=2)
+            assert np.array_equal(c.chain, h.chain) and np.array_equal(c.lnprobability, h.lnprobability), (nw, premark)
+        emu._engine_ready().tune("premark", 2)
+        assert c.acceptance_fraction.mean() > 0.0

@@ -5,7 +5,7 @@ does — and, with a one-rank RCCL communicator installed, still enqueues the tw
 (ncclAllGather on the kernels' stream: launch and protocol cost without a wire).  Also: the same share through the
 host-driven loop (Python enqueues every kernel), to show what the C loop removes.
 
-    python tools/gpu_shard_sim.py [R ...] [--c-only] [--cfg=5]         # default 1 2 4 8
+    python tools/gpu_shard_sim.py [R ...] [--c-only] [--cfg=5] [--ball=1e-3]        # default 1 2 4 8, uniform start
 """
 import json
 import os
@@ -62,6 +62,10 @@ def main():
         if a.startswith("--walkers="):
             nw = int(a[10:])
     X0 = synth.walkers(nw, info["d"])
+    for a in sys.argv[1:]:
+        if a.startswith("--ball="):                  # burnt-in start: walkers in a ball of this relative radius around theta*
+            X0 = synth.walkers_ball(nw, info["xstar"], float(a[7:]))
+            print(json.dumps({"start": "ball", "radius": float(a[7:])}), flush=True)
     c_only = "--c-only" in sys.argv
     worlds = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [1, 2, 4, 8]
     comm = False
