@@ -136,7 +136,85 @@ def extras(chain4, emu4, info4):
                   c5["kernel"], 0.1)
     eng5.set_theta(synth.fixed_theta(c5["d"], c5["P"]))
     out["fit_fixed_theta_cfg5"] = fit_entry(eng5, c5["N"], c5["P"], c5["kernel"])
+
+    def k_build_entry(eng, Nn, dd, Pp, kernel):
+        """K(X,X) + (noise + alpha) I of all GPs (k_kmat_mfma): the lower block triangle is all the factorisation reads.
+        Bound: the slower of the HBM write of 4 N^2 bytes per GP and the fp64 vector work of N^2 / 2 pairs at
+        F_pair = 3d + 3 (RBF) / 3d + 10 (Matern-5/2) flops."""
+        t = timed(lambda: eng.fit_piece("kmat"), 20)
+        eng.factor()
+        byts = 4.0 * Nn * Nn * Pp
+        fpair = 3 * dd + 3 if kernel == "RBF" else 3 * dd + 10
+        flops = 0.5 * Nn * Nn * fpair * Pp
+        t_hbm, t_valu = byts / 8e12, flops / (FP64_MFMA_PEAK_TFLOPS * 1e12)
+        bound = "hbm" if t_hbm >= t_valu else "fp64 valu"
+        return {"N": Nn, "d": dd, "gps": Pp, "kernel": kernel, "us": t * 1e6,
+                "roofline": {"bound": bound, "kernel": "k_kmat_mfma", "bytes": byts, "flops": flops,
+                             "achieved": byts / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": max(t_hbm, t_valu) / t,
+                             "frac_note": "time at the binding limit (max of 4 N^2 P bytes at 8 TB/s and N^2/2 F_pair P "
+                                          "flops at 78.6 TF/s) / measured time",
+                             "valu_tflops_algorithmic": flops / t / 1e12},
+                "what": "kernel-matrix assembly for all GPs, lower block triangle (what the Cholesky reads)"}
+
+    out["k_build_cfg5"] = k_build_entry(eng5, c5["N"], c5["d"], c5["P"], c5["kernel"])
     eng5.close()
+    out["k_build_cfg4"] = k_build_entry(eng4, info4["N"], info4["d"], info4["P"], info4["kernel"])
+
+    # log-marginal likelihood + gradient of all GPs at one theta (what every L-BFGS-B iteration of the hyper-parameter
+    # search costs: sk:_gpr.py:537-652): K build, Cholesky, L^-1, alpha, K^-1 = L^-T L^-1, the d + 2 derivative reductions
+    th4 = synth.fixed_theta(info4["d"], info4["P"])
+    t = timed(lambda: eng4.lml(th4), 5)
+    fl = 4.0 / 3.0 * info4["N"] ** 3 * info4["P"]
+    out["lml_grad_cfg4"] = {"N": info4["N"], "d": info4["d"], "gps": info4["P"], "ms": t * 1e3,
+                            "roofline": {"bound": "mfma", "kernel": "gpb_gp_lml: k_kmat_mfma, Cholesky chain, k_trtri_level, k_kinv, k_lml_grad",
+                                         "flops": fl, "achieved": fl / t / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
+                                         "unit": "TFLOP/s", "frac": fl / t / 1e12 / FP64_MFMA_PEAK_TFLOPS},
+                            "what": "one LML + gradient evaluation of all GPs incl. the download of value and gradient; "
+                                    "flops = P (N^3/3 Cholesky + N^3/3 inverse + 2N^3/3 K^-1) = 4/3 N^3 P"}
+    emu4._engine_ready().set_theta(emu4.thetas_)
+    emu4._engine_ready().factor()
+
+    # a chain at the size of the reference's real analyses: nine emulators with their own designs, kernels and numbers of
+    # GPs over one 20-parameter space, 540 observables, block-diagonal covariance (src/mcmc.py:153-166,
+    # examples/RunBayesianAnalysis.ipynb:35-48), 4096 walkers, the whole step loop in gpb_chain_emcee_run
+    from gpbayestools_hic_amd.sampler import StretchSampler
+    from gpbayestools_hic_amd.workload import build_multi_chain
+    specs = [(1000, 60, 6 + i % 3, ("RBF", "Matern25", "RBF")[i % 3]) for i in range(9)]
+    mchain, memus, minfo = build_multi_chain(specs, 20)
+    nwm, nst = 4096, 10
+    gps = sum(sp[2] for sp in specs)
+    nine = {"emulators": 9, "design_points_each": 1000, "params": 20, "observables": mchain.nobs, "gps": gps, "walkers": nwm}
+    for tag, X0m in (("burnt_in", synth.walkers_ball(nwm, minfo["xstar"], 1e-8)), ("uniform_start", synth.walkers(nwm, 20))):
+        sm = StretchSampler(mchain, nwm, seed=5)
+        assert sm._resident_engine() is not None
+        sm.run(X0m, 3, status=10 ** 9, store=False)
+        for e in memus:
+            e._engine_ready().profile(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sm.run(None, nst, status=10 ** 9, store=False)
+        torch.cuda.synchronize()
+        dtm = (time.perf_counter() - t0) / nst
+        kms, nl, live_rows = 0.0, 0, 0.0
+        for i, (e, sp) in enumerate(zip(memus, specs)):
+            n_l, ms_l, u_l = e._engine_ready().profile_read()
+            e._engine_ready().profile(False)
+            if i == 0:                        # the chain's first emulator owns the compaction and its live-row counter
+                live_rows = u_l / sp[2]
+            kms += ms_l
+            nl += n_l
+        units = gps * live_rows * 1024.0 ** 2      # (GP, row) pairs x Np^2 (1000 design points pad to 1024)
+        nine[tag] = {"ms_per_step": dtm * 1e3, "walker_evals_per_s": nwm / dtm,
+                     "rows_inside_box_fraction": units / 1024.0 ** 2 / (gps * nwm * nst),
+                     "k_predict_launches_per_step": nl / nst, "k_predict_ms_per_step": kms / nst,
+                     "k_predict_tflops": units / (kms * 1e-3) / 1e12 if kms else None,
+                     "k_predict_frac_of_peak": units / (kms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS if kms else None}
+        del sm
+    nine["what"] = ("stretch-move steps of a nine-emulator chain through gpb_chain_emcee_run; k_predict figures: algorithmic "
+                    "flops Np^2 per evaluated (GP, row) over the summed HIP-event times of the nine launches per half-step")
+    out["nine_emulator_chain"] = nine
+    for e in memus:
+        e._engine.close()
     return out
 
 

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgpbayes.so")
+# GPB_DEBUG_LIB=1 (the sweeps in tools/): the build with every measured-and-rejected kernel variant behind its tune key
+LIB_PATH = os.path.join(HERE, "libgpbayes_debug.so" if os.environ.get("GPB_DEBUG_LIB") == "1" else "libgpbayes.so")
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -70,6 +71,8 @@ DEBUG = {
     "gpb_test_gemm": (C.c_int, [VP, c_i64, c_i64, c_i64, VP, VP, VP, C.c_int]),
     "gpb_debug_force_tile": (C.c_int, [VP, C.c_int, c_i64]),
     "gpb_debug_tune": (C.c_int, [VP, C.c_int, C.c_int]),
+    "gpb_debug_has_variants": (C.c_int, []),
+    "gpb_debug_fit_piece": (C.c_int, [VP, C.c_int]),
     "gpb_debug_force_generic_mvn": (C.c_int, [VP, C.c_int]),
     "gpb_debug_tile_trace": (C.c_int, [VP, c_i64]),
     "gpb_debug_tile_trace_read": (C.c_int, [VP, VP, c_i64, VP]),

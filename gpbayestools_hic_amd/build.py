@@ -6,29 +6,35 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgpbayes.so")
+LIB_DEBUG = os.path.join(HERE, "libgpbayes_debug.so")
 SOURCES = ["gpb_api.hip", "gpb_fit.hip", "gpb_chol.hip", "gpb_predict.hip", "gpb_like.hip", "gpb_cov.hip", "gpb_pmap.hip"]
-HEADERS = ["gpb_internal.h", "gemm_tile.h", "chol_block.h", os.path.join("..", "..", "include", "gpbayes.h"),
+HEADERS = ["gpb_internal.h", "gemm_tile.h", "chol_block.h", "fast_math.h", os.path.join("..", "..", "include", "gpbayes.h"),
            os.path.join("..", "..", "include", "gpbayes_debug.h")]
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def _stale(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build_native(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB
+def build_native(force=False, verbose=False, debug_variants=False):
+    """libgpbayes.so: the product library (the kernels its own rules select).  debug_variants=True: libgpbayes_debug.so,
+    the same sources with -DGPB_DEBUG_VARIANTS — every measured-and-rejected kernel variant behind its gpb_debug_tune key,
+    for the sweeps in tools/ and the variant tests (loaded with GPB_DEBUG_LIB=1)."""
+    lib = LIB_DEBUG if debug_variants else LIB
+    if not force and not _stale(lib):
+        return lib
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    bdir = os.path.join(HERE, "build", "debug" if debug_variants else "product")
+    os.makedirs(bdir, exist_ok=True)
     for src in SOURCES:
-        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        obj = os.path.join(bdir, src.replace(".hip", ".o"))
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
-               os.path.join(CSRC, src), "-o", obj]
+               os.path.join(CSRC, src), "-o", obj] + (["-DGPB_DEBUG_VARIANTS"] if debug_variants else [])
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -37,12 +43,14 @@ def build_native(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stdout.decode()))
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
     print(build_native(force="--force" in sys.argv, verbose=True))
+    if "--debug-variants" in sys.argv:
+        print(build_native(force="--force" in sys.argv, verbose=True, debug_variants=True))

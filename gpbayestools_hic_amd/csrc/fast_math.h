@@ -1,0 +1,57 @@
+// fast_math.h — fp64 exp / sqrt / kernel shape functions for the K(X,X) assembly (k_kmat_mfma), where they are most of the
+// vector instructions.  (Measured in k_kcross as well, tools/gpu_shard_sim.py A/B in one process: 2.8996 vs 2.8979 ms/step at
+// 2048-row batches, 0.4359 vs 0.4349 at 256 — that kernel is bound by its LDS broadcasts, not by exp; it keeps the library forms.)  Each is within 1-2 ulp of the library form that
+// sklearn's numpy calls round to (the parity bars on kernel matrices are 1e-13 .. 1e-11).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/gpbayes.h"
+
+namespace gpb {
+
+// exp(x) for x <= 0 without the library's special-case selects, its coefficients in SGPRs (scalar loads from constant
+// memory: as immediates the compiler re-materialised them in VGPRs with two v_mov_b32 each — 12 per evaluation, a sixth of
+// the kernel's vector instructions).  n = rint(x log2 e), r = x - n ln 2 (two-term), e^r by the Taylor polynomial of degree
+// 13 (|r| <= ln 2 / 2: truncation 4e-18), 2^n by v_ldexp_f64 (underflows to 0 for n < -1074: x = -inf gives 0).
+// 1-2 ulp; numpy's exp, which sklearn calls, is within 1 ulp: 4e-16 relative between the two (the G1 / G2 bars: 1e-13, 1e-11).
+static __constant__ double EXP_C[16] = {1.4426950408889634, -6.93147180369123816490e-01, -1.90821492927058770002e-10,
+                                 1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0,
+                                 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0 / 3.0};
+__device__ __forceinline__ double exp_nonpos(double x) {
+    const double n = __builtin_rint(x * EXP_C[0]);
+    double r = fma(n, EXP_C[1], x);
+    r = fma(n, EXP_C[2], r);
+    double q = EXP_C[3];
+#pragma unroll
+    for (int k = 4; k <= 14; ++k) q = fma(q, r, EXP_C[k]);      // 1/13! ... 1/2!
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    return ldexp(q, (int)n);
+}
+// sqrt(x) for x >= 0 by v_rsq_f64 and two coupled Newton steps (Goldschmidt), 1 ulp, without the library form's scaling
+// and special-case selects (17 instructions); x is clamped to 1e-300 first (coincident points: sqrt = 1e-150, K = 1).
+__device__ __forceinline__ double sqrt_pos(double x) {
+    x = fmax(x, 1e-300);
+    const double y = __builtin_amdgcn_rsq(x);
+    double sq = x * y, h = 0.5 * y;
+    const double e = fma(-h, sq, 0.5);
+    sq = fma(sq, e, sq);
+    h = fma(h, e, h);
+    return fma(fma(-sq, sq, x), h, sq);
+}
+// shape functions of k_kmat_mfma: as shape_fn, with exp_nonpos, sqrt_pos and t^2 / 3 as a multiplication (each within
+// 1-2 ulp of the library form)
+template <int KIND>
+__device__ __forceinline__ double shape_fn_fast(double r2) {
+    if (KIND == GPB_KERNEL_RBF) {
+        return exp_nonpos(-0.5 * r2);
+    } else if (KIND == GPB_KERNEL_MATERN15) {
+        const double t = sqrt_pos(r2) * 1.7320508075688772;
+        return (1.0 + t) * exp_nonpos(-t);
+    } else {
+        const double t = sqrt_pos(r2) * 2.23606797749979;
+        return (1.0 + t + (t * t) * EXP_C[15]) * exp_nonpos(-t);
+    }
+}
+
+
+}  // namespace gpb

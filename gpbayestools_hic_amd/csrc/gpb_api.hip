@@ -723,8 +723,26 @@ extern "C" int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles
 
 // Launch-geometry knobs (never change a result); the key list is documented with the declaration in
 // include/gpbayes_debug.h and mirrored by GPEngine.tune() in engine.py.
+extern "C" int gpb_debug_has_variants(void) {
+#ifdef GPB_DEBUG_VARIANTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
     if (!ctx) return GPB_E_ARG;
+#ifndef GPB_DEBUG_VARIANTS
+    // the product library holds only the kernels its own rules select: the keys that switch to a measured-and-rejected
+    // variant exist in the debug build (libgpbayes_debug.so, -DGPB_DEBUG_VARIANTS) and are refused here
+    {
+        const bool variant = (key == 2 && value != 4) || (key == 5 && value == 0) || (key == 18 && value != 1) ||
+                             (key == 21 && value != 1) || (key == 24 && value != 1) || (key == 37 && value != 1) ||
+                             (key == 38 && value != 0) || (key == 39 && value != 1) || (key == 0 && value > 1);
+        if (variant) GPB_FAIL(GPB_E_ARG, "gpb_debug_tune: this value selects a kernel variant of the debug build only");
+    }
+#endif
     switch (key) {
         case 0: if (value < -1 || value > 3) return GPB_E_ARG; ctx->force_xcd = value; break;
         case 1: if (value < 1 || value > 8) return GPB_E_ARG; ctx->wgs_per_cu64 = value; break;
@@ -760,12 +778,30 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 36: if (value < 0 || value > 2) return GPB_E_ARG; ctx->balance_shards = value; break;
         case 37: if (value < 0 || value > 1) return GPB_E_ARG; ctx->mma_pipe = value; break;
         case 38: if (value < 0 || value > 1) return GPB_E_ARG; ctx->fold_tiles = value; break;
+        case 39: if (value < 0 || value > 1) return GPB_E_ARG; ctx->kmat_mfma = value; break;
         case 33: if (value < 0) return GPB_E_ARG; ctx->tile_switch_c = value; break;
         case 34: if (value < 0) return GPB_E_ARG; ctx->mid_switch_c = value; break;
         case 35: if (value < 0) return GPB_E_ARG; ctx->narrow_switch_c = value; break;
         default: return GPB_E_ARG;
     }
     return 0;
+}
+
+// Measurement hook: enqueue ONE piece of the fit on the context's stream (0 = K(X,X) assembly, 1 = blocked Cholesky of the
+// K that is there, 2 = triangular inverse, 3 = alpha) so that bench.py and the profiling tools can time and profile the
+// pieces apart.  The factorisation state is left invalid (call gpb_gp_factor afterwards).
+extern "C" int gpb_debug_fit_piece(gpb_ctx* ctx, int piece) {
+    if (!ctx) return GPB_E_ARG;
+    if (!ctx->have_theta) GPB_FAIL(GPB_E_STATE, "gpb_debug_fit_piece before gpb_gp_set_theta");
+    GPB_HIP(hipSetDevice(ctx->device));
+    ctx->factored = false;
+    switch (piece) {
+        case 0: return launch_kmat(ctx);
+        case 1: return launch_potrf(ctx);
+        case 2: return launch_trtri(ctx);
+        case 3: return launch_alpha(ctx);
+        default: return GPB_E_ARG;
+    }
 }
 
 extern "C" int gpb_debug_force_generic_mvn(gpb_ctx* ctx, int on) {

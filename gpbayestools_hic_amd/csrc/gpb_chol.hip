@@ -62,10 +62,11 @@ __global__ __launch_bounds__(CHOL_THREADS, 4) void k_chol_diag(double* __restric
 
 // Column panel: L_ik = A_ik L_kk^-T for row block i = kb + 1 + blockIdx.x, in place.
 __global__ __launch_bounds__(CHOL_THREADS) void k_chol_trsm(double* __restrict__ K, const double* __restrict__ Linv,
-                                                            int64_t Np, int64_t kb) {
+                                                            int64_t Np, int64_t kb, unsigned P) {
     __shared__ double sa[64][LDP], sx[64][LDP];
-    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t c0 = kb * 64, r0 = (kb + 1 + blockIdx.x) * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = (int)(blockIdx.x % P), bx = (int)(blockIdx.x / P);      // GP fastest: see k_chol_update
+    const int64_t c0 = kb * 64, r0 = (kb + 1 + bx) * 64;
     double* Ap = K + (int64_t)p * Np * Np + r0 * Np + c0;
     load_tile(Ap, Np, sa, tid);
     load_tile(Linv + (int64_t)p * Np * Np + c0 * Np + c0, Np, sx, tid);
@@ -84,11 +85,16 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_trsm(double* __restrict__
 // diagonal block: its workgroup keeps the updated block in LDS, factors and inverts it, and stores L and L^-1.
 __global__ __launch_bounds__(CHOL_THREADS, 4) void k_chol_update(double* __restrict__ K, double* __restrict__ Linv,
                                                               int64_t Np, int64_t kb, int64_t je,
-                                                              int* __restrict__ info) {
+                                                              int* __restrict__ info, unsigned P) {
     __shared__ CholLds s;
-    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // 1-D grid, GP fastest: tile t of ALL GPs is dispatched before tile t + 1 of any.  With the GP as grid.y the chain's
+    // workgroup (tile 0) of the last GP stood behind every tile of the GPs before it — 4464 workgroups at the first step
+    // of N = 2048 with 10 GPs — and the step waited for it.
+    const int p = (int)(blockIdx.x % P);
+    const unsigned bx = blockIdx.x / P;
     const int64_t nb = Np / 64;
-    int64_t j = kb + 1, t = blockIdx.x;
+    int64_t j = kb + 1, t = bx;
     while (t >= nb - j) { t -= nb - j; ++j; }          // column j holds nb - j tiles (rows j .. nb-1)
     const int64_t i = j + t;
     if (j >= je) return;
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(CHOL_THREADS, 4) void k_chol_update(double* __restr
     __syncthreads();
     d4 acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
     mma_nt_64(s.a, i != j ? s.x : s.a, acc, wave, lane);
-    if (blockIdx.x != 0) {
+    if (bx != 0) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -176,13 +182,13 @@ int launch_potrf_fused(gpb_ctx* ctx) {
         for (int64_t kb = pb / 64; kb < je; ++kb) {
             const int64_t rem = nb - kb - 1;
             if (rem <= 0) break;
-            hipLaunchKernelGGL(k_chol_trsm, dim3((unsigned)rem, P), dim3(CHOL_THREADS), 0, ctx->stream, ctx->K, ctx->Linv,
-                               Np, kb);
+            hipLaunchKernelGGL(k_chol_trsm, dim3((unsigned)rem * P), dim3(CHOL_THREADS), 0, ctx->stream, ctx->K, ctx->Linv,
+                               Np, kb, P);
             if (kb + 1 < je) {
                 int64_t ntile = 0;
                 for (int64_t j = kb + 1; j < je; ++j) ntile += nb - j;
-                hipLaunchKernelGGL(k_chol_update, dim3((unsigned)ntile, P), dim3(CHOL_THREADS), 0, ctx->stream, ctx->K,
-                                   ctx->Linv, Np, kb, je, ctx->info);
+                hipLaunchKernelGGL(k_chol_update, dim3((unsigned)ntile * P), dim3(CHOL_THREADS), 0, ctx->stream, ctx->K,
+                                   ctx->Linv, Np, kb, je, ctx->info, P);
             }
         }
         if (pe >= Np) break;

@@ -7,6 +7,7 @@
 // has ragged edges in N:  K_pad = [[K,0],[0,I]]  =>  L_pad = [[L,0],[0,I]], same for L^-1.
 #include "gpb_internal.h"
 #include "gemm_tile.h"
+#include "fast_math.h"
 #include <math.h>
 #include <vector>
 
@@ -71,6 +72,7 @@ int launch_scale_design(gpb_ctx* ctx) {
 }
 
 // ------------------------------------------------------------------ K(X,X)
+#ifdef GPB_DEBUG_VARIANTS       // round 1/2's kernel (tune key 39 = 0), for A/B
 // One 64x64 tile per workgroup, tiles of the lower block triangle only (the factorisation reads nothing above
 // it); scaled design rows staged in LDS; HBM-write bound (4*Np^2 bytes per GP).  Diagonal: c*1 + sigma_n^2 + alpha (sk:kernels.py:1559-1560,
 // 1401-1412; sk:_gpr.py:347).  Padding rows/cols: identity.
@@ -127,7 +129,139 @@ __global__ __launch_bounds__(256) void k_kmat(const double* __restrict__ Xsc, co
         }
 }
 
+#endif  // GPB_DEBUG_VARIANTS
+
+// The same matrix, organised for throughput (the default; tune key 39 = 0 selects the kernel above for A/B):
+//   * a 1-D grid over the tiles of the lower block triangle only (no empty workgroups);
+//   * r^2 = |a|^2 + |b|^2 - 2 a.b on the centred, length-scaled design (Xc / dnorm, as k_kcross): d multiply-adds per pair
+//     instead of d subtractions + d multiply-adds, and the a.b of a 32x32 wave tile as 4 x dpad/4 fp64 MFMAs whose
+//     fragments are read from the two operand blocks staged once in LDS (2 x 64 rows x dpad doubles, one barrier); the k
+//     loop of the kernel above spent as many LDS cycles on operand reads as VALU cycles on arithmetic.  Centring at the design's column means keeps |a|, |b| small: the cancellation costs ~1e-16 (|a|^2 + |b|^2)
+//     absolute in r^2, i.e. <= 1e-15 relative in K for length scales down to a tenth of the design's extent;
+//   * the diagonal / padding logic only in the tiles that have a diagonal or padding (a uniform branch): the interior
+//     tiles are straight-line code whose 16 exponentials share their constants.
+// Bound: max(HBM write 4 Np^2 bytes per GP, fp64 VALU ~ Np^2 / 2 x (dpad + ~30) operations per GP).
+template <int KIND, int DPAD>
+__global__ __launch_bounds__(256) void k_kmat_mfma(const double* __restrict__ Xc, const double* __restrict__ dnorm,
+                                                   const double* __restrict__ amp, const double* __restrict__ noise,
+                                                   double alpha_reg, double* __restrict__ K, int64_t N, int64_t Np) {
+    // the tile's two operand blocks (64 design rows x DPAD each, contiguous in Xc) are staged in LDS by coalesced 16-byte
+    // loads — fragment-shaped loads straight from global memory touched sixteen 32-byte pieces per instruction, 1920 cache
+    // line requests per workgroup — and read back as MFMA fragments (row stride DPAD + 1 doubles: conflict-free)
+    constexpr int LDX = DPAD + 1;
+    __shared__ double sXi[64 * LDX], sXj[64 * LDX], sdi[64], sdj[64];
+    const int p = blockIdx.y;
+    // tile t of the lower block triangle, row by row: t = bi (bi + 1) / 2 + bj, bj <= bi
+    const int64_t t = blockIdx.x;
+    int64_t bi = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while (bi * (bi + 1) / 2 > t) --bi;
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    const int64_t bj = t - bi * (bi + 1) / 2;
+    const int64_t i0 = bi * 64, j0 = bj * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = (wave >> 1) * 32, n0 = (wave & 1) * 32, lr = lane & 15, lk = lane >> 4;
+    const double* Xp = Xc + (int64_t)p * Np * DPAD;
+    const double* dn = dnorm + (int64_t)p * Np;
+    {
+        const d2* gi = reinterpret_cast<const d2*>(Xp + i0 * DPAD);
+        const d2* gj = reinterpret_cast<const d2*>(Xp + j0 * DPAD);
+#pragma unroll
+        for (int e = tid; e < 64 * DPAD / 2; e += 256) {
+            const int r = (2 * e) / DPAD, k = 2 * e - r * DPAD;       // DPAD is even: a pair never straddles two rows
+            const d2 vi = gi[e], vj = gj[e];
+            sXi[r * LDX + k] = vi.x; sXi[r * LDX + k + 1] = vi.y;
+            sXj[r * LDX + k] = vj.x; sXj[r * LDX + k + 1] = vj.y;
+        }
+        if (tid < 64) sdi[tid] = dn[i0 + tid];
+        else if (tid < 128) sdj[tid - 64] = dn[j0 + tid - 64];
+    }
+    __syncthreads();
+    constexpr int KG = DPAD / 4;
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+    // A fragment: lane holds A[row lr][k lk]; B fragment: B[k lk][col lr] = Xc[col][k]
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+        double fa[2], fb[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            fa[a] = sXi[(m0 + 16 * a + lr) * LDX + 4 * g + lk];
+            fb[a] = sXj[(n0 + 16 * a + lr) * LDX + 4 * g + lk];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+    const double c = amp[p];
+    double* Kp = K + (int64_t)p * Np * Np;
+    const bool special = bi == bj || i0 + 64 > N;       // a diagonal or padding in this tile (j0 <= i0)
+    if (!special) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const double dj = sdj[n0 + 16 * b + lr];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double r2 = fmax(fma(-2.0, acc[a][b][r], sdi[m0 + 16 * a + lk + 4 * r] + dj), 0.0);
+                    Kp[(i0 + m0 + 16 * a + lk + 4 * r) * Np + j0 + n0 + 16 * b + lr] = c * shape_fn_fast<KIND>(r2);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // four evaluations in flight, not sixteen: registers for occupancy
+            }
+        return;
+    }
+    const double dg = amp[p] + noise[p] + alpha_reg;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const double dj = sdj[n0 + 16 * b + lr];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t i = i0 + m0 + 16 * a + lk + 4 * r, j = j0 + n0 + 16 * b + lr;
+                const double r2 = fmax(fma(-2.0, acc[a][b][r], sdi[m0 + 16 * a + lk + 4 * r] + dj), 0.0);
+                double v;
+                if (i >= N || j >= N) v = (i == j) ? 1.0 : 0.0;
+                else if (i == j) v = dg;
+                else v = c * shape_fn_fast<KIND>(r2);
+                Kp[i * Np + j] = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+template <int KIND>
+static void launch_kmat_mfma(gpb_ctx* ctx) {
+    const int64_t nb = ctx->Np / 64;
+    dim3 grid((unsigned)(nb * (nb + 1) / 2), (unsigned)ctx->P);
+#define GPB_KM(DP)                                                                                                  \
+    hipLaunchKernelGGL((k_kmat_mfma<KIND, DP>), grid, dim3(256), 0, ctx->stream, ctx->Xc, ctx->dnorm, ctx->amp,     \
+                       ctx->noise, ctx->alpha_reg, ctx->K, ctx->N, ctx->Np)
+    switch (ctx->dpad) {
+        case 8: GPB_KM(8); break;
+        case 16: GPB_KM(16); break;
+        case 20: GPB_KM(20); break;
+        case 24: GPB_KM(24); break;
+        case 32: GPB_KM(32); break;
+        case 48: GPB_KM(48); break;
+        default: GPB_KM(64); break;
+    }
+#undef GPB_KM
+}
+
 int launch_kmat(gpb_ctx* ctx) {
+    if (ctx->kmat_mfma) {
+        if (ctx->kind == GPB_KERNEL_RBF) launch_kmat_mfma<GPB_KERNEL_RBF>(ctx);
+        else if (ctx->kind == GPB_KERNEL_MATERN15) launch_kmat_mfma<GPB_KERNEL_MATERN15>(ctx);
+        else launch_kmat_mfma<GPB_KERNEL_MATERN25>(ctx);
+        GPB_HIP(hipGetLastError());
+        return 0;
+    }
+#ifdef GPB_DEBUG_VARIANTS
     dim3 grid((unsigned)(ctx->Np / 64), (unsigned)(ctx->Np / 64), (unsigned)ctx->P);
     const size_t sh = 2 * 64 * (ctx->dpad + 1) * sizeof(double);
 #define GPB_KMAT(KIND)                                                                          \
@@ -139,8 +273,12 @@ int launch_kmat(gpb_ctx* ctx) {
 #undef GPB_KMAT
     GPB_HIP(hipGetLastError());
     return 0;
+#else
+    GPB_FAIL(GPB_E_STATE, "gpb: internal: k_kmat is a debug-build variant");
+#endif
 }
 
+#ifdef GPB_DEBUG_VARIANTS       // round 1's three-launch schedule (tune key 24 = 0), for A/B
 // ------------------------------------------------------------------ Cholesky: diagonal block
 // Factor the 64x64 diagonal block kb in LDS and invert the factor; write L_kk back (upper zeroed) and
 // L_kk^-1 into the diagonal block of Linv.  This kernel is the serial chain of the blocked
@@ -297,6 +435,7 @@ __global__ __launch_bounds__(256, 2) void k_trsm_panel(double* __restrict__ K, c
     gemm_tile_loop<64, false, true>(Ap, Np, Xp, Np, 0, 0, 64, 64, 0, 64, lds, acc);
     tile_store<64>(Ap, Np, 0, 0, 64, 64, 1.0, false, acc);
 }
+#endif  // GPB_DEBUG_VARIANTS
 
 // Trailing update (SYRK on MFMA): A[i][j] -= sum_{k in [c0, c0+kw)} L[i][k] L[j][k] for rows i >= r0 and
 // columns j in [r0, ce), lower part only (tiles entirely above the diagonal exit).  Two-level blocking:
@@ -341,6 +480,9 @@ void launch_syrk_panel(gpb_ctx* ctx, int64_t pb, int64_t pe) { launch_syrk_range
 int launch_potrf_fused(gpb_ctx* ctx);                  // gpb_chol.hip: two launches per 64-column step
 
 int launch_potrf(gpb_ctx* ctx) {
+#ifndef GPB_DEBUG_VARIANTS
+    return launch_potrf_fused(ctx);
+#else
     if (ctx->chol_algo == 1) return launch_potrf_fused(ctx);
     // round 1's schedule (three launches per step), kept for A/B measurements: tune key 24 = 0
     const int64_t Np = ctx->Np, nb = Np / 64;
@@ -372,6 +514,7 @@ int launch_potrf(gpb_ctx* ctx) {
     }
     GPB_HIP(hipGetLastError());
     return 0;
+#endif
 }
 
 // ------------------------------------------------------------------ L^-1 by block doubling

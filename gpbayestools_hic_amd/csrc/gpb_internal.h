@@ -126,6 +126,7 @@ struct gpb_ctx {
     int chol_lookahead = 1;        // far part of a panel's trailing update on a side stream, under the next panel's chain
     hipStream_t side_stream = nullptr;
     std::vector<hipEvent_t> chol_events;
+    int kmat_mfma = 1;             // tune key 39: K(X,X) tiles by k_kmat_mfma (dot-product form on the matrix cores, no LDS)
     int chol_algo = 1;             // 1 = two launches per step, next diagonal block fused into the update (gpb_chol.hip); 0 = round 1
     int syrk_tile = 0;              // tile of the end-of-panel trailing updates (0 = by fill, 64, 128)
     int trtri_tile = 0;            // tile of the triangular-inverse levels (0 = by fill, 64, 128)

@@ -479,6 +479,7 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (KB == 32 ? 3 :
         predict_tile<T, NW, TN, KB, PIPE>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace, tri_skip);
 }
 
+#ifdef GPB_DEBUG_VARIANTS
 // ---------------------------------------------------------------------------------------------------------------
 // Folded tiles for small walker batches (a rank's share of a sharded ensemble: 128 - 512 rows).
 // L^-1 is lower triangular, so the K loop of row block ib is 64 (ib + 1) long: one tile per workgroup leaves a CU with
@@ -490,6 +491,8 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (KB == 32 ? 3 :
 // of K*^T), beyond it only the heavy block goes on.  Every workgroup of the launch has the same length, five of them
 // are resident per CU from the first cycle to the last, and nothing is left to balance.  A (row block, walker) sum
 // sees exactly the MFMA sequence and the reduction tree of the one-tile kernels: same bits.
+// MEASURED, NOT FASTER (profiles/r03_small_batch_notes.txt: 198 vs 189 us at 256 rows, 125 vs 106 us at ~120): the one-tile
+// launch already keeps the matrix pipe 80 % busy (PMC), its tail is not what the time goes to.  Debug builds only.
 // Units are dealt to the XCDs in contiguous ranges of (GP, a) groups (blockIdx % 8 = XCD under round-robin dispatch): the
 // nW units of a group read the same two L^-1 row panels at the same time, and an XCD sees the K*^T panels of one or two
 // GPs only — each L^-1 block leaves HBM / the Infinity Cache once.
@@ -621,6 +624,8 @@ __global__ __launch_bounds__(256, (TN == 32 ? 5 : 4)) void k_predict_fold(
     if (tid < TN) spart[((int64_t)ibl * P + p) * Wld + nb + tid] = red[tid] + red[TN + tid];
 }
 
+#endif  // GPB_DEBUG_VARIANTS
+
 __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ mpart, const double* __restrict__ spart,
                                                   const double* __restrict__ amp, const double* __restrict__ noise,
                                                   double* __restrict__ mean_pc, double* __restrict__ var_pc,
@@ -685,9 +690,17 @@ static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int
         while (cpw < 8 && wgs1 / (2 * cpw) >= 4 * (int64_t)ctx->num_cu) cpw *= 2;
     }
     dim3 grid((unsigned)(Wuse / (64 * wpl)), (unsigned)((nchunk + cpw - 1) / cpw), (unsigned)ctx->P);
+#ifdef GPB_DEBUG_VARIANTS       // the difference form of the distance (tune key 18 = 0): A/B and the parity test of both forms
+#define GPB_KX_DIFF(DP)                                                                                          \
+    hipLaunchKernelGGL((k_kcross<KIND, DP, false, 1>), grid, dim3(256), 0, ctx->stream, Xs_dev, W, (int)ctx->d,  \
+                       ctx->Xsc, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT, ctx->mpart, ctx->N, ctx->Np, ctx->Wld, \
+                       (int)ctx->P, ctx->dnorm, ctx->muS, cpw, nrows_dev)
+#else
+#define GPB_KX_DIFF(DP) ((void)0)
+#endif
 #define GPB_KX(DP)                                                                                               \
     do {                                                                                                         \
-        if (ctx->kcross_dot && wpl == 2)                                                                         \
+        if (ctx->kcross_dot && wpl == 2)                                                                    \
             hipLaunchKernelGGL((k_kcross<KIND, DP, true, (DP <= 32 ? 2 : 1)>), grid, dim3(256), 0, ctx->stream,  \
                                Xs_dev, W, (int)ctx->d, ctx->Xc, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT,         \
                                ctx->mpart, ctx->N, ctx->Np, ctx->Wld, (int)ctx->P, ctx->dnorm, ctx->muS, cpw,   \
@@ -697,9 +710,7 @@ static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int
                                (int)ctx->d, ctx->Xc, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT, ctx->mpart,        \
                                ctx->N, ctx->Np, ctx->Wld, (int)ctx->P, ctx->dnorm, ctx->muS, cpw, nrows_dev);   \
         else                                                                                                     \
-            hipLaunchKernelGGL((k_kcross<KIND, DP, false, 1>), grid, dim3(256), 0, ctx->stream, Xs_dev, W,       \
-                               (int)ctx->d, ctx->Xsc, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT, ctx->mpart,       \
-                               ctx->N, ctx->Np, ctx->Wld, (int)ctx->P, ctx->dnorm, ctx->muS, cpw, nrows_dev);   \
+            GPB_KX_DIFF(DP);                                                                                     \
     } while (0)
     switch (ctx->dpad) {
         case 8: GPB_KX(8); break;
@@ -711,6 +722,7 @@ static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int
         default: GPB_KX(64); break;
     }
 #undef GPB_KX
+#undef GPB_KX_DIFF
     return 0;
 }
 
@@ -801,6 +813,9 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
         const int resident = (nwv == 4 && xcd_rows < 2 && (all_resident || (T == 64 && ctx->static64)))
                                  ? ctx->resident_order : 0;      // order 0 = ticket queues on request
         const unsigned grid = (unsigned)((resident || nblocks < slots) ? nblocks : slots);
+        const unsigned grid128 = (unsigned)(nblocks < slots ? nblocks : slots);      // the persistent 128x128 launch
+        (void)grid; (void)grid128;
+#ifdef GPB_DEBUG_VARIANTS
 #define GPB_PRED(TT, WW, NN, KK)                                                                                 \
     do {                                                                                                         \
         if (resident)                                                                                            \
@@ -813,7 +828,10 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
                                ctx->KsT, ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xcd_rows,            \
                                ctx->tile_counter, (unsigned)nblocks, ctx->tile_trace, ctx->tri_skip, nrows_dev);   \
     } while (0)
-        // (32-deep K-steps for the 64-row tiles were measured: within 2.5 % either way, not kept)
+        // the measured-and-rejected variants (tools, A/B sweeps and the variant tests; built with -DGPB_DEBUG_VARIANTS into
+        // libgpbayes_debug.so): persistent 64-row tiles, 8-wave tiles, the 128x128 tile without the fragment read-ahead or
+        // as a static launch, folded row-block pairs.  (32-deep K-steps for the 64-row tiles were measured: within 2.5 %
+        // either way, not kept.)
         if (ctx->mma_pipe && T == 128 && nwv == 4 && !resident)
             hipLaunchKernelGGL((k_predict<128, 4, 128, 16, true>), dim3(grid), dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT,
                                ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xcd_rows, ctx->tile_counter,
@@ -835,6 +853,27 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
         else if (TN == 128) GPB_PRED(64, 4, 128, 16);
         else if (nwv == 8) GPB_PRED(64, 8, 64, 16);
         else               GPB_PRED(64, 4, 64, 16);
+#else
+        // The product library holds the shapes the rule can select: the persistent 128x128 tile with the fragment
+        // read-ahead (ticket queues) and the static 64-row tiles (64x128, 64x64, 64x32; order 1-3, XCD map 0/1).
+        (void)slots;
+        if (T == 128) {
+            hipLaunchKernelGGL((k_predict<128, 4, 128, 16, true>), dim3(grid128), dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT,
+                               ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xcd_rows, ctx->tile_counter,
+                               (unsigned)nblocks, ctx->tile_trace, ctx->tri_skip, nrows_dev);
+        } else {
+            const int order = ctx->resident_order ? ctx->resident_order : 2;
+            const int xr = xcd_rows < 2 ? xcd_rows : 0;
+#define GPB_PRED(NN)                                                                                                \
+    hipLaunchKernelGGL((k_predict_static<64, 4, NN, 16>), dim3((unsigned)(xr == 1 ? ((ngroups + 7) / 8) * 8 * nW : ngroups * nW)), \
+                       dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT, ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xr, \
+                       (unsigned)(xr == 1 ? ((ngroups + 7) / 8) * 8 * nW : ngroups * nW), order, (unsigned)(ctx->num_cu / 8), \
+                       ctx->tile_priority ? nI : 0, ctx->tile_trace, ctx->tri_skip, nrows_dev)
+            if (TN == 32) GPB_PRED(32);
+            else if (TN == 128) GPB_PRED(128);
+            else GPB_PRED(64);
+        }
+#endif
 #undef GPB_PRED
         if (ctx->profile) {
             GPB_HIP(hipEventRecord(e1, ctx->stream));

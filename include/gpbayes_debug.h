@@ -75,8 +75,17 @@ int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
  * the ordered list of all rows inside the box (2: always, 1, default: from 8 ranks on) or the rows inside the box of a
  * contiguous share (0); 37 = the 128x128 predict tile reads the next k-group's LDS fragments before the current group's
  * MFMAs (1, default) or as the compiler orders them (0); 38 = the 64x32 / 64x64 predict tiles run as folded pairs of row
- * blocks, one equal-length K loop per workgroup (k_predict_fold: 1, default) or one tile per workgroup (0). */
+ * blocks, one equal-length K loop per workgroup (k_predict_fold: 1) or one tile per workgroup (0, default: measured, the
+ * fold is not faster); 39 = K(X,X) by k_kmat_mfma (1, default: dot-product form, a.b on the matrix cores) or k_kmat (0). */
 int gpb_debug_tune(gpb_ctx* ctx, int key, int value);
+/* 1 when the library was built with -DGPB_DEBUG_VARIANTS (libgpbayes_debug.so: every measured-and-rejected kernel variant
+ * behind its tune key, for the sweeps in tools/ and the variant tests), 0 for the product library, whose gpb_debug_tune
+ * refuses the values that would select such a variant (waves 8, ticket queues for 64-row tiles, the 128x128 tile without the
+ * read-ahead, folded tiles, difference-form distances, the earlier K-build kernel, round 1's Cholesky schedule). */
+int gpb_debug_has_variants(void);
+/* measurement hook: enqueue one piece of gpb_gp_factor alone (0 = K(X,X) assembly, 1 = Cholesky, 2 = triangular inverse,
+ * 3 = alpha) on the context's stream; leaves the context without a valid factorisation (call gpb_gp_factor afterwards) */
+int gpb_debug_fit_piece(gpb_ctx* ctx, int piece);
 /* debug hook: per-tile placement and timing of the predict kernel.  capacity > 0 arms (and clears) a trace of
  * that many records, 0 disarms; read copies up to max_records records of 8 uint32 {HW_ID register, XCC_ID,
  * GP, row block, walker tile, start, end (100 MHz ticks), blockIdx} to the host and re-arms. */

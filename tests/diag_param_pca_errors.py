@@ -1,6 +1,7 @@
 """Where does the parameterTrafoPCA path lose digits against the reference golden (tests/golden/g7_param_pca.npz)?
 Prints LML / mean / cov errors of the HIP path with both forms of the cross-kernel distance."""
 import os
+os.environ.setdefault("GPB_DEBUG_LIB", "1")      # the sweeps switch to kernel variants of the debug build
 import sys
 import tempfile
 

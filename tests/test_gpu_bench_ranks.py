@@ -30,7 +30,10 @@ def _run(cmd, env):
 
 
 def test_bench_two_ranks_on_one_gpu_equal_the_single_gpu_run():
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # torch.distributed.run gives every rank OMP_NUM_THREADS=1; the host side of trainEmulator (scaler + PCA: an N x M SVD
+    # in numpy, as in the reference) rounds differently with threaded BLAS, and the GP targets with it — same threading on
+    # both sides, so that the comparison below is about the sharding alone
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     one = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS, env)
     env2 = dict(env, GPB_DIST_BACKEND="gloo")
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",

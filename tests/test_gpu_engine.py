@@ -208,7 +208,9 @@ def test_loglike_fast_and_generic_paths(eng, M, P):
     eng.tune("lowrank", 0)                                       # the dense M x M kernels from here on
     fast = eng.loglike(Xw).copy()
     assert eng.last_not_pd == 0
-    assert relerr(lowrank, fast) < 1e-12
+    # two device paths to the same number (-1/2 q - 1/2 log det, both terms O(10 .. 100) and of either sign): the bar is
+    # on the difference against the larger of |value| and 1 — a row whose terms cancel to ~0.1 is not 10x less accurate
+    assert float(np.max(np.abs(lowrank - fast) / np.maximum(np.abs(fast), 1.0))) < 1e-12
     # the block kernels sum the predict partials themselves in k_finalize's order: same bits with and without the fusion
     eng.tune("fuse_finalize", 0); unfused = eng.loglike(Xw).copy(); eng.tune("fuse_finalize", 1)
     assert np.array_equal(unfused, fast)
@@ -311,29 +313,41 @@ def test_predict_tile_sizes_are_bit_identical(eng):
         eng.set_theta(synth.fixed_theta(d, P)); eng.factor()
         Xs = rng.random((300, d))
         eng.force_tile(128); m1, v1 = eng.predict(Xs)
-        for tile, waves in ((64, 4), (64, 8), (128, 8)):
+        # The product library holds the shapes its rule selects (128x128 on ticket queues; 64x128, 64x64, 64x32 as static
+        # launches in three orders, two XCD maps).  The debug build (GPB_DEBUG_LIB=1) adds the measured-and-rejected
+        # variants: 8-wave tiles, ticket queues for the 64-row tiles, two more XCD maps, folded row-block pairs.
+        full = eng.has_variants
+        for tile, waves in ((64, 4), (64, 8), (128, 8)) if full else ((64, 4),):
             eng.force_tile(tile); eng.tune("waves", waves)
             m2, v2 = eng.predict(Xs)
             assert np.array_equal(m1, m2) and np.array_equal(v1, v2), (tile, waves)
         eng.tune("waves", 4)
-        for xcd in (0, 1, 2, 3):                          # tile -> XCD queue maps only reorder the work
+        for xcd in (0, 1, 2, 3) if full else (0, 1):      # tile -> XCD queue maps only reorder the work
             eng.tune("xcd", xcd)
             for tile in (64, 128, 32, 65):                # 32 = 64 rows x 32 walkers, 65 = 64 x 128
                 eng.force_tile(tile)
-                for order in (0, 1, 2, 3):                # ticket queues / static orders of a resident grid
+                for order in (0, 1, 2, 3) if full else (1, 2, 3):      # ticket queues / static orders of a resident grid
                     eng.tune("resident", order)
                     m2, v2 = eng.predict(Xs)
                     assert np.array_equal(m1, m2) and np.array_equal(v1, v2), (tile, xcd, order)
         eng.tune("xcd", -1); eng.tune("resident", 2)
-        # folded pairs of row blocks (k_predict_fold, the default for the 64x32 / 64x64 shapes above) against one tile per
-        # workgroup: same MFMA sequence per (row block, walker), same tree; 7 row blocks leave the middle one unpaired
-        for tile in (32, 64):
+        if not full:
+            from gpbayestools_hic_amd._native import GPBError
+            for key, val in (("waves", 8), ("resident", 0), ("fold_tiles", 1), ("xcd", 2), ("kcross_dot", 0), ("mma_pipe", 0),
+                             ("chol_algo", 0), ("kmat_mfma", 0)):
+                with pytest.raises(GPBError, match="debug build"):
+                    eng.tune(key, val)                    # refused, not silently ignored
+        # folded pairs of row blocks (k_predict_fold) against one tile per workgroup: same MFMA sequence per (row block,
+        # walker), same tree; 7 row blocks leave the middle one unpaired
+        for tile in (32, 64) if full else ():
             eng.force_tile(tile)
             for fold in (0, 1):
                 eng.tune("fold_tiles", fold)
                 for W in (300, 32, 1):
                     m2, v2 = eng.predict(Xs[:W])
                     assert np.array_equal(m1[:W], m2) and np.array_equal(v1[:W], v2), (tile, fold, W)
+        if full:
+            eng.tune("fold_tiles", 0)
         eng.force_tile(0)
 
 
@@ -346,7 +360,7 @@ def test_predict_tile_trace_covers_every_tile_once(eng):
     eng.set_theta(synth.fixed_theta(d, P)); eng.factor()
     Xs = rng.random((W, d))
     eng.force_tile(64)
-    for order in (2, 0):                                   # static snake launch / persistent ticket queues
+    for order in (2, 0) if eng.has_variants else (2,):     # static snake launch / persistent ticket queues (debug build)
         eng.tune("resident", order)
         eng.tile_trace(4096)                               # (an armed trace selects the one-tile-per-workgroup kernels)
         eng.predict(Xs)

@@ -116,6 +116,8 @@ def test_cholesky_schedules_agree(N):
     assert np.max(np.abs(auto_X - ref_X)) < 1e-11 * np.max(np.abs(ref_X))
     for algo, outer, look in ((1, 512, 1), (1, 512, 0), (0, 512, 0), (1, 512, 1), (1, 256, 1), (1, 256, 0), (1, 128, 1),
                               (1, 0, 1)):
+        if algo == 0 and not eng.has_variants:             # round 1's three-launch schedule: debug build (GPB_DEBUG_LIB=1)
+            continue
         eng.tune("chol_algo", algo); eng.tune("chol_outer", outer); eng.tune("chol_lookahead", look)
         eng.factor()
         L, Xi = eng.get("L"), eng.get("Linv")

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Lookahead variants of the blocked Cholesky (far part of the trailing update on a side stream): off / on (low-priority side stream).  One engine per variant (the side stream is created once)."""
+import os
+os.environ.setdefault("GPB_DEBUG_LIB", "1")      # the sweeps switch to kernel variants of the debug build
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

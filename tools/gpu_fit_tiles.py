@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Fit at fixed theta: tile choice of the panel-end SYRK and of the triangular-inverse levels (tune keys)."""
+import os
+os.environ.setdefault("GPB_DEBUG_LIB", "1")      # the sweeps switch to kernel variants of the debug build
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -5,6 +5,7 @@ outer panel width.  Checks both factors against each other (not bit-identical: t
 different sub-block products) and the factorisation residual."""
 import json
 import os
+os.environ.setdefault("GPB_DEBUG_LIB", "1")      # the sweeps switch to kernel variants of the debug build
 import sys
 import time
 

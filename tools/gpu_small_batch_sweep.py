@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """One rank's share of an 8-way sharded cfg-4 step (256 walkers per batch): launch-geometry knobs of the small kernels
 around k_predict (k_kcross walkers per lane / chunks per workgroup, finalize fusion)."""
+import os
+os.environ.setdefault("GPB_DEBUG_LIB", "1")      # the sweeps switch to kernel variants of the debug build
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpu_shard_sim import timed  # noqa: E402

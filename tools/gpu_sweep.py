@@ -4,6 +4,7 @@ shape (128x128, 64x64, 64x32 = "32"), the XCD affinity, the persistent workgroup
 tile orders of fully resident grids."""
 import json
 import os
+os.environ.setdefault("GPB_DEBUG_LIB", "1")      # the sweeps switch to kernel variants of the debug build
 import sys
 
 import numpy as np

@@ -3,6 +3,7 @@
 critical tiles.  usage: gpu_tile_trace.py [W=256] [tile=0] [resident=2]"""
 import json
 import os
+os.environ.setdefault("GPB_DEBUG_LIB", "1")      # the sweeps switch to kernel variants of the debug build
 import sys
 
 import numpy as np
