@@ -199,10 +199,13 @@ def extras(chain4, emu4, info4):
         for i, (e, sp) in enumerate(zip(memus, specs)):
             n_l, ms_l, u_l = e._engine_ready().profile_read()
             e._engine_ready().profile(False)
-            if i == 0:                        # the chain's first emulator owns the compaction and its live-row counter
-                live_rows = u_l / sp[2]
+            if i == 0:                        # the chain's first emulator owns the compaction and its live-row counter,
+                u0, n0 = u_l, n_l             # and the timing events of a launch that covers several emulators
             kms += ms_l
             nl += n_l
+        # all nine designs pad to Np = 1024, so ONE predict launch per half-step covers the 63 GPs (k_predict_multi) and the
+        # first context counts units for all of them; launched one by one (tune chain_batch 0) it counts its own GPs only
+        live_rows = u0 / (gps if nl == n0 else specs[0][2])
         units = gps * live_rows * 1024.0 ** 2      # (GP, row) pairs x Np^2 (1000 design points pad to 1024)
         nine[tag] = {"ms_per_step": dtm * 1e3, "walker_evals_per_s": nwm / dtm,
                      "rows_inside_box_fraction": units / 1024.0 ** 2 / (gps * nwm * nst),
@@ -211,7 +214,8 @@ def extras(chain4, emu4, info4):
                      "k_predict_frac_of_peak": units / (kms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS if kms else None}
         del sm
     nine["what"] = ("stretch-move steps of a nine-emulator chain through gpb_chain_emcee_run; k_predict figures: algorithmic "
-                    "flops Np^2 per evaluated (GP, row) over the summed HIP-event times of the nine launches per half-step")
+                    "flops Np^2 per evaluated (GP, row) over the HIP-event times of the predict launches (one per half-step for all nine "
+                    "emulators: k_predict_multi)")
     out["nine_emulator_chain"] = nine
     for e in memus:
         e._engine.close()

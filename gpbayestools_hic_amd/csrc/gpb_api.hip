@@ -739,7 +739,7 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
     {
         const bool variant = (key == 2 && value != 4) || (key == 5 && value == 0) || (key == 18 && value != 1) ||
                              (key == 21 && value != 1) || (key == 24 && value != 1) || (key == 37 && value != 1) ||
-                             (key == 38 && value != 0) || (key == 39 && value != 1) || (key == 0 && value > 1);
+                             (key == 38 && value != 0) || (key == 39 && value != 1);
         if (variant) GPB_FAIL(GPB_E_ARG, "gpb_debug_tune: this value selects a kernel variant of the debug build only");
     }
 #endif
@@ -779,6 +779,7 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 37: if (value < 0 || value > 1) return GPB_E_ARG; ctx->mma_pipe = value; break;
         case 38: if (value < 0 || value > 1) return GPB_E_ARG; ctx->fold_tiles = value; break;
         case 39: if (value < 0 || value > 1) return GPB_E_ARG; ctx->kmat_mfma = value; break;
+        case 40: if (value < 0 || value > 1) return GPB_E_ARG; ctx->chain_batch = value; break;
         case 33: if (value < 0) return GPB_E_ARG; ctx->tile_switch_c = value; break;
         case 34: if (value < 0) return GPB_E_ARG; ctx->mid_switch_c = value; break;
         case 35: if (value < 0) return GPB_E_ARG; ctx->narrow_switch_c = value; break;
@@ -832,7 +833,7 @@ extern "C" int gpb_profile_read(gpb_ctx* ctx, int64_t* launches, double* total_m
         unsigned long long live = 0;
         GPB_HIP(hipMemcpy(&live, ctx->rows_live, sizeof(live), hipMemcpyDeviceToHost));
         GPB_HIP(hipMemset(ctx->rows_live, 0, sizeof(live)));
-        ctx->prof_units += (double)ctx->P * (double)live;
+        ctx->prof_units += (ctx->prof_gps > 0.0 ? ctx->prof_gps : (double)ctx->P) * (double)live;
         ctx->prof_compacted = false;
     }
     *launches = (int64_t)ctx->prof_events.size();

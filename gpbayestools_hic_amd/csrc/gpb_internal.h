@@ -119,6 +119,7 @@ struct gpb_ctx {
     int wgs_per_cu64x128 = 5;       // ... for the 64x128 tile (4 resident at 128 VGPRs)
     int64_t narrow_switch = 1280;   // 64x64 tiles when at least this many of them exist per 256 CUs, else 64x32
     int static64 = 1;               // 64-row predict tiles always launch as k_predict_static
+    int chain_batch = 1;            // tune key 40: a chain's emulators of equal padded size share one predict launch
     int fold_tiles = 0;             // tune key 38: 64x32 / 64x64 predict tiles run as folded row-block pairs (k_predict_fold; measured, not faster)
     int predict_waves = 4;          // waves per k_predict tile (4 or 8)
     unsigned* tile_counter = nullptr;   // 8 ticket queues (stride 16) + done counter [128]; re-armed by the kernel
@@ -158,6 +159,7 @@ struct gpb_ctx {
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     double prof_units = 0.0;       // (GP, walker) pairs processed by the timed launches
+    double prof_gps = 0.0;         // GPs per timed launch (a chain's batched launch: those of all its emulators)
 
     // ---- RCCL ---------------------------------------------------------------------
     void* comm = nullptr;
@@ -194,6 +196,11 @@ int ensure_wcap(gpb_ctx* ctx, int64_t W);
 // nrows_dev (device int, optional): the batch was compacted, only its first *nrows_dev rows are live
 int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var, bool finalize = true,
                    const int* nrows_dev = nullptr);
+// its three phases, for callers that batch the middle one over several contexts (chains of emulators)
+int launch_kcross(gpb_ctx* ctx, const double* Xs_dev, int64_t W, const int* nrows_dev);
+int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev);
+int launch_finalize(gpb_ctx* ctx, int64_t W, bool need_var);
+constexpr int GPB_MAX_MULTI_GP = 96;      // GPs one batched launch can address (its table is a kernel argument)
 int launch_predict_cov(gpb_ctx* ctx, const double* Xs_dev, int64_t W, double* cov_dev);
 // likelihood (gpb_like.hip)
 int launch_obs(gpb_ctx* ctx, int64_t W, const double* estd_dev, double* mean_dev, double* cov_dev);

@@ -1422,6 +1422,11 @@ int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, doub
         if ((rc = ensure_wcap(ctxs[e], W))) { if (e) c0->err = ctxs[e]->err; return rc; }
     if ((rc = launch_compact(c0, X_dev, W, chain_ndim(c0), lo_dev, hi_dev, outside, ll_dev, premarked))) return rc;
     if (!cmpv) cmpv = c0->cmp_idx;                     // (count, -, -, -, indices ...) of the rows inside the box
+    // Three passes over the emulators (each kernel sees what it would see in its own emulator's sequence: same bits):
+    // (1) parameter map + K*^T and the mean partials, emulator by emulator;
+    // (2) V = L^-1 K*^T with the fused sum of squares: ONE launch for each run of emulators whose designs pad to the same
+    //     Np (the reference's analyses: nine emulators on one design) instead of one partly filled launch per emulator;
+    // (3) per emulator the block log-likelihood, added up in emuList order.
     for (int e = 0; e < E; ++e) {
         gpb_ctx* c = ctxs[e];
         const double* Xg = c0->cmp_X;
@@ -1430,8 +1435,21 @@ int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, doub
             if ((rc = gpb_param_map(c, c0->cmp_X, W, c->Xs))) { c0->err = c->err; return rc; }
             Xg = c->Xs;
         }
+        if ((rc = launch_kcross(c, Xg, W, cmpv))) { c0->err = c->err; return rc; }
+    }
+    for (int e = 0; e < E;) {
+        int n = 1, gps = (int)ctxs[e]->P;
+        while (c0->chain_batch && e + n < E && ctxs[e + n]->Np == ctxs[e]->Np && gps + (int)ctxs[e + n]->P <= GPB_MAX_MULTI_GP) {
+            gps += (int)ctxs[e + n]->P;
+            ++n;
+        }
+        if ((rc = launch_vsq(ctxs + e, n, W, cmpv))) { c0->err = ctxs[e]->err; return rc; }
+        e += n;
+    }
+    for (int e = 0; e < E; ++e) {
+        gpb_ctx* c = ctxs[e];
         const bool fused = loglike_fuses_finalize(c, W);
-        if ((rc = launch_predict(c, Xg, W, true, !fused, cmpv)) ||
+        if ((!fused && (rc = launch_finalize(c, W, true))) ||
             (rc = launch_loglike(c, W, ll_dev, e > 0, fused, nullptr, nullptr, nullptr, outside,
                                  e == E - 1 ? inside_const : 0.0, cmpv))) {
             c0->err = c->err;

@@ -415,6 +415,9 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (T == 64 && TN 
     //      4 L^-1 row panels and 16 K*^T column panels instead of ~32 + ~20 (L2 hit rate, fabric traffic)
     //   3: queue = super-block % 8 (GP x group of 4 row blocks, heaviest groups first): the same sharing, dealt
     //      out at a quarter of a GP so that the queues stay balanced
+    //   (measured in round 3 and dropped: map 0's queues walked GP by GP, so that an XCD's resident tiles are all row blocks
+    //   of two GPs and a K*^T panel is fetched once for its 16 row blocks: 20 % less fabric traffic, 15 % MORE time — the
+    //   heaviest-first order over all GPs is worth more than the reuse; profiles/r03_xcd_map_ab.txt)
     const int x = blockIdx.x & 7;
     for (int s = 0; s < 8; ++s) {
         const unsigned qx = (unsigned)((x + s) & 7);
@@ -477,6 +480,89 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (KB == 32 ? 3 :
     int p, ib, wt;
     if (decode_tile(xcd_mode, t, qx, nI, nW, P, p, ib, wt))
         predict_tile<T, NW, TN, KB, PIPE>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace, tri_skip);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Chains of several emulators (Chain.emuList: nine emulators, 63 GPs in the reference's analyses): ONE launch over the GPs
+// of all emulators whose designs pad to the same Np, instead of one launch per emulator with 6-8 GPs each and a partly
+// filled chip behind every one of them.  The tile list is that of a single emulator with G = sum of P_e GPs; entry g of
+// the table (a kernel argument: at most 96 GPs x 32 bytes) says where GP g's L^-1, K*^T and partials live.  A tile
+// computes exactly what it computes in its emulator's own launch: same bits.
+constexpr int MAX_MULTI_GP = GPB_MAX_MULTI_GP;
+struct PredGP {
+    const double* Linv;      // the emulator's [P_e][Np][Np]
+    const double* KsT;       // [P_e][Np][Wld]
+    double* spart;           // [Np / 64][P_e][Wld]
+    int P, p;                // GPs of the emulator, this GP's index in it
+};
+struct PredTable { PredGP gp[MAX_MULTI_GP]; };
+
+template <int T, int NW, int TN, int KB, bool PIPE = false>
+__global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (T == 64 && TN == 64 && NW == 4 ? 6 : 4))) void k_predict_multi(
+    const PredTable tab, int64_t Np, int64_t Wld, int G, int nI, int nW, int xcd_mode, unsigned* __restrict__ queue,
+    unsigned nblocks, unsigned* __restrict__ trace, int tri_skip, const int* __restrict__ nrows) {
+    if (nrows) {
+        nW = (*nrows + TN - 1) / TN;
+        nblocks = (unsigned)((xcd_mode == 1 ? ((G * nI + 7) / 8) * 8 : G * nI) * nW);
+    }
+    __shared__ TileLds<T, TN, KB> lds;
+    unsigned& s_ticket = *reinterpret_cast<unsigned*>(&lds.As[KB - 1][T + 12]);
+    const int x = blockIdx.x & 7;
+    for (int s = 0; s < 8; ++s) {                      // as k_predict: eight XCD-affine ticket queues, LPT order, stealing
+        const unsigned qx = (unsigned)((x + s) & 7);
+        unsigned nq;
+        if (xcd_mode == 3)      nq = superblock_queue_len(qx, nI, nW, G);
+        else if (xcd_mode == 2) nq = ((unsigned)G > qx) ? (((unsigned)G - qx + 7u) / 8u) * (unsigned)(nI * nW) : 0u;
+        else                    nq = (nblocks > qx) ? (nblocks - qx + 7u) / 8u : 0u;
+        for (;;) {
+            if (threadIdx.x == 0) s_ticket = atomicAdd(&queue[qx * 16], 1u);
+            __syncthreads();
+            const unsigned t = s_ticket;
+            __syncthreads();
+            if (t >= nq) break;
+            int g, ib, wt;
+            if (!decode_tile(xcd_mode, t, qx, nI, nW, G, g, ib, wt)) continue;
+            const PredGP& e = tab.gp[g];
+            predict_tile<T, NW, TN, KB, PIPE>(lds, e.p, ib, wt, e.Linv, e.KsT, e.spart, Np, Wld, e.P, 0, trace, tri_skip);
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (atomicAdd(&queue[128], 1u) == gridDim.x - 1) {
+            for (int i = 0; i < 8; ++i) queue[i * 16] = 0u;
+            queue[128] = 0u;
+        }
+    }
+}
+
+template <int T, int NW, int TN, int KB>
+__global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (KB == 32 ? 3 : 4))) void k_predict_static_multi(
+    const PredTable tab, int64_t Np, int64_t Wld, int G, int nI, int nW, int xcd_mode, unsigned nblocks, int order,
+    unsigned ncu_x, int prio_levels, unsigned* __restrict__ trace, int tri_skip, const int* __restrict__ nrows) {
+    __shared__ TileLds<T, TN, KB> lds;
+    if (nrows) {
+        nW = (*nrows + TN - 1) / TN;
+        nblocks = (unsigned)((xcd_mode == 1 ? ((G * nI + 7) / 8) * 8 : G * nI) * nW);
+    }
+    const unsigned qx = blockIdx.x & 7u;
+    const unsigned nq = (nblocks > qx) ? (nblocks - qx + 7u) / 8u : 0u;
+    unsigned t = blockIdx.x >> 3;
+    if (t >= nq) return;
+    const unsigned k = t / ncu_x, c = t - k * ncu_x;
+    if (order == 2) {
+        if ((k & 1u) && (k + 1u) * ncu_x <= nq) t = k * ncu_x + (ncu_x - 1u - c);
+    } else if (order == 3) {
+        const unsigned n2 = (nq / (2u * ncu_x)) * (2u * ncu_x);
+        if (t < n2) {
+            const unsigned kp = k >> 1;
+            const unsigned pi = kp * ncu_x + ((kp & 1u) ? (ncu_x - 1u - c) : c);
+            t = 2u * pi + (k & 1u);
+        }
+    }
+    int g, ib, wt;
+    if (decode_tile(xcd_mode, t, qx, nI, nW, G, g, ib, wt)) {
+        const PredGP& e = tab.gp[g];
+        predict_tile<T, NW, TN, KB, false>(lds, e.p, ib, wt, e.Linv, e.KsT, e.spart, Np, Wld, e.P, prio_levels, trace, tri_skip);
+    }
 }
 
 #ifdef GPB_DEBUG_VARIANTS
@@ -726,8 +812,8 @@ static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int
     return 0;
 }
 
-// Xs_dev: [W][d] on the device.  Results land in ctx->mean_pc / var_pc ([P][Wcap]).
-int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var, bool finalize, const int* nrows_dev) {
+// K*^T and the mean partials of a batch: Xs_dev [W][d] on the device.  Sets the leading dimension of the batch's workspaces.
+int launch_kcross(gpb_ctx* ctx, const double* Xs_dev, int64_t W, const int* nrows_dev) {
     if (!ctx->factored) GPB_FAIL(GPB_E_STATE, "gpb: predict before gpb_gp_factor");
     if (W > ctx->Wcap) GPB_FAIL(GPB_E_STATE, "gpb: internal: W exceeds workspace");
     const int64_t Wuse = round_up(W, WPAD);
@@ -738,9 +824,27 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
     if (ctx->kind == GPB_KERNEL_RBF) launch_kcross_kind<GPB_KERNEL_RBF>(ctx, Xs_dev, W, Wuse, nrows_dev);
     else if (ctx->kind == GPB_KERNEL_MATERN15) launch_kcross_kind<GPB_KERNEL_MATERN15>(ctx, Xs_dev, W, Wuse, nrows_dev);
     else launch_kcross_kind<GPB_KERNEL_MATERN25>(ctx, Xs_dev, W, Wuse, nrows_dev);
-    const int nchunk = (int)((ctx->Np + KX_CHUNK - 1) / KX_CHUNK);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+// V = L^-1 K*^T with the fused sum of squares for the GPs of E contexts in one launch (E = 1: an emulator's own launch;
+// E > 1: the emulators of a chain whose designs pad to the same Np — see k_predict_multi).  All contexts: same Np, same
+// batch (launch_kcross done), same stream.  Timing events and the unit count go to ctxs[0].
+int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev) {
+    gpb_ctx* ctx = ctxs[0];
+    const int64_t Wuse = round_up(W, WPAD);
+    int64_t Gsum = 0;
+    for (int e = 0; e < E; ++e) {
+        if (ctxs[e]->Np != ctx->Np || ctxs[e]->Wld != Wuse || ctxs[e]->stream != ctx->stream)
+            GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_vsq over contexts of different shape");
+        Gsum += ctxs[e]->P;
+    }
+    const bool multi = E > 1;
+    if (multi && Gsum > MAX_MULTI_GP) GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_vsq: too many GPs for one table");
+    const int64_t GP = Gsum;                           // GPs of the launch: what the tile counts are made of
     const int nI64 = (int)(ctx->Np / 64);
-    if (need_var) {
+    {
         // T rows x TN walkers per tile: the LARGEST shape of which enough tiles exist to fill the chip (measured,
         // cfg 3 and cfg 4 sweeps at 128..2048 walkers, profiles/r01_tile_shape_sweep.txt): 128x128 (2 per CU, 64
         // MFMAs per wave between barriers) from 3.75 tiles per CU on, 64x128 (32 MFMAs) and 64x64 (16) from 5 per
@@ -761,8 +865,8 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
                 Wsel = est < 64 ? 64 : (est > Wuse ? Wuse : est);
             }
         }
-        const int64_t tiles128 = ctx->P * ((ctx->Np + 127) / 128) * ((Wsel + 127) / 128);
-        const int64_t tiles64x128 = ctx->P * nI64 * ((Wsel + 127) / 128), tiles64 = ctx->P * nI64 * ((Wsel + 63) / 64);
+        const int64_t tiles128 = GP * ((ctx->Np + 127) / 128) * ((Wsel + 127) / 128);
+        const int64_t tiles64x128 = GP * nI64 * ((Wsel + 127) / 128), tiles64 = GP * nI64 * ((Wsel + 63) / 64);
         // Compacted batches have their own switch points (tools/gpu_shard_sim.py --walkers=.. --tune=force_tile:..,
         // profiles/r02_tile_shape_sweep_compacted.txt, cfg 4 at 190 .. 2060 live rows): the larger shape pays later —
         // 64x32 up to 9.4 tiles of 64x64 per CU (5), 64x64 up to 4.5 of 64x128 (5), 64x128 up to 9.4 of 128x128 (3.75).
@@ -773,8 +877,8 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
         if (cmpd) {
             // ... counted in fractions of a walker tile: the estimate wanders by a few rows from launch to launch, and
             // a whole-tile count made a rank's ~495 live rows flip between 4 and 5 tiles of 128, i.e. between two shapes
-            const double f128 = (double)(ctx->P * ((ctx->Np + 127) / 128)) * (double)Wsel / 128.0 * 256.0 / ctx->num_cu;
-            const double f64 = (double)(ctx->P * nI64) * (double)Wsel / 64.0 * 256.0 / ctx->num_cu;
+            const double f128 = (double)(GP * ((ctx->Np + 127) / 128)) * (double)Wsel / 128.0 * 256.0 / ctx->num_cu;
+            const double f64 = (double)(GP * nI64) * (double)Wsel / 64.0 * 256.0 / ctx->num_cu;
             if (f128 >= (double)sw128) T = TN = 128;
             else if (f64 * 0.5 >= (double)swmid) TN = 128;
             else if (f64 >= (double)swnarrow) TN = 64;
@@ -794,7 +898,7 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
         // which operand is larger decides the XCD affinity: L^-1 (P Np^2/2) or K*^T (P Np W)
         int xcd_rows = (2 * Wuse < ctx->Np) ? 1 : 0;
         if (ctx->force_xcd >= 0) xcd_rows = ctx->force_xcd;      // 0, 1 or 2 (GP-affine)
-        const int64_t ngroups = (int64_t)ctx->P * nI;
+        const int64_t ngroups = GP * nI;
         const int64_t nblocks = (xcd_rows == 1) ? ((ngroups + 7) / 8) * 8 * nW : ngroups * nW;
         const int nwv = ctx->predict_waves;             // 4 or 8 waves per tile
         const int per_cu = (T == 128) ? (nwv == 8 ? ctx->wgs_per_cu128w8 : 2)
@@ -815,6 +919,33 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
         const unsigned grid = (unsigned)((resident || nblocks < slots) ? nblocks : slots);
         const unsigned grid128 = (unsigned)(nblocks < slots ? nblocks : slots);      // the persistent 128x128 launch
         (void)grid; (void)grid128;
+        if (multi) {
+            // one launch over the GPs of all the emulators (see k_predict_multi): the product shapes only
+            PredTable tab;
+            int g = 0;
+            for (int e = 0; e < E; ++e)
+                for (int pp = 0; pp < (int)ctxs[e]->P; ++pp, ++g)
+                    tab.gp[g] = PredGP{ctxs[e]->Linv, ctxs[e]->KsT, ctxs[e]->spart, (int)ctxs[e]->P, pp};
+            const int order = ctx->resident_order ? ctx->resident_order : 2;
+            const int xr = xcd_rows < 2 ? xcd_rows : 0;
+            const unsigned nb_s = (unsigned)(xr == 1 ? ((ngroups + 7) / 8) * 8 * nW : ngroups * nW);
+            if (T == 128)
+                hipLaunchKernelGGL((k_predict_multi<128, 4, 128, 16, true>), dim3((unsigned)(nblocks < slots ? nblocks : slots)),
+                                   dim3(256), 0, ctx->stream, tab, ctx->Np, ctx->Wld, (int)GP, nI, nW, xcd_rows,
+                                   ctx->tile_counter, (unsigned)nblocks, ctx->tile_trace, ctx->tri_skip, nrows_dev);
+            else if (TN == 32)
+                hipLaunchKernelGGL((k_predict_static_multi<64, 4, 32, 16>), dim3(nb_s), dim3(256), 0, ctx->stream, tab, ctx->Np,
+                                   ctx->Wld, (int)GP, nI, nW, xr, nb_s, order, (unsigned)(ctx->num_cu / 8),
+                                   ctx->tile_priority ? nI : 0, ctx->tile_trace, ctx->tri_skip, nrows_dev);
+            else if (TN == 128)
+                hipLaunchKernelGGL((k_predict_static_multi<64, 4, 128, 16>), dim3(nb_s), dim3(256), 0, ctx->stream, tab, ctx->Np,
+                                   ctx->Wld, (int)GP, nI, nW, xr, nb_s, order, (unsigned)(ctx->num_cu / 8),
+                                   ctx->tile_priority ? nI : 0, ctx->tile_trace, ctx->tri_skip, nrows_dev);
+            else
+                hipLaunchKernelGGL((k_predict_static_multi<64, 4, 64, 16>), dim3(nb_s), dim3(256), 0, ctx->stream, tab, ctx->Np,
+                                   ctx->Wld, (int)GP, nI, nW, xr, nb_s, order, (unsigned)(ctx->num_cu / 8),
+                                   ctx->tile_priority ? nI : 0, ctx->tile_trace, ctx->tri_skip, nrows_dev);
+        } else {
 #ifdef GPB_DEBUG_VARIANTS
 #define GPB_PRED(TT, WW, NN, KK)                                                                                 \
     do {                                                                                                         \
@@ -874,21 +1005,41 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
             else GPB_PRED(64);
         }
 #endif
+        }
 #undef GPB_PRED
         if (ctx->profile) {
             GPB_HIP(hipEventRecord(e1, ctx->stream));
             ctx->prof_events.push_back({e0, e1});
-            if (!nrows_dev) ctx->prof_units += (double)ctx->P * (double)W;      // compacted: counted on the device
+            ctx->prof_gps = (double)GP;                                         // GPs per timed launch (a chain: all of them)
+            if (!nrows_dev) ctx->prof_units += (double)GP * (double)W;          // compacted: counted on the device
             else ctx->prof_compacted = true;
         }
     }
-    if (finalize)
-        hipLaunchKernelGGL(k_finalize, dim3((unsigned)((Wuse + 255) / 256), (unsigned)ctx->P), dim3(256), 0,
-                           ctx->stream, ctx->mpart, ctx->spart, ctx->amp, ctx->noise, ctx->mean_pc, ctx->var_pc,
-                           ctx->Wld, Wuse, (int)ctx->P, nchunk, nI64, need_var ? 1 : 0);
     GPB_HIP(hipGetLastError());
     return 0;
 }
+
+int launch_finalize(gpb_ctx* ctx, int64_t W, bool need_var) {
+    const int64_t Wuse = round_up(W, WPAD);
+    const int nchunk = (int)((ctx->Np + KX_CHUNK - 1) / KX_CHUNK), nI64 = (int)(ctx->Np / 64);
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((Wuse + 255) / 256), (unsigned)ctx->P), dim3(256), 0,
+                       ctx->stream, ctx->mpart, ctx->spart, ctx->amp, ctx->noise, ctx->mean_pc, ctx->var_pc,
+                       ctx->Wld, Wuse, (int)ctx->P, nchunk, nI64, need_var ? 1 : 0);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+// Xs_dev: [W][d] on the device.  Results land in ctx->mean_pc / var_pc ([P][Wcap]) when finalize is set, else in the
+// partials (mpart, spart) for a consumer that sums them itself.
+int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var, bool finalize, const int* nrows_dev) {
+    int rc = launch_kcross(ctx, Xs_dev, W, nrows_dev);
+    if (rc) return rc;
+    gpb_ctx* one[1] = {ctx};
+    if (need_var && (rc = launch_vsq(one, 1, W, nrows_dev))) return rc;
+    if (finalize) return launch_finalize(ctx, W, need_var);
+    return 0;
+}
+
 
 // ------------------------------------------------------------------ test hooks
 // MODE: 0 = C = A[M,K] B[K,N]; 1 = C = A[M,K] B[N,K]^T; 2 = C = A[K,M]^T B[K,N]

@@ -76,7 +76,9 @@ int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
  * contiguous share (0); 37 = the 128x128 predict tile reads the next k-group's LDS fragments before the current group's
  * MFMAs (1, default) or as the compiler orders them (0); 38 = the 64x32 / 64x64 predict tiles run as folded pairs of row
  * blocks, one equal-length K loop per workgroup (k_predict_fold: 1) or one tile per workgroup (0, default: measured, the
- * fold is not faster); 39 = K(X,X) by k_kmat_mfma (1, default: dot-product form, a.b on the matrix cores) or k_kmat (0). */
+ * fold is not faster); 39 = K(X,X) by k_kmat_mfma (1, default: dot-product form, a.b on the matrix cores) or k_kmat (0);
+ * 40 = the emulators of a chain whose designs pad to the same size share ONE predict launch (1, default) or launch one
+ * after the other (0); set on the chain's first context; same results. */
 int gpb_debug_tune(gpb_ctx* ctx, int key, int value);
 /* 1 when the library was built with -DGPB_DEBUG_VARIANTS (libgpbayes_debug.so: every measured-and-rejected kernel variant
  * behind its tune key, for the sweeps in tools/ and the variant tests), 0 for the product library, whose gpb_debug_tune

@@ -322,7 +322,7 @@ def test_predict_tile_sizes_are_bit_identical(eng):
             m2, v2 = eng.predict(Xs)
             assert np.array_equal(m1, m2) and np.array_equal(v1, v2), (tile, waves)
         eng.tune("waves", 4)
-        for xcd in (0, 1, 2, 3) if full else (0, 1):      # tile -> XCD queue maps only reorder the work
+        for xcd in (0, 1, 2, 3):                          # tile -> XCD queue maps only reorder the work (64-row static tiles: 0 / 1)
             eng.tune("xcd", xcd)
             for tile in (64, 128, 32, 65):                # 32 = 64 rows x 32 walkers, 65 = 64 x 128
                 eng.force_tile(tile)
@@ -333,7 +333,7 @@ def test_predict_tile_sizes_are_bit_identical(eng):
         eng.tune("xcd", -1); eng.tune("resident", 2)
         if not full:
             from gpbayestools_hic_amd._native import GPBError
-            for key, val in (("waves", 8), ("resident", 0), ("fold_tiles", 1), ("xcd", 2), ("kcross_dot", 0), ("mma_pipe", 0),
+            for key, val in (("waves", 8), ("resident", 0), ("fold_tiles", 1), ("kcross_dot", 0), ("mma_pipe", 0),
                              ("chol_algo", 0), ("kmat_mfma", 0)):
                 with pytest.raises(GPBError, match="debug build"):
                     eng.tune(key, val)                    # refused, not silently ignored

@@ -52,6 +52,21 @@ def test_nine_emulator_chain_against_the_oracle(tmp_path):
     chain.use_chain_call = False
     assert np.array_equal(chain.log_posterior(X), got)
     chain.use_chain_call = True
+    # ... and inside the call the emulators whose designs pad to the same size (here 96 / 128, then 80 / 112 / 72 design
+    # points: Np = 128) share ONE predict launch over all their GPs (k_predict_static_multi / k_predict_multi): same bits as
+    # one launch per emulator, for batches that select each of the tile shapes
+    for W in (48, 700, 3000):
+        Xb = X if W == 48 else synth.walkers(W, D, seed=W)
+        one = chain.log_posterior(Xb)
+        engs[0].tune("chain_batch", 0)
+        assert np.array_equal(chain.log_posterior(Xb), one), W
+        engs[0].tune("chain_batch", 1)
+        for tile in (128, 65, 64, 32):
+            for g in engs:
+                g.force_tile(tile)
+            assert np.array_equal(chain.log_posterior(Xb), one), (W, tile)
+        for g in engs:
+            g.force_tile(0)
     # three steps of the C-driven loop over the nine emulators against emcee's stretch move with the oracle's
     # log-posterior fed the same Philox draws (oracle/stretch_oracle.py)
     from test_gpu_sampler_step import _oracle_chain as emcee_by_the_oracle

@@ -46,7 +46,19 @@ def main():
                 eng.fit_piece("kmat"); eng.fit_piece("potrf")
             t = timed(chol) - row["kmat_mfma1_us"][-1]
             row.setdefault(f"potrf_algo{algo}_us", []).append(round(t, 1))
+        eng.tune("chol_algo", 1)
+        for tile in (0, 64, 128):                        # tile of the end-of-panel trailing updates (0 = rule)
+            eng.tune("syrk_tile", tile)
+
+            def chol():
+                eng.fit_piece("kmat"); eng.fit_piece("potrf")
+            row[f"potrf_syrk_tile{tile}_us"] = round(timed(chol) - row["kmat_mfma1_us"][-1], 1)
+        eng.tune("syrk_tile", 0)
         eng.factor()
+        for tile in (0, 64, 128):
+            eng.tune("trtri_tile", tile)
+            row[f"trtri_tile{tile}_us"] = round(timed(lambda: eng.fit_piece("trtri")), 1)
+        eng.tune("trtri_tile", 0)
         row["trtri_us"] = round(timed(lambda: eng.fit_piece("trtri")), 1)
         row["alpha_us"] = round(timed(lambda: eng.fit_piece("alpha")), 1)
         row["factor_ms"] = round(timed(lambda: eng.factor(), 5) / 1e3, 3)

@@ -21,6 +21,12 @@ def main():
     d, nw = 20, 4096
     specs = [(N, 60, 6 + i % 3, ("RBF", "Matern25", "RBF")[i % 3]) for i in range(9)]
     chain, emus, info = build_multi_chain(specs, d)
+    for a in sys.argv[2:]:
+        if a.startswith("--tune="):                  # e.g. --tune=chain_batch:0 (set on every emulator's engine)
+            k, v = a[7:].split(":")
+            for e in emus:
+                e._engine_ready().tune(k, int(v))
+            print(json.dumps({"tune": {k: int(v)}}), flush=True)
     X = torch.as_tensor(synth.walkers(nw // 2, d), device="cuda")
     row = {"emulators": 9, "N": N, "d": d, "observables": chain.nobs, "GPs": sum(s[2] for s in specs), "rows": nw // 2}
     outs = {}
@@ -38,6 +44,9 @@ def main():
     row["same_bits"] = bool(np.array_equal(outs["one_call"], outs["per_emulator_calls"]))
     row["rows_inside_box"] = int(np.isfinite(outs["one_call"]).sum())
     X0 = synth.walkers(nw, d)
+    if "--ball" in sys.argv:                         # burnt-in start: every proposal row inside the box
+        X0 = synth.walkers_ball(nw, info["xstar"], 1e-10)
+        row["start"] = "ball"
     for tag, flag in (("c_loop", True), ("host_loop_per_emulator_calls", False)):
         chain.use_chain_call = flag
         s = StretchSampler(chain, nw, seed=1)
