@@ -10,8 +10,11 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$root/gpurun_out/$out"
 cd /tmp && export TMPDIR=/tmp
 i=0
+# PMC_VALU=1 adds the vector / scalar instruction counters (the pair kernels: K build, cross kernel)
+extra=()
+[ "${PMC_VALU:-0}" = "1" ] && extra=("SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY")
 for grp in "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
-           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "${extra[@]}"; do
     i=$((i + 1))
     d="$root/gpurun_out/$out/pass$i"
     rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$d" -- "$@" > "$d.log" 2>&1 || { echo "pass $i ($grp) failed"; tail -3 "$d.log"; continue; }
