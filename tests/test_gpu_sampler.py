@@ -186,6 +186,8 @@ def test_resident_c_loop_equals_the_host_driven_loop(tmp_path):
 def test_resident_loop_with_a_one_rank_communicator(tmp_path):
     """the sharded form of gpb_emcee_run (rows of this rank + in-stream ncclAllGather) with the only communicator a
     one-GPU box can form: world 1, same numbers as the unsharded loop"""
+    import ctypes
+    import torch
     from gpbayestools_hic_amd import StretchSampler, synth
     from gpbayestools_hic_amd.workload import build_chain
     chain, emu, info = build_chain(1, workdir=str(tmp_path))
@@ -203,8 +205,26 @@ def test_resident_loop_with_a_one_rank_communicator(tmp_path):
     s = StretchSampler(chain, nw, seed=9, sharding=sh)
     assert s._resident_engine()[0] is eng
     s.run(X0, 8)
-    eng.dist_finalize()
     assert np.array_equal(s.chain, ref.chain) and np.array_equal(s.lnprobability, ref.lnprobability)
+    # a sharded run lets the ranks AGREE that gpb_chain_emcee_prepare (state checks, workspaces) succeeded everywhere before
+    # any of them enqueues the in-stream all-gathers: a rank whose peers report a failure raises without touching the
+    # ensemble, and an own failure is what gets reported
+    votes = []
+    lib = eng.lib
+    assert lib.gpb_chain_emcee_prepare((ctypes.c_void_p * 1)(eng.h), 1, nw) == 0
+    assert lib.gpb_chain_emcee_prepare((ctypes.c_void_p * 1)(eng.h), 1, nw + 1) < 0          # odd ensemble
+    assert lib.gpb_chain_emcee_prepare(None, 1, nw) < 0
+    sh2 = types.SimpleNamespace(world=2, rank=0, direct=eng, logprob=lambda fn, X, out: fn(X, out),
+                                _all_ok=lambda ok: (votes.append(ok), False)[1])              # "another rank failed"
+    eng._dist_world = 1        # (the engine's communicator has one rank; the stub claims two: only the agreement is under test)
+    s2 = StretchSampler(chain, nw, seed=9, sharding=sh2)
+    s2.pos.copy_(s.pos); s2.lp.copy_(s.lp)
+    before = s2.pos.clone()
+    if s2._resident_engine() is not None:
+        with pytest.raises(RuntimeError, match="another rank"):
+            s2.run(None, 2)
+        assert votes == [True] and torch.equal(s2.pos, before)
+    eng.dist_finalize()
     # the measurement hook: one rank's share of a 4-way split (rows it does not evaluate are rejected)
     eng.tune("sim_ranks", 4)
     m = StretchSampler(chain, nw, seed=9)
