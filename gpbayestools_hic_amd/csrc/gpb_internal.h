@@ -198,6 +198,7 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
                    const int* nrows_dev = nullptr);
 // its three phases, for callers that batch the middle one over several contexts (chains of emulators)
 int launch_kcross(gpb_ctx* ctx, const double* Xs_dev, int64_t W, const int* nrows_dev);
+int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, int64_t W, const int* nrows_dev);
 int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev);
 int launch_finalize(gpb_ctx* ctx, int64_t W, bool need_var);
 constexpr int GPB_MAX_MULTI_GP = 96;      // GPs one batched launch can address (its table is a kernel argument)

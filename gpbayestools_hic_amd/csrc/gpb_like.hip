@@ -654,6 +654,115 @@ static int launch_loglike_lowrank(gpb_ctx* ctx, int64_t W, double* ll_dev, bool 
     return 0;
 }
 
+// ---- the low-rank block log-likelihoods of ALL emulators of a chain in one launch (round 3) --------------------------------
+// gpb_chain_logpost / gpb_chain_emcee_run end a batch with one k_loglike_lowrank per emulator, each adding its block onto the
+// row's log-probability: 32 workgroups (2048 rows) of latency-bound work per launch, nine launches in a row for the
+// reference's nine emulators.  Here a workgroup walks the emulators itself, in emuList order — the same sequence of
+// additions per row as the separate launches.  PP = the largest number of GPs of any emulator of the chain (rounded up to a
+// multiple of 4); an emulator with fewer runs with identity padding: its R and v0 are zero beyond P (lr_R / lr_v0 are zero
+// padded), so the padded rows of S are unit rows, their pivots 1, their v 0 — every product, sum and logarithm of the exact-size
+// kernel is reproduced bit for bit (x * 1 = x, x + 0 = x, log 1 = 0; the groups of four pivots per logarithm start at the same
+// places).  Compacted batches only (the chain calls): rows w >= cmp[0] do not exist.
+constexpr int MAX_LR_CTX = 24;
+struct LrCtx {
+    const double *mpart, *spart, *amp, *noise, *R, *v0;
+    int* notpd;
+    double cperp, logdet0;
+    int P, nchunk, nI64;
+};
+struct LrTable { LrCtx c[MAX_LR_CTX]; int E; };
+
+template <int PP>
+__global__ __launch_bounds__(256) void k_loglike_lowrank_multi(const LrTable tab, int64_t Wld, int64_t W,
+                                                              double* __restrict__ ll, const int* __restrict__ cmp,
+                                                              double inside_const) {
+    __shared__ double sR[PP][PP + 1];
+    __shared__ double sv0[PP];
+    __shared__ double smg[2][PP][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t w = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = w < W && w < cmp[0];
+    double total = 0.0;
+    for (int e = 0; e < tab.E; ++e) {
+        const LrCtx& c = tab.c[e];
+        const int P = c.P;
+        if (e) __syncthreads();                        // wave 0 is done with the previous emulator's tables
+        for (int i = threadIdx.x; i < PP * PP; i += 256) sR[i / PP][i % PP] = c.R[(i / PP) * 16 + (i % PP)];
+        if (threadIdx.x < PP) sv0[threadIdx.x] = c.v0[threadIdx.x];
+        if (live) {                                    // k_finalize's sums, in its order (as k_loglike_lowrank)
+            for (int p = grp; p < P; p += 4) {
+                double a = 0.0, sq = 0.0;
+                const double* mp = c.mpart + (int64_t)p * Wld + w;
+                const double* sp = c.spart + (int64_t)p * Wld + w;
+                const int64_t st = (int64_t)P * Wld;
+                const int nboth = c.nchunk < c.nI64 ? c.nchunk : c.nI64;
+                int k = 0;
+                for (; k + 16 <= nboth; k += 16) {
+                    double mv[16], sv[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) { mv[u] = mp[(k + u) * st]; sv[u] = sp[(k + u) * st]; }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) { a += mv[u]; sq += sv[u]; }
+                }
+                for (int u = k; u < c.nchunk; ++u) a += mp[u * st];
+                for (int u = k; u < c.nI64; ++u) sq += sp[u * st];
+                smg[0][p][lane] = a;
+                smg[1][p][lane] = (c.amp[p] + c.noise[p]) - sq;
+            }
+        }
+        __syncthreads();
+        if (grp != 0 || !live) continue;               // (uniform per wave; every wave still reaches the barriers above)
+        double m[PP], g[PP];
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            m[p] = 0.0; g[p] = 0.0;
+            if (p < P) { m[p] = smg[0][p][lane]; g[p] = smg[1][p][lane]; }
+        }
+        double S[PP][PP], v[PP];
+#pragma unroll
+        for (int i = 0; i < PP; ++i) {
+            double vi = sv0[i];
+#pragma unroll
+            for (int p = i; p < PP; ++p) vi = fma(sR[i][p], m[p], vi);
+            v[i] = vi;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double sij = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+                for (int p = i; p < PP; ++p) sij = fma(sR[i][p] * g[p], sR[j][p], sij);
+                S[i][j] = sij;
+            }
+        }
+        double q = 0.0, prod = 1.0, logsum = 0.0;
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < PP; ++j) {
+            const double ajj = S[j][j];
+            bad = bad || !(ajj > 0.0);
+            const double rinv = rsqrt(ajj);
+            const double zj = v[j] * rinv;
+            q = fma(zj, zj, q);
+            prod *= ajj;
+            if ((j & 3) == 3 || j == PP - 1) { logsum += log(prod); prod = 1.0; }
+#pragma unroll
+            for (int i = j + 1; i < PP; ++i) {
+                const double lij = S[i][j] * rinv;
+                v[i] = fma(-lij, zj, v[i]);
+#pragma unroll
+                for (int k = j + 1; k <= i; ++k) S[i][k] = fma(-lij, S[k][j] * rinv, S[i][k]);
+            }
+        }
+        double r = -0.5 * (c.cperp + q) - 0.5 * (c.logdet0 + logsum);
+        bad = bad || !(logsum < INFINITY);
+        if (bad) {
+            r = nan("");
+            atomicAdd(c.notpd, 1);
+        }
+        total = e ? (total + r) : r;                   // ll = r0; ll = ll + r1; ... as the separate launches accumulate
+    }
+    if (grp == 0 && live) ll[cmp[4 + w]] = total + inside_const;
+}
+
 __global__ void k_box(const double* __restrict__ X, int64_t W, int d, const double* __restrict__ lo,
                       const double* __restrict__ hi, double outside, double inside_const, double* __restrict__ ll);
 
@@ -1423,19 +1532,27 @@ int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, doub
     if ((rc = launch_compact(c0, X_dev, W, chain_ndim(c0), lo_dev, hi_dev, outside, ll_dev, premarked))) return rc;
     if (!cmpv) cmpv = c0->cmp_idx;                     // (count, -, -, -, indices ...) of the rows inside the box
     // Three passes over the emulators (each kernel sees what it would see in its own emulator's sequence: same bits):
-    // (1) parameter map + K*^T and the mean partials, emulator by emulator;
+    // (1) parameter maps, then K*^T and the mean partials — ONE launch per run of emulators of equal padded size
+    //     (k_kcross_multi);
     // (2) V = L^-1 K*^T with the fused sum of squares: ONE launch for each run of emulators whose designs pad to the same
     //     Np (the reference's analyses: nine emulators on one design) instead of one partly filled launch per emulator;
-    // (3) per emulator the block log-likelihood, added up in emuList order.
+    // (3) the block log-likelihoods, added up in emuList order: one launch that walks the emulators (k_loglike_lowrank_multi)
+    //     when every block takes the low-rank kernel, else one launch per emulator.
+    const double* Xg[64];
     for (int e = 0; e < E; ++e) {
         gpb_ctx* c = ctxs[e];
-        const double* Xg = c0->cmp_X;
+        Xg[e] = c0->cmp_X;
         c->hint_from = c0;
         if (c->pmap_d_in > 0) {                        // this emulator's GPs see the PCA-reduced parameters
             if ((rc = gpb_param_map(c, c0->cmp_X, W, c->Xs))) { c0->err = c->err; return rc; }
-            Xg = c->Xs;
+            Xg[e] = c->Xs;
         }
-        if ((rc = launch_kcross(c, Xg, W, cmpv))) { c0->err = c->err; return rc; }
+    }
+    for (int e = 0; e < E;) {                          // K*^T: one launch per run of emulators of equal padded size and input count
+        int n = 1;
+        while (c0->chain_batch && e + n < E && ctxs[e + n]->Np == ctxs[e]->Np && ctxs[e + n]->d == ctxs[e]->d && n < 32) ++n;
+        if ((rc = launch_kcross_group(ctxs + e, Xg + e, n, W, cmpv))) { c0->err = ctxs[e]->err; return rc; }
+        e += n;
     }
     for (int e = 0; e < E;) {
         int n = 1, gps = (int)ctxs[e]->P;
@@ -1445,6 +1562,30 @@ int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, doub
         }
         if ((rc = launch_vsq(ctxs + e, n, W, cmpv))) { c0->err = ctxs[e]->err; return rc; }
         e += n;
+    }
+    if (c0->chain_batch && E > 1 && E <= MAX_LR_CTX) {  // all blocks by the low-rank kernel: one launch walks the emulators
+        bool all = true;
+        int64_t pmax = 0;
+        for (int e = 0; e < E; ++e) {
+            all = all && lowrank_applies(ctxs[e]) && ctxs[e]->fuse_finalize && ctxs[e]->Wld == c0->Wld;
+            pmax = ctxs[e]->P > pmax ? ctxs[e]->P : pmax;
+        }
+        if (all) {
+            LrTable tab;
+            for (int e = 0; e < E; ++e) {
+                const gpb_ctx* c = ctxs[e];
+                tab.c[e] = LrCtx{c->mpart, c->spart, c->amp, c->noise, c->lr_R, c->lr_v0, c->notpd, c->lr_cperp, c->lr_logdet0,
+                                 (int)c->P, (int)((c->Np + KX_CHUNK - 1) / KX_CHUNK), (int)(c->Np / 64)};
+            }
+            tab.E = E;
+            const dim3 grid((unsigned)((W + 63) / 64));
+#define GPB_LRM(PPV)                                                                                             \
+    hipLaunchKernelGGL(k_loglike_lowrank_multi<PPV>, grid, dim3(256), 0, c0->stream, tab, c0->Wld, W, ll_dev, cmpv, inside_const)
+            if (pmax <= 4) GPB_LRM(4); else if (pmax <= 8) GPB_LRM(8); else if (pmax <= 12) GPB_LRM(12); else GPB_LRM(16);
+#undef GPB_LRM
+            if (hipGetLastError() != hipSuccess) { c0->err = "gpb: k_loglike_lowrank_multi launch failed"; return GPB_E_HIP; }
+            return 0;
+        }
     }
     for (int e = 0; e < E; ++e) {
         gpb_ctx* c = ctxs[e];

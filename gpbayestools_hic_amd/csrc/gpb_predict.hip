@@ -38,14 +38,23 @@ __device__ __forceinline__ double shape_fn_p(double r2) {
 // tenth of the design's extent (2e-13 at sklearn's lower search bound); measured against the oracle the two forms
 // are indistinguishable (1e-13 between them).  One form for every batch size, so a walker's result still does not
 // depend on how the ensemble is split.
+// LDS of a k_kcross workgroup (the kernels own it; the body below is shared by the one-emulator and the chain kernels)
+template <int DPAD, int WPL>
+struct KxLds {
+    double red[4][64 * WPL];
+    double sdn[KX_CHUNK];
+    __attribute__((aligned(16))) double sbuf[64 * WPL * (DPAD + 1)];       // walker tile, then the design rows
+    double sal[KX_CHUNK];
+};
+
 template <int KIND, int DPAD, bool DOT, int WPL>
-__global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, int64_t W, int d,
-                                                const double* __restrict__ Xsc, const double* __restrict__ ls,
-                                                const double* __restrict__ amp, const double* __restrict__ alpha,
-                                                double* __restrict__ KsT, double* __restrict__ mpart,
-                                                int64_t N, int64_t Np, int64_t Wld, int P,
-                                                const double* __restrict__ dnorm, const double* __restrict__ muS,
-                                                int chunks_per_wg, const int* __restrict__ nrows) {
+__device__ __forceinline__ void kcross_body(KxLds<DPAD, WPL>& L, const double* __restrict__ Xs, int64_t W, int d,
+                                            const double* __restrict__ Xsc, const double* __restrict__ ls,
+                                            const double* __restrict__ amp, const double* __restrict__ alpha,
+                                            double* __restrict__ KsT, double* __restrict__ mpart, int64_t N, int64_t Np,
+                                            int64_t Wld, int P, const double* __restrict__ dnorm,
+                                            const double* __restrict__ muS, int chunks_per_wg,
+                                            const int* __restrict__ nrows, const int p) {
     constexpr int WT = 64 * WPL;                        // walkers per workgroup: lane l holds walkers l, l + 64, ...
     // compacted batches (gpb_logpost): only the first *nrows rows (those inside the prior box) exist; the launch
     // geometry was sized for the whole batch and the workgroups beyond them leave at once
@@ -53,16 +62,15 @@ __global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, i
         W = *nrows;
         if ((int64_t)blockIdx.z * WT >= W) return;
     }
-    __shared__ double red[4][WT];
-    __shared__ double sdn[KX_CHUNK];
-    __shared__ __attribute__((aligned(16))) double sbuf[WT * (DPAD + 1)];  // walker tile, then the design rows
-    __shared__ double sal[KX_CHUNK];
+    double (*red)[WT] = L.red;
+    double* sdn = L.sdn;
+    double* sbuf = L.sbuf;
+    double* sal = L.sal;
     double (*sx)[DPAD + 1] = reinterpret_cast<double (*)[DPAD + 1]>(sbuf);
     double* sxr = sbuf;                                 // [KX_CHUNK][DPAD] design rows / length scale
     // grid: x = chunk group, y = GP, z = walker tile — the walker tile is the SLOWEST index, so that the workgroups of a
     // compacted batch's empty walker tiles (the launch is sized for the whole batch) are dispatched after every live one
     // instead of in between (compacted ~1000 of 2048 rows: 83.5 us against 55 for a full 1024-row batch before)
-    const int p = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t w0 = (int64_t)blockIdx.z * WT;
@@ -196,6 +204,51 @@ __global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, i
             }
         }
     }
+}
+
+template <int KIND, int DPAD, bool DOT, int WPL>
+__global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, int64_t W, int d,
+                                                const double* __restrict__ Xsc, const double* __restrict__ ls,
+                                                const double* __restrict__ amp, const double* __restrict__ alpha,
+                                                double* __restrict__ KsT, double* __restrict__ mpart,
+                                                int64_t N, int64_t Np, int64_t Wld, int P,
+                                                const double* __restrict__ dnorm, const double* __restrict__ muS,
+                                                int chunks_per_wg, const int* __restrict__ nrows) {
+    __shared__ KxLds<DPAD, WPL> lds;
+    kcross_body<KIND, DPAD, DOT, WPL>(lds, Xs, W, d, Xsc, ls, amp, alpha, KsT, mpart, N, Np, Wld, P, dnorm, muS,
+                                      chunks_per_wg, nrows, (int)blockIdx.y);
+}
+
+// The cross kernels of ALL emulators of a chain in one launch (round 3): grid.y runs over the GPs of every emulator of the
+// group (same padded design size, same number of GP inputs); entry e of the table — a kernel argument — holds emulator e's
+// pointers, its kernel family and the index of its first GP.  At a few hundred walkers nine launches of 6-8 GPs each were
+// pure launch-and-latency time (9 x 12-14 us per half-step of 490 at 512 walkers); the work and the bits are unchanged.
+constexpr int MAX_KX_CTX = 32;
+struct KxCtx {
+    const double *Xs, *Xc, *ls, *amp, *alpha, *dnorm, *muS;
+    double *KsT, *mpart;
+    int N, P, kind, g0;
+};
+struct KxTable { KxCtx c[MAX_KX_CTX]; int E; };
+
+template <int DPAD, int WPL>
+__global__ __launch_bounds__(256) void k_kcross_multi(const KxTable tab, int64_t W, int d, int64_t Np, int64_t Wld,
+                                                      int chunks_per_wg, const int* __restrict__ nrows) {
+    __shared__ KxLds<DPAD, WPL> lds;
+    const int g = (int)blockIdx.y;
+    int e = 0;
+    while (e + 1 < tab.E && g >= tab.c[e + 1].g0) ++e;             // uniform: the emulator this GP belongs to
+    const KxCtx& c = tab.c[e];
+    const int p = g - c.g0;
+    if (c.kind == GPB_KERNEL_RBF)
+        kcross_body<GPB_KERNEL_RBF, DPAD, true, WPL>(lds, c.Xs, W, d, c.Xc, c.ls, c.amp, c.alpha, c.KsT, c.mpart, c.N, Np, Wld,
+                                                     c.P, c.dnorm, c.muS, chunks_per_wg, nrows, p);
+    else if (c.kind == GPB_KERNEL_MATERN15)
+        kcross_body<GPB_KERNEL_MATERN15, DPAD, true, WPL>(lds, c.Xs, W, d, c.Xc, c.ls, c.amp, c.alpha, c.KsT, c.mpart, c.N, Np,
+                                                          Wld, c.P, c.dnorm, c.muS, chunks_per_wg, nrows, p);
+    else
+        kcross_body<GPB_KERNEL_MATERN25, DPAD, true, WPL>(lds, c.Xs, W, d, c.Xc, c.ls, c.amp, c.alpha, c.KsT, c.mpart, c.N, Np,
+                                                          Wld, c.P, c.dnorm, c.muS, chunks_per_wg, nrows, p);
 }
 
 // 1-D grid of P * nI * nW tiles (T x T, T = 128 or 64), heaviest row blocks first; consecutive blocks
@@ -827,6 +880,68 @@ int launch_kcross(gpb_ctx* ctx, const double* Xs_dev, int64_t W, const int* nrow
     if (ctx->kind == GPB_KERNEL_RBF) launch_kcross_kind<GPB_KERNEL_RBF>(ctx, Xs_dev, W, Wuse, nrows_dev);
     else if (ctx->kind == GPB_KERNEL_MATERN15) launch_kcross_kind<GPB_KERNEL_MATERN15>(ctx, Xs_dev, W, Wuse, nrows_dev);
     else launch_kcross_kind<GPB_KERNEL_MATERN25>(ctx, Xs_dev, W, Wuse, nrows_dev);
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
+// K*^T and the mean partials for E contexts of a chain in ONE launch (k_kcross_multi): all with the same padded design size,
+// the same number of GP inputs and the same batch; Xs[e] = context e's input rows (its parameter map's output, or the chain's
+// gathered rows).  Falls back to one launch per context when the group does not qualify (difference-form debug variant,
+// more contexts than the table holds).
+int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, int64_t W, const int* nrows_dev) {
+    gpb_ctx* ctx = ctxs[0];
+    bool ok = E > 1 && E <= MAX_KX_CTX && ctx->kcross_dot;
+    for (int e = 0; e < E && ok; ++e)
+        ok = ctxs[e]->Np == ctx->Np && ctxs[e]->d == ctx->d && ctxs[e]->dpad == ctx->dpad && ctxs[e]->stream == ctx->stream;
+    if (!ok) {
+        for (int e = 0; e < E; ++e) {
+            const int rc = launch_kcross(ctxs[e], Xs[e], W, nrows_dev);
+            if (rc) { ctx->err = ctxs[e]->err; return rc; }
+        }
+        return 0;
+    }
+    const int64_t Wuse = round_up(W, WPAD);
+    KxTable tab;
+    int G = 0;
+    for (int e = 0; e < E; ++e) {
+        gpb_ctx* c = ctxs[e];
+        if (!c->factored) GPB_FAIL(GPB_E_STATE, "gpb: predict before gpb_gp_factor");
+        if (W > c->Wcap) GPB_FAIL(GPB_E_STATE, "gpb: internal: W exceeds workspace");
+        c->Wld = Wuse;
+        tab.c[e] = KxCtx{Xs[e], c->Xc, c->ls, c->amp, c->alpha, c->dnorm, c->muS, c->KsT, c->mpart, (int)c->N, (int)c->P,
+                         c->kind, G};
+        G += (int)c->P;
+    }
+    tab.E = E;
+    const int nchunk = (int)((ctx->Np + KX_CHUNK - 1) / KX_CHUNK);
+    const int wpl = (ctx->kcross_wpl == 2 && ctx->dpad <= 32 && Wuse >= 256 && Wuse % 128 == 0) ? 2 : 1;
+    int cpw = ctx->kcross_chunks;
+    if (cpw <= 0) {                                    // as launch_kcross_kind, with the GPs of the whole group
+        const int64_t Wgeo = nrows_dev ? round_up(Wuse / 2, 64 * wpl) : Wuse;
+        const int64_t wgs1 = (Wgeo / (64 * wpl)) * nchunk * G;
+        cpw = 1;
+        while (cpw < 8 && wgs1 / (2 * cpw) >= 4 * (int64_t)ctx->num_cu) cpw *= 2;
+    }
+    dim3 grid((unsigned)((nchunk + cpw - 1) / cpw), (unsigned)G, (unsigned)(Wuse / (64 * wpl)));
+#define GPB_KXM(DP)                                                                                              \
+    do {                                                                                                         \
+        if (wpl == 2)                                                                                            \
+            hipLaunchKernelGGL((k_kcross_multi<DP, (DP <= 32 ? 2 : 1)>), grid, dim3(256), 0, ctx->stream, tab, W, \
+                               (int)ctx->d, ctx->Np, Wuse, cpw, nrows_dev);                                       \
+        else                                                                                                     \
+            hipLaunchKernelGGL((k_kcross_multi<DP, 1>), grid, dim3(256), 0, ctx->stream, tab, W, (int)ctx->d,    \
+                               ctx->Np, Wuse, cpw, nrows_dev);                                                   \
+    } while (0)
+    switch (ctx->dpad) {
+        case 8: GPB_KXM(8); break;
+        case 16: GPB_KXM(16); break;
+        case 20: GPB_KXM(20); break;
+        case 24: GPB_KXM(24); break;
+        case 32: GPB_KXM(32); break;
+        case 48: GPB_KXM(48); break;
+        default: GPB_KXM(64); break;
+    }
+#undef GPB_KXM
     GPB_HIP(hipGetLastError());
     return 0;
 }

@@ -19,6 +19,9 @@ def main():
     import torch
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     d, nw = 20, 4096
+    for a in sys.argv[2:]:
+        if a.startswith("--walkers="):
+            nw = int(a[10:])
     specs = [(N, 60, 6 + i % 3, ("RBF", "Matern25", "RBF")[i % 3]) for i in range(9)]
     chain, emus, info = build_multi_chain(specs, d)
     for a in sys.argv[2:]:
