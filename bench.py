@@ -110,9 +110,14 @@ def extras(chain4, emu4, info4):
     out["gp_predict_cfg2"] = {"points": 10000, "gps": info2["P"], "ms": t * 1e3, "points_per_s": 10000 / t,
                               "what": "mean + variance of all 10 GPs per point, inputs/outputs resident in HBM"}
     Xh = synth.walkers(10000, info2["d"])
-    t0 = time.perf_counter(); emu2.predict(Xh, return_cov=True, extra_std=0.0); th = time.perf_counter() - t0
-    out["emulator_predict_cfg2_host"] = {"points": 10000, "ms": th * 1e3, "points_per_s": 10000 / th,
-                                         "what": "Emulator.predict(return_cov=True): numpy in, mean[W,32] + cov[W,32,32] out (PCIe inclusive)"}
+    ths = []
+    for _ in range(4):          # the first call also fills the page-locked host cache the 82 MB result comes from
+        t0 = time.perf_counter(); res = emu2.predict(Xh, return_cov=True, extra_std=0.0); ths.append(time.perf_counter() - t0)
+        del res
+    th = sorted(ths[1:])[1]
+    out["emulator_predict_cfg2_host"] = {"points": 10000, "ms": th * 1e3, "points_per_s": 10000 / th, "first_call_ms": ths[0] * 1e3,
+                                         "what": "Emulator.predict(return_cov=True): numpy in, mean[W,32] + cov[W,32,32] out (PCIe "
+                                                 "inclusive; median of three calls after the first)"}
     def fit_entry(eng, Nn, Pp, kernel):
         """fit at fixed theta: K build + blocked Cholesky + L^-1 + alpha for all GPs (gpb_gp_factor).  Roofline block:
         algorithmic flops = P (N^3/3 [Cholesky] + N^3/3 [triangular inverse]) against the fp64 MFMA peak; the chain of

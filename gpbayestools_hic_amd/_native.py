@@ -128,3 +128,19 @@ def ptr(a):
 
 def f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def host_empty(shape, pinned_from=1 << 20):
+    """float64 result array on the host.  Large ones (>= `pinned_from` bytes) live in page-locked memory from torch's
+    caching host allocator, so that the library's device-to-host copy is one DMA at the link's rate instead of a staged
+    copy into fresh pageable pages (82 MB of covariances: 10.9 ms -> see DESIGN); the array is an ordinary numpy array
+    that keeps its block alive, and the allocator takes the block back when the array is dropped."""
+    n = int(np.prod(shape))
+    if 8 * n >= pinned_from:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                return torch.empty(tuple(int(x) for x in shape), dtype=torch.float64, pin_memory=True).numpy()
+        except Exception:       # no torch / no pinned memory left: pageable memory is always correct
+            pass
+    return np.empty(shape)

@@ -32,7 +32,7 @@ namespace {
 
 // s.a -> L block of K (upper zeroed), s.x -> diagonal block of Linv; reports a non-positive pivot
 __device__ __forceinline__ void store_diag(const CholLds& s, double* __restrict__ Kb, double* __restrict__ Xb, int64_t Np,
-                                           int64_t c0, int* __restrict__ info_p) {
+                                           int64_t c0, int* __restrict__ info_p, bool first = false) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -43,7 +43,12 @@ __device__ __forceinline__ void store_diag(const CholLds& s, double* __restrict_
         *reinterpret_cast<d2*>(Kb + (int64_t)r * Np + c) = lv;
         *reinterpret_cast<d2*>(Xb + (int64_t)r * Np + c) = xv;
     }
-    if (tid == 0 && s.bad >= 0 && *info_p == 0) *info_p = (int)(c0 + s.bad + 1);     // LAPACK dpotrf's info
+    // LAPACK dpotrf's info: the first non-positive pivot of the GP.  The first diagonal block of a factorisation also clears
+    // what the previous one left (instead of a memset in front of the chain: two fill kernels, ~10 us)
+    if (tid == 0) {
+        if (first) *info_p = s.bad >= 0 ? (int)(c0 + s.bad + 1) : 0;
+        else if (s.bad >= 0 && *info_p == 0) *info_p = (int)(c0 + s.bad + 1);
+    }
 }
 
 }  // namespace
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(CHOL_THREADS, 4) void k_chol_diag(double* __restric
     double* Kb = K + (int64_t)p * Np * Np + c0 * Np + c0;
     load_tile(Kb, Np, s.a, threadIdx.x);
     potf2_inv_64(s);                                   // opens with a barrier
-    store_diag(s, Kb, Linv + (int64_t)p * Np * Np + c0 * Np + c0, Np, c0, info + p);
+    store_diag(s, Kb, Linv + (int64_t)p * Np * Np + c0 * Np + c0, Np, c0, info + p, kb == 0);
 }
 
 // Column panel: L_ik = A_ik L_kk^-T for row block i = kb + 1 + blockIdx.x, in place.
@@ -172,8 +177,7 @@ int launch_potrf_fused(gpb_ctx* ctx) {
         int rc = ensure_lookahead(ctx, (size_t)(2 * npanel));
         if (rc) return rc;
     }
-    GPB_HIP(hipMemsetAsync(ctx->info, 0, sizeof(int) * ctx->P, ctx->stream));
-    int64_t ip = 0;
+    int64_t ip = 0;                                    // (info: cleared by the first k_chol_diag)
     bool far_pending = false;
     for (int64_t pb = 0; pb < Np; pb += NBO, ++ip) {
         const int64_t pe = imin64(pb + NBO, Np), je = pe / 64;

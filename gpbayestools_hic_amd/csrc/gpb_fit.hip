@@ -596,35 +596,42 @@ __global__ __launch_bounds__(256) void k_lower_matvec(const double* __restrict__
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) y[(int64_t)p * Np + i] = s;
 }
-// alpha_j = sum_{i>=j} Linv[i][j] y_i : 64 columns per workgroup, rows strided over 4 waves.
-__global__ __launch_bounds__(256) void k_lower_matvec_t(const double* __restrict__ Linv, const double* __restrict__ y,
-                                                        double* __restrict__ out, int64_t Np) {
-    __shared__ double red[4][64];
+// alpha_j = sum_{i>=j} Linv[i][j] y_i : 64 columns per workgroup, rows strided over 16 waves.
+constexpr int MVT_WAVES = 16;
+__global__ __launch_bounds__(64 * MVT_WAVES) void k_lower_matvec_t(const double* __restrict__ Linv, const double* __restrict__ y,
+                                                                  double* __restrict__ out, int64_t Np) {
+    __shared__ double red[MVT_WAVES][64];
     const int p = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t j0 = (int64_t)blockIdx.x * 64, j = j0 + lane;
     const double* Lp = Linv + (int64_t)p * Np * Np;
     const double* yp = y + (int64_t)p * Np;
-    // four independent chains per wave (rows i = j0 + wave + 4t, chain t mod 4): the single dependent chain
-    // was pure load latency (~115 us at N = 2048); fixed order, so the result is reproducible
+    // The kernel is pure load latency (a column block is Np / 64 workgroups x P: fewer than the chip has CUs up to N = 1024):
+    // four independent chains per wave (rows i = j0 + wave + 16 t, chain t mod 4) and sixteen waves keep 64 row loads of
+    // a column block in flight (four waves: 26 us at N = 1024, 59 at 2048).  Fixed order: reproducible.
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int64_t i = j0 + wave;
-    for (; i + 12 < Np; i += 16) {
+    constexpr int64_t S = MVT_WAVES;
+    for (; i + 3 * S < Np; i += 4 * S) {
         s0 = fma(Lp[i * Np + j], yp[i], s0);
-        s1 = fma(Lp[(i + 4) * Np + j], yp[i + 4], s1);
-        s2 = fma(Lp[(i + 8) * Np + j], yp[i + 8], s2);
-        s3 = fma(Lp[(i + 12) * Np + j], yp[i + 12], s3);
+        s1 = fma(Lp[(i + S) * Np + j], yp[i + S], s1);
+        s2 = fma(Lp[(i + 2 * S) * Np + j], yp[i + 2 * S], s2);
+        s3 = fma(Lp[(i + 3 * S) * Np + j], yp[i + 3 * S], s3);
     }
-    for (; i < Np; i += 4) s0 = fma(Lp[i * Np + j], yp[i], s0);
-    const double s = (s0 + s1) + (s2 + s3);
-    red[wave][lane] = s;
+    for (; i < Np; i += S) s0 = fma(Lp[i * Np + j], yp[i], s0);
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (wave == 0) out[(int64_t)p * Np + j] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    if (wave == 0) {
+        double s = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < MVT_WAVES; ++w) s += red[w][lane];
+        out[(int64_t)p * Np + j] = s;
+    }
 }
 
 int launch_alpha(gpb_ctx* ctx) {
     hipLaunchKernelGGL(k_lower_matvec, dim3((unsigned)(ctx->Np / 4), (unsigned)ctx->P), dim3(256), 0, ctx->stream,
                        ctx->Linv, ctx->Z, ctx->yv, ctx->Np);
-    hipLaunchKernelGGL(k_lower_matvec_t, dim3((unsigned)(ctx->Np / 64), (unsigned)ctx->P), dim3(256), 0,
+    hipLaunchKernelGGL(k_lower_matvec_t, dim3((unsigned)(ctx->Np / 64), (unsigned)ctx->P), dim3(64 * MVT_WAVES), 0,
                        ctx->stream, ctx->Linv, ctx->yv, ctx->alpha, ctx->Np);
     GPB_HIP(hipGetLastError());
     return 0;

@@ -205,7 +205,7 @@ class GPEngine:
         Xs = nat.f64(Xs).reshape(-1, self.d)
         W = Xs.shape[0]
         mean = np.empty((W, self.P))
-        cov = np.empty((self.P, W, W))
+        cov = nat.host_empty((self.P, W, W))
         self._ck(self.lib.gpb_gp_predict_cov(self.h, nat.ptr(Xs), W, 0, nat.ptr(mean), nat.ptr(cov)))
         return mean, cov
 
@@ -233,8 +233,8 @@ class GPEngine:
         Xs = nat.f64(Xs).reshape(-1, self.d)
         W = Xs.shape[0]
         es = None if extra_std is None else nat.f64(np.broadcast_to(np.asarray(extra_std, float).reshape(-1), (W,)))
-        mean = np.empty((W, self.M))
-        cov = np.empty((W, self.M, self.M)) if return_cov else None
+        mean = nat.host_empty((W, self.M))
+        cov = nat.host_empty((W, self.M, self.M)) if return_cov else None
         self._ck(self.lib.gpb_emu_predict(self.h, nat.ptr(Xs), W, 0, nat.ptr(es), nat.ptr(mean), nat.ptr(cov)))
         return (mean, cov) if return_cov else mean
 
