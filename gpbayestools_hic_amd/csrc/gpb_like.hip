@@ -518,8 +518,45 @@ static int launch_loglike_wg(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accum
 // dependency chain per walker; here ~1 k flops).  R is upper triangular, so row i of R touches p >= i only.
 // Same conventions as the dense kernels: a non-positive pivot inside the box gives NaN and counts in notpd; the
 // fused k_finalize sums (part) use k_finalize's order.
+// k_finalize's sums for the 64 walkers of a workgroup, in its order (same bits): sum (GP p, mean or variance) is one chain of
+// additions over the row chunks; the 2 P sums are dealt to the workgroup's eight waves, each with up to 32 partials in flight
+// per round trip to L2.  (Four waves with 16 + 16 in flight walked three GPs x two round trips each: most of the kernel's
+// 11 us at 256 walkers; with 8 of one kind a 64-walker workgroup spent 20 us waiting.)
+// (13-16 GPs: the per-walker algebra needs more than the 256 registers an eight-wave workgroup leaves a wave: four waves)
+template <int PP> constexpr int lr_threads() { return PP > 12 ? 256 : 512; }
 template <int PP>
-__global__ __launch_bounds__(256) void k_loglike_lowrank(const double* __restrict__ mean_pc,
+__device__ __forceinline__ void partial_sums(double (*smg)[PP][64], const double* __restrict__ mpart,
+                                             const double* __restrict__ spart, const double* __restrict__ amp,
+                                             const double* __restrict__ noise, int P, int nchunk, int nI64, int64_t Wld,
+                                             int64_t w, int lane, int grp) {
+    const int64_t st = (int64_t)P * Wld;
+    for (int u = grp; u < 2 * P; u += lr_threads<PP>() / 64) {
+        const int p = u >> 1, kind = u & 1;
+        const double* src = (kind ? spart : mpart) + (int64_t)p * Wld + w;
+        const int n = kind ? nI64 : nchunk;
+        double a = 0.0;
+        int c = 0;
+        for (; c + 32 <= n; c += 32) {
+            double v[32];
+#pragma unroll
+            for (int t = 0; t < 32; ++t) v[t] = src[(c + t) * st];
+#pragma unroll
+            for (int t = 0; t < 32; ++t) a += v[t];
+        }
+        for (; c + 8 <= n; c += 8) {
+            double v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = src[(c + t) * st];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) a += v[t];
+        }
+        for (; c < n; ++c) a += src[c * st];
+        smg[kind][p][lane] = kind ? (amp[p] + noise[p]) - a : a;
+    }
+}
+
+template <int PP>
+__global__ __launch_bounds__(lr_threads<PP>()) void k_loglike_lowrank(const double* __restrict__ mean_pc,
                                                         const double* __restrict__ var_pc, int64_t Wld, int64_t W,
                                                         int P, const double* __restrict__ Rg,
                                                         const double* __restrict__ v0g, double cperp, double logdet0,
@@ -531,32 +568,11 @@ __global__ __launch_bounds__(256) void k_loglike_lowrank(const double* __restric
     __shared__ double sv0[PP];
     __shared__ double smg[2][PP][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    for (int e = threadIdx.x; e < PP * PP; e += 256) sR[e / PP][e % PP] = Rg[(e / PP) * 16 + (e % PP)];
+    for (int e = threadIdx.x; e < PP * PP; e += lr_threads<PP>()) sR[e / PP][e % PP] = Rg[(e / PP) * 16 + (e % PP)];
     if (threadIdx.x < PP) sv0[threadIdx.x] = v0g[threadIdx.x];
     const int64_t w = (int64_t)blockIdx.x * 64 + lane;
-    if (part.mpart && w < W && (!box.cmp || w < box.cmp[0])) {
-        // k_finalize's sums, in its order (same bits) — but 16 partials of the mean AND 16 of the variance in flight per
-        // round trip to L2 (with 8 of one kind a 64-walker workgroup spent most of its 20 us waiting for 24 of them)
-        for (int p = grp; p < P; p += 4) {
-            double a = 0.0, sq = 0.0;
-            const double* mp = part.mpart + (int64_t)p * Wld + w;
-            const double* sp = part.spart + (int64_t)p * Wld + w;
-            const int64_t st = (int64_t)P * Wld;
-            const int nboth = part.nchunk < part.nI64 ? part.nchunk : part.nI64;
-            int c = 0;
-            for (; c + 16 <= nboth; c += 16) {
-                double mv[16], sv[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) { mv[u] = mp[(c + u) * st]; sv[u] = sp[(c + u) * st]; }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) { a += mv[u]; sq += sv[u]; }
-            }
-            for (int u = c; u < part.nchunk; ++u) a += mp[u * st];
-            for (int u = c; u < part.nI64; ++u) sq += sp[u * st];
-            smg[0][p][lane] = a;
-            smg[1][p][lane] = (part.amp[p] + part.noise[p]) - sq;
-        }
-    }
+    if (part.mpart && w < W && (!box.cmp || w < box.cmp[0]))
+        partial_sums<PP>(smg, part.mpart, part.spart, part.amp, part.noise, P, part.nchunk, part.nI64, Wld, w, lane, grp);
     __syncthreads();
     if (grp != 0 || w >= W || (box.cmp && w >= box.cmp[0])) return;
     const int64_t wo = box.cmp ? box.cmp[4 + w] : w;
@@ -640,7 +656,7 @@ static int launch_loglike_lowrank(gpb_ctx* ctx, int64_t W, double* ll_dev, bool 
                                   const PartArgs& part) {
     const dim3 grid((unsigned)((W + 63) / 64));
 #define GPB_LR(PPV)                                                                                              \
-    hipLaunchKernelGGL(k_loglike_lowrank<PPV>, grid, dim3(256), 0, ctx->stream, ctx->mean_pc, ctx->var_pc, ctx->Wld, \
+    hipLaunchKernelGGL(k_loglike_lowrank<PPV>, grid, dim3(lr_threads<PPV>()), 0, ctx->stream, ctx->mean_pc, ctx->var_pc, ctx->Wld, \
                        W, (int)ctx->P, ctx->lr_R, ctx->lr_v0, ctx->lr_cperp, ctx->lr_logdet0, ll_dev,              \
                        accumulate ? 1 : 0, ctx->notpd, box, part)
     switch (ctx->P) {                        // exact sizes: the work per walker grows with PP^3
@@ -673,7 +689,7 @@ struct LrCtx {
 struct LrTable { LrCtx c[MAX_LR_CTX]; int E; };
 
 template <int PP>
-__global__ __launch_bounds__(256) void k_loglike_lowrank_multi(const LrTable tab, int64_t Wld, int64_t W,
+__global__ __launch_bounds__(lr_threads<PP>()) void k_loglike_lowrank_multi(const LrTable tab, int64_t Wld, int64_t W,
                                                               double* __restrict__ ll, const int* __restrict__ cmp,
                                                               double inside_const) {
     __shared__ double sR[PP][PP + 1];
@@ -687,29 +703,10 @@ __global__ __launch_bounds__(256) void k_loglike_lowrank_multi(const LrTable tab
         const LrCtx& c = tab.c[e];
         const int P = c.P;
         if (e) __syncthreads();                        // wave 0 is done with the previous emulator's tables
-        for (int i = threadIdx.x; i < PP * PP; i += 256) sR[i / PP][i % PP] = c.R[(i / PP) * 16 + (i % PP)];
+        for (int i = threadIdx.x; i < PP * PP; i += lr_threads<PP>()) sR[i / PP][i % PP] = c.R[(i / PP) * 16 + (i % PP)];
         if (threadIdx.x < PP) sv0[threadIdx.x] = c.v0[threadIdx.x];
-        if (live) {                                    // k_finalize's sums, in its order (as k_loglike_lowrank)
-            for (int p = grp; p < P; p += 4) {
-                double a = 0.0, sq = 0.0;
-                const double* mp = c.mpart + (int64_t)p * Wld + w;
-                const double* sp = c.spart + (int64_t)p * Wld + w;
-                const int64_t st = (int64_t)P * Wld;
-                const int nboth = c.nchunk < c.nI64 ? c.nchunk : c.nI64;
-                int k = 0;
-                for (; k + 16 <= nboth; k += 16) {
-                    double mv[16], sv[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) { mv[u] = mp[(k + u) * st]; sv[u] = sp[(k + u) * st]; }
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) { a += mv[u]; sq += sv[u]; }
-                }
-                for (int u = k; u < c.nchunk; ++u) a += mp[u * st];
-                for (int u = k; u < c.nI64; ++u) sq += sp[u * st];
-                smg[0][p][lane] = a;
-                smg[1][p][lane] = (c.amp[p] + c.noise[p]) - sq;
-            }
-        }
+        if (live)                                      // k_finalize's sums, in its order (as k_loglike_lowrank)
+            partial_sums<PP>(smg, c.mpart, c.spart, c.amp, c.noise, P, c.nchunk, c.nI64, Wld, w, lane, grp);
         __syncthreads();
         if (grp != 0 || !live) continue;               // (uniform per wave; every wave still reaches the barriers above)
         double m[PP], g[PP];
@@ -1580,7 +1577,7 @@ int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, doub
             tab.E = E;
             const dim3 grid((unsigned)((W + 63) / 64));
 #define GPB_LRM(PPV)                                                                                             \
-    hipLaunchKernelGGL(k_loglike_lowrank_multi<PPV>, grid, dim3(256), 0, c0->stream, tab, c0->Wld, W, ll_dev, cmpv, inside_const)
+    hipLaunchKernelGGL(k_loglike_lowrank_multi<PPV>, grid, dim3(lr_threads<PPV>()), 0, c0->stream, tab, c0->Wld, W, ll_dev, cmpv, inside_const)
             if (pmax <= 4) GPB_LRM(4); else if (pmax <= 8) GPB_LRM(8); else if (pmax <= 12) GPB_LRM(12); else GPB_LRM(16);
 #undef GPB_LRM
             if (hipGetLastError() != hipSuccess) { c0->err = "gpb: k_loglike_lowrank_multi launch failed"; return GPB_E_HIP; }
