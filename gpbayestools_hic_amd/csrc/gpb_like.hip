@@ -1094,6 +1094,30 @@ __device__ __forceinline__ SplitPerm make_perm(uint64_t seed, uint32_t step, int
     return SplitPerm{(uint32_t)n, (uint32_t)hb, k.x, k.y, (uint32_t)randomize};
 }
 
+// A slot of the compacted batch for every walker of the workgroup that asks for one (`want`, set in the walker's lane t0 = 0):
+// ONE atomic per workgroup — 2048 walkers taking their slots from one counter one by one serialised on the atomic's return
+// (k_accept_propose 18 us at 2048 rows a batch against 8 at 256).  The order of the slots does not matter (a row's result
+// does not depend on its place in the batch).  Barriers: only in workgroups whose every thread has a walker (`full`, uniform
+// per workgroup); the ensemble's last, partly filled workgroup takes the slots walker by walker.  Returns the slot in the
+// lane t0 = 0 that asked (-1 elsewhere).
+__device__ __forceinline__ int take_slot(bool want, bool full, int* __restrict__ cmp) {
+    __shared__ int s_want[32], s_base;                 // up to 1024 threads = 32 walkers per workgroup
+    if (!full) return want ? atomicAdd(cmp, 1) : -1;
+    const int wl = (int)(threadIdx.x >> 5), nw = (int)(blockDim.x >> 5);
+    if ((threadIdx.x & 31) == 0) s_want[wl] = want ? 1 : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int i = 0; i < nw; ++i) tot += s_want[i];
+        s_base = tot ? atomicAdd(cmp, tot) : 0;
+    }
+    __syncthreads();
+    if (!want) return -1;
+    int off = 0;
+    for (int i = 0; i < wl; ++i) off += s_want[i];
+    return s_base + off;
+}
+
 // lo != nullptr (the C-driven loop over a compacted chain): the prior-box test of the rows [r0, r0 + chunk) — this
 // rank's rows of the batch — is taken here, on the proposal still in registers: flags[k - r0] = 1 inside / 0 outside
 // (strict inequalities, src/mcmc.py:275) and ll[k] = outside for the rows outside; k_compact_gather then ranks the
@@ -1109,6 +1133,7 @@ __global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, 
     const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t k = gid >> 5;
     const int t0 = (int)(gid & 31);
+    const bool full = ((int64_t)(blockIdx.x + 1) * blockDim.x) >> 5 <= nhalf;      // every thread of this workgroup has a walker
     if (k >= nhalf) return;
     const SplitPerm pi = make_perm(seed, step, 2 * nhalf, hb, randomize);
     const U4 r = philox(seed, (uint32_t)k, step, (uint32_t)half, 0u);
@@ -1142,11 +1167,8 @@ __global__ void k_propose(const double* __restrict__ pos, int64_t nhalf, int d, 
         if (Xc) {
             // ... and gathers the rows inside the box itself: a slot from a counter (cmp[0], zeroed by k_accept), in
             // whatever order the walkers arrive — a row's result does not depend on its place in the batch
-            int slot = -1;
-            if (t0 == 0 && mine && in) {
-                slot = atomicAdd(cmp, 1);
-                cmp[4 + slot] = (int)(k - r0);
-            }
+            int slot = take_slot(t0 == 0 && mine && in, full, cmp);
+            if (slot >= 0) cmp[4 + slot] = (int)(k - r0);
             slot = __shfl(slot, (int)(threadIdx.x & 32), 64);
             if (slot >= 0) {
                 if (t0 < d) Xc[(int64_t)slot * d + t0] = v2[0];
@@ -1267,6 +1289,7 @@ __global__ void k_accept_propose(double* __restrict__ pos, const double* __restr
         if (rows_live) atomicAdd(rows_live, (unsigned long long)cnt);
         cmp_prev[0] = 0;
     }
+    const bool full = ((int64_t)(blockIdx.x + 1) * blockDim.x) >> 5 <= nhalf;      // every thread of this workgroup has a walker
     if (k >= nhalf) return;
     const SplitPerm pa = make_perm(seed, step_a, 2 * nhalf, hb, randomize);
     const PendingAccept A{q_a, factor_a, lp_in, LpSource{lpq_a, rank_of_a, meta_a, chunk_a, outside}, seed, step_a, half_a};
@@ -1320,11 +1343,8 @@ __global__ void k_accept_propose(double* __restrict__ pos, const double* __restr
     }
     const bool mine = k >= r0 && k < r0 + chunk;
     if (t0 == 0 && mine && !in) ll[k] = outside;
-    int slot = -1;
-    if (t0 == 0 && mine && in) {
-        slot = atomicAdd(cmp, 1);
-        cmp[4 + slot] = (int)(k - r0);
-    }
+    int slot = take_slot(t0 == 0 && mine && in, full, cmp);
+    if (slot >= 0) cmp[4 + slot] = (int)(k - r0);
     slot = __shfl(slot, (int)(threadIdx.x & 32), 64);
     if (slot >= 0) {
         if (t0 < d) Xc[(int64_t)slot * d + t0] = v2[0];
