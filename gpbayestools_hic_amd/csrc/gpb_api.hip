@@ -129,7 +129,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     dev_free(&ctx->lr_R); dev_free(&ctx->lr_v0);
     dev_free(&ctx->xmean); dev_free(&ctx->muS); dev_free(&ctx->Xc); dev_free(&ctx->dnorm);
     dev_free(&ctx->X); dev_free(&ctx->Xsc); dev_free(&ctx->ls); dev_free(&ctx->amp); dev_free(&ctx->noise);
-    dev_free(&ctx->Z); dev_free(&ctx->K); dev_free(&ctx->Linv); dev_free(&ctx->T); dev_free(&ctx->yv);
+    dev_free(&ctx->Z); dev_free(&ctx->K); dev_free(&ctx->Linv); dev_free(&ctx->LinvT); dev_free(&ctx->T); dev_free(&ctx->yv);
     dev_free(&ctx->alpha); dev_free(&ctx->apart); dev_free(&ctx->info); dev_free(&ctx->lmlbuf);
     dev_free(&ctx->gpart); dev_free(&ctx->Xs); dev_free(&ctx->estd); dev_free(&ctx->KsT); dev_free(&ctx->mpart);
     dev_free(&ctx->spart); dev_free(&ctx->mean_pc); dev_free(&ctx->var_pc); dev_free(&ctx->out_stage);
@@ -203,6 +203,8 @@ extern "C" int gpb_gp_set(gpb_ctx* ctx, int64_t N, int64_t d, int64_t P, const d
     if ((rc = dev_alloc(ctx, &ctx->Z, P * Np))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->K, P * Np * Np))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->Linv, P * Np * Np))) return rc;
+    dev_free(&ctx->LinvT);                             // the k-major copy follows the new shape on its next use
+    ctx->linvT_valid = false;
     // zeroed ONCE: the factorisation writes the diagonal blocks (with zeros above the diagonal) and the blocks below
     // them, never the blocks above — and the 128-wide tiles of the predict / K^-1 products read those as zeros
     GPB_HIP(hipMemsetAsync(ctx->Linv, 0, sizeof(double) * P * Np * Np, ctx->stream));
@@ -739,7 +741,7 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
     {
         const bool variant = (key == 2 && value != 4) || (key == 5 && value == 0) || (key == 18 && value != 1) ||
                              (key == 21 && value != 1) || (key == 24 && value != 1) || (key == 37 && value != 1) ||
-                             (key == 38 && value != 0) || (key == 39 && value != 1);
+                             (key == 38 && value != 0) || (key == 39 && value != 1) || (key == 41 && value != 0);
         if (variant) GPB_FAIL(GPB_E_ARG, "gpb_debug_tune: this value selects a kernel variant of the debug build only");
     }
 #endif
@@ -780,6 +782,7 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 38: if (value < 0 || value > 1) return GPB_E_ARG; ctx->fold_tiles = value; break;
         case 39: if (value < 0 || value > 1) return GPB_E_ARG; ctx->kmat_mfma = value; break;
         case 40: if (value < 0 || value > 1) return GPB_E_ARG; ctx->chain_batch = value; break;
+        case 41: if (value < 0 || value > 1) return GPB_E_ARG; ctx->predict_dma = value; break;
         case 33: if (value < 0) return GPB_E_ARG; ctx->tile_switch_c = value; break;
         case 34: if (value < 0) return GPB_E_ARG; ctx->mid_switch_c = value; break;
         case 35: if (value < 0) return GPB_E_ARG; ctx->narrow_switch_c = value; break;

@@ -44,6 +44,9 @@ struct gpb_ctx {
     double* Z = nullptr;           // [P][Np]
     double* K = nullptr;           // [P][Np][Np]  K, overwritten by L (lower) in gp_factor
     double* Linv = nullptr;        // [P][Np][Np]
+    double* LinvT = nullptr;       // [P][Np][Np] k-major copy (LinvT[k][m] = Linv[m][k]) for the LDS-DMA predict tiles, made on first use
+    bool linvT_valid = false;      // ... cleared by every factorisation
+    int predict_dma = 0;           // tune key 41: the 64-row predict tiles stage their operands by LDS-DMA (k_predict_static_dma)
     double* T = nullptr;           // [P][Np][Np]  workspace (trtri / K^-1)
     double* yv = nullptr;          // [P][Np]      L^-1 z
     double* alpha = nullptr;       // [P][Np]      K^-1 z

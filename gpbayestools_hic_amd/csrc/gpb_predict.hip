@@ -378,6 +378,131 @@ __device__ __forceinline__ void predict_tile(TileLds<T, TN, KB>& lds, int p, int
     }
 }
 
+#ifdef GPB_DEBUG_VARIANTS
+// ---------------------------------------------------------------------------------------------------------------
+// The 64-row tile with its operands staged by LDS-DMA (global_load_lds_dwordx4: global memory -> LDS without passing
+// through registers; round 3, the variant the round-2 review asked for).  Needs L^-1 k-major (LinvT[k][m] = Linv[m][k],
+// written once per factorisation by k_transpose_linv) so that a K-step's A tile is 16 contiguous 512-byte rows like the
+// K*^T tile; two LDS stages, ONE barrier per K-step: wait for this wave's DMA of step s, barrier (every wave's DMA of
+// step s has landed, every wave is done with the MFMAs of step s - 1), issue the DMA of step s + 1 into the other
+// stage, MFMAs of step s.  No ds_write, no staging registers.  Rows are unpadded: a 16-lane group of the fragment reads
+// covers 128 contiguous bytes whatever the row stride, and nothing is stored to these tiles by ds_write.  Same
+// accumulation order over k, same interleaved m-tile map, same skipped zero products in the diagonal block and the same
+// reduction tree as predict_tile: same bits.
+template <int TN>
+struct __attribute__((aligned(16))) DmaLds {
+    double As[2][16][64];
+    double Bs[2][16][TN];
+};                                                   // TN = 32: 24 KB, 64: 32 KB, 128: 48 KB
+
+template <int TN>
+__device__ __forceinline__ void dma_stage(DmaLds<TN>& L, int buf, const double* __restrict__ At, int64_t Np,
+                                          const double* __restrict__ Bg, int64_t Wld, int64_t k0, int wave, int lane) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                    // A: this wave's rows 4 w .. 4 w + 3, two rows (2 x 32 lanes x 16 B) per instruction
+        const double* src = At + (k0 + 4 * wave + 2 * i + (lane >> 5)) * Np + (lane & 31) * 2;
+        __builtin_amdgcn_global_load_lds((const void*)src, (lds_ptr)&L.As[buf][4 * wave + 2 * i][0], 16, 0, 0);
+    }
+    if (TN == 32) {                                  // B: 256-byte rows, four per instruction
+        const double* src = Bg + (k0 + 4 * wave + (lane >> 4)) * Wld + (lane & 15) * 2;
+        __builtin_amdgcn_global_load_lds((const void*)src, (lds_ptr)&L.Bs[buf][4 * wave][0], 16, 0, 0);
+    } else if (TN == 64) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double* src = Bg + (k0 + 4 * wave + 2 * i + (lane >> 5)) * Wld + (lane & 31) * 2;
+            __builtin_amdgcn_global_load_lds((const void*)src, (lds_ptr)&L.Bs[buf][4 * wave + 2 * i][0], 16, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double* src = Bg + (k0 + 4 * wave + i) * Wld + lane * 2;
+            __builtin_amdgcn_global_load_lds((const void*)src, (lds_ptr)&L.Bs[buf][4 * wave + i][0], 16, 0, 0);
+        }
+    }
+}
+
+template <int TN, int IMIN>
+__device__ __forceinline__ void tile_mma_dma(const double (*As)[64], const double (*Bs)[TN], Acc<64, 4, TN>& acc, int lane,
+                                             int m0, int n0) {
+    constexpr int NJ = TN / 32;
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 4) {
+        double a[2], b[NJ];
+#pragma unroll
+        for (int i = IMIN; i < 2; ++i) a[i] = As[kk + lk][m0 + 32 * i + lr];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j] = Bs[kk + lk][n0 + 16 * j + lr];
+#pragma unroll
+        for (int i = IMIN; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc.v[i][j], 0, 0, 0);
+    }
+}
+
+template <int TN>
+__device__ __forceinline__ void predict_tile_dma(DmaLds<TN>& lds, int p, int ib, int wt, const double* __restrict__ LinvT,
+                                                 const double* __restrict__ KsT, double* __restrict__ spart, int64_t Np,
+                                                 int64_t Wld, int P, int prio_levels) {
+    constexpr int NJ = TN / 32, TNW = TN / 2;
+    const int64_t mb = (int64_t)ib * 64, nb = (int64_t)wt * TN;
+    if (prio_levels > 0) set_wave_prio((4 * ib) / prio_levels);
+    Acc<64, 4, TN> acc;
+    acc_zero<64, 4, TN>(acc);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = wm * 16, n0 = wn * TNW;          // the wave rows own the 16-row m-tiles alternately (as gemm_tile_loop TRI)
+    const double* At = LinvT + (int64_t)p * Np * Np + mb;
+    const double* Bg = KsT + (int64_t)p * Np * Wld + nb;
+    const int nsteps = (int)((mb + 64) / 16);        // k in [0, mb + 64): the last four steps are the diagonal block
+    dma_stage<TN>(lds, 0, At, Np, Bg, Wld, 0, wave, lane);
+    for (int s = 0; s < nsteps; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < nsteps) dma_stage<TN>(lds, (s + 1) & 1, At, Np, Bg, Wld, (int64_t)(s + 1) * 16, wave, lane);
+        if (s + 2 < nsteps) tile_mma_dma<TN, 0>(lds.As[s & 1], lds.Bs[s & 1], acc, lane, m0, n0);
+        else                tile_mma_dma<TN, 1>(lds.As[s & 1], lds.Bs[s & 1], acc, lane, m0, n0);   // m-tiles 0, 1: zeros from k = mb + 32 on
+    }
+    // the reduction tree of predict_tile (TRI form, T = 64): wave row 0 starts the two chains, wave row 1 finishes them
+    double* part = &lds.As[0][0][0];                 // [chain c][j][wn][lane]: 2 NJ 2 64 doubles <= 8 KB of the A stages
+    double* red = &lds.Bs[0][0][0];
+    __syncthreads();
+    if (wm == 0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                double v = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v = fma(acc.v[c][j][r], acc.v[c][j][r], v);
+                part[((c * NJ + j) * 2 + wn) * 64 + lane] = v;
+            }
+    }
+    __syncthreads();
+    if (wm == 1) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            double h[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                double v = part[((c * NJ + j) * 2 + wn) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v = fma(acc.v[c][j][r], acc.v[c][j][r], v);
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                h[c] = v;
+            }
+            if (lane < 16) red[wn * TNW + 16 * j + lane] = h[0] + h[1];
+        }
+    }
+    __syncthreads();
+    if (tid < TN) spart[((int64_t)ib * P + p) * Wld + nb + tid] = red[tid];
+}
+#endif  // GPB_DEBUG_VARIANTS
+
 // xcd_mode 3: "super-blocks" = (GP, group of 4 consecutive row blocks) x all walker tiles, heaviest groups first,
 // dealt round-robin to the eight queues.  With 2 x 32 resident 128x128 workgroups an XCD has about one
 // super-block in flight: its tiles share 4 L^-1 row panels and nW K*^T column panels through that XCD's L2.
@@ -537,6 +662,52 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (KB == 32 ? 3 :
     if (decode_tile(xcd_mode, t, qx, nI, nW, P, p, ib, wt))
         predict_tile<T, NW, TN, KB, PIPE>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace, tri_skip);
 }
+
+#ifdef GPB_DEBUG_VARIANTS
+// k_predict_static with the LDS-DMA tile (same tile list and order; map 0 / 1)
+template <int TN>
+__global__ __launch_bounds__(256, (TN == 128 ? 3 : 4)) void k_predict_static_dma(
+    const double* __restrict__ LinvT, const double* __restrict__ KsT, double* __restrict__ spart, int64_t Np, int64_t Wld,
+    int P, int nI, int nW, int xcd_mode, unsigned nblocks, int order, unsigned ncu_x, int prio_levels,
+    const int* __restrict__ nrows) {
+    __shared__ DmaLds<TN> lds;
+    if (nrows) {
+        nW = (*nrows + TN - 1) / TN;
+        nblocks = (unsigned)((xcd_mode == 1 ? ((P * nI + 7) / 8) * 8 : P * nI) * nW);
+    }
+    const unsigned qx = blockIdx.x & 7u;
+    const unsigned nq = (nblocks > qx) ? (nblocks - qx + 7u) / 8u : 0u;
+    unsigned t = blockIdx.x >> 3;
+    if (t >= nq) return;
+    const unsigned k = t / ncu_x, c = t - k * ncu_x;
+    if (order == 2) {
+        if ((k & 1u) && (k + 1u) * ncu_x <= nq) t = k * ncu_x + (ncu_x - 1u - c);
+    } else if (order == 3) {
+        const unsigned n2 = (nq / (2u * ncu_x)) * (2u * ncu_x);
+        if (t < n2) {
+            const unsigned kp = k >> 1;
+            const unsigned pi = kp * ncu_x + ((kp & 1u) ? (ncu_x - 1u - c) : c);
+            t = 2u * pi + (k & 1u);
+        }
+    }
+    int p, ib, wt;
+    if (decode_tile(xcd_mode, t, qx, nI, nW, P, p, ib, wt))
+        predict_tile_dma<TN>(lds, p, ib, wt, LinvT, KsT, spart, Np, Wld, P, prio_levels);
+}
+
+// LinvT[p][k][m] = Linv[p][m][k] (the k-major copy the LDS-DMA tiles read), 64x64 blocks through LDS
+__global__ __launch_bounds__(256) void k_transpose_linv(const double* __restrict__ Linv, double* __restrict__ LinvT,
+                                                        int64_t Np) {
+    __shared__ double s[64][65];
+    const int64_t off = (int64_t)blockIdx.z * Np * Np, r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s[ty + 4 * j][tx] = Linv[off + (r0 + ty + 4 * j) * Np + c0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) LinvT[off + (c0 + ty + 4 * j) * Np + r0 + tx] = s[tx][ty + 4 * j];
+}
+#endif  // GPB_DEBUG_VARIANTS
 
 // ---------------------------------------------------------------------------------------------------------------
 // Chains of several emulators (Chain.emuList: nine emulators, 63 GPs in the reference's analyses): ONE launch over the GPs
@@ -1081,7 +1252,28 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev) {
         // libgpbayes_debug.so): persistent 64-row tiles, 8-wave tiles, the 128x128 tile without the fragment read-ahead or
         // as a static launch, folded row-block pairs.  (32-deep K-steps for the 64-row tiles were measured: within 2.5 %
         // either way, not kept.)
-        if (ctx->mma_pipe && T == 128 && nwv == 4 && !resident)
+        if (ctx->predict_dma && T == 64 && nwv == 4) {
+            // LDS-DMA tiles (tune key 41; measured, 0-5 % slower: profiles/r03_small_batch_notes.txt): need the k-major copy of
+            // L^-1, made here after a new factorisation
+            if (!ctx->LinvT) GPB_HIP(hipMalloc(&ctx->LinvT, sizeof(double) * (size_t)(ctx->P * ctx->Np * ctx->Np)));
+            if (!ctx->linvT_valid) {
+                hipLaunchKernelGGL(k_transpose_linv, dim3((unsigned)(ctx->Np / 64), (unsigned)(ctx->Np / 64), (unsigned)ctx->P),
+                                   dim3(256), 0, ctx->stream, ctx->Linv, ctx->LinvT, ctx->Np);
+                ctx->linvT_valid = true;
+            }
+            const int order = ctx->resident_order ? ctx->resident_order : 2;
+            const int xr = xcd_rows < 2 ? xcd_rows : 0;
+            const unsigned nb_s = (unsigned)(xr == 1 ? ((ngroups + 7) / 8) * 8 * nW : ngroups * nW);
+#define GPB_PRED_DMA(NN)                                                                                            \
+    hipLaunchKernelGGL((k_predict_static_dma<NN>), dim3(nb_s), dim3(256), 0, ctx->stream, ctx->LinvT, ctx->KsT, ctx->spart, \
+                       ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xr, nb_s, order, (unsigned)(ctx->num_cu / 8),         \
+                       ctx->tile_priority ? nI : 0, nrows_dev)
+            if (TN == 32) GPB_PRED_DMA(32);
+            else if (TN == 128) GPB_PRED_DMA(128);
+            else GPB_PRED_DMA(64);
+#undef GPB_PRED_DMA
+        }
+        else if (ctx->mma_pipe && T == 128 && nwv == 4 && !resident)
             hipLaunchKernelGGL((k_predict<128, 4, 128, 16, true>), dim3(grid), dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT,
                                ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xcd_rows, ctx->tile_counter,
                                (unsigned)nblocks, ctx->tile_trace, ctx->tri_skip, nrows_dev);

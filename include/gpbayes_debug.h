@@ -78,12 +78,13 @@ int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles);
  * blocks, one equal-length K loop per workgroup (k_predict_fold: 1) or one tile per workgroup (0, default: measured, the
  * fold is not faster); 39 = K(X,X) by k_kmat_mfma (1, default: dot-product form, a.b on the matrix cores) or k_kmat (0);
  * 40 = the emulators of a chain whose designs pad to the same size share ONE predict launch (1, default) or launch one
- * after the other (0); set on the chain's first context; same results. */
+ * after the other (0); set on the chain's first context; same results; 41 = the 64-row predict tiles stage their operands
+ * by LDS-DMA from a k-major copy of L^-1 (1: debug build, measured 0-5 % slower, same bits) or through registers (0, default). */
 int gpb_debug_tune(gpb_ctx* ctx, int key, int value);
 /* 1 when the library was built with -DGPB_DEBUG_VARIANTS (libgpbayes_debug.so: every measured-and-rejected kernel variant
  * behind its tune key, for the sweeps in tools/ and the variant tests), 0 for the product library, whose gpb_debug_tune
  * refuses the values that would select such a variant (waves 8, ticket queues for 64-row tiles, the 128x128 tile without the
- * read-ahead, folded tiles, difference-form distances, the earlier K-build kernel, round 1's Cholesky schedule). */
+ * read-ahead, folded tiles, LDS-DMA tiles, difference-form distances, the earlier K-build kernel, round 1's Cholesky schedule). */
 int gpb_debug_has_variants(void);
 /* measurement hook: enqueue one piece of gpb_gp_factor alone (0 = K(X,X) assembly, 1 = Cholesky, 2 = triangular inverse,
  * 3 = alpha) on the context's stream; leaves the context without a valid factorisation (call gpb_gp_factor afterwards) */

@@ -334,7 +334,7 @@ def test_predict_tile_sizes_are_bit_identical(eng):
         if not full:
             from gpbayestools_hic_amd._native import GPBError
             for key, val in (("waves", 8), ("resident", 0), ("fold_tiles", 1), ("kcross_dot", 0), ("mma_pipe", 0),
-                             ("chol_algo", 0), ("kmat_mfma", 0)):
+                             ("chol_algo", 0), ("kmat_mfma", 0), ("predict_dma", 1)):
                 with pytest.raises(GPBError, match="debug build"):
                     eng.tune(key, val)                    # refused, not silently ignored
         # folded pairs of row blocks (k_predict_fold) against one tile per workgroup: same MFMA sequence per (row block,
@@ -348,6 +348,14 @@ def test_predict_tile_sizes_are_bit_identical(eng):
                     assert np.array_equal(m1[:W], m2) and np.array_equal(v1[:W], v2), (tile, fold, W)
         if full:
             eng.tune("fold_tiles", 0)
+        # 64-row tiles staged by LDS-DMA from the k-major copy of L^-1 (k_predict_static_dma): same MFMA sequence, same tree
+        for tile in (32, 64, 65) if full else ():
+            eng.force_tile(tile)
+            eng.tune("predict_dma", 1)
+            for W in (300, 32):
+                m2, v2 = eng.predict(Xs[:W])
+                assert np.array_equal(m1[:W], m2) and np.array_equal(v1[:W], v2), ("dma", tile, W)
+            eng.tune("predict_dma", 0)
         eng.force_tile(0)
 
 
