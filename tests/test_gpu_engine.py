@@ -176,6 +176,24 @@ def test_lml_gradient_matches_oracle_and_finite_difference(eng):
             assert maxrel(grad[p], go) < 1e-9
 
 
+def test_lml_gradient_with_more_than_thirty_parameters(eng):
+    """d + 2 > 32 hyper-parameters: the gradient's final sum runs in two blocks of 32 (k_grad_final's grid.y); N = 700 puts
+    66 tiles on its eight interleaved chunks"""
+    from oracle import gp_oracle as O
+    from gpbayestools_hic_amd import synth
+    N, d, P = 700, 33, 2
+    rng = np.random.default_rng(23)
+    X = synth.lhs(N, d, seed=6)
+    Z = np.sin(X @ rng.standard_normal((d, P)) * 0.5).T
+    th = np.array([np.concatenate([[0.1 * p], np.log(rng.uniform(1.5, 3.0, d)), [np.log(0.05)]]) for p in range(P)])
+    eng.set_data(X, Z, "RBF", 0.1)
+    val, grad = eng.lml(th)
+    for p in range(P):
+        vo, go = O.lml(th[p], X, Z[p], O.KIND_NAMES["RBF"], 0.1, eval_gradient=True)
+        assert abs(val[p] - vo) < 1e-10 * abs(vo)
+        assert maxrel(grad[p], go) < 1e-9
+
+
 # ---------------------------------------------------------------- fused log-likelihood: both MVN kernels vs the oracle
 @pytest.mark.parametrize("M,P", [(4, 4), (13, 5), (32, 10), (41, 7), (64, 10), (64, 3), (100, 6),
                                  (20, 1), (24, 16), (24, 17), (3, 3)])      # low-rank form: P = 1, its largest P, one beyond
