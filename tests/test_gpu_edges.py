@@ -247,3 +247,31 @@ def test_compaction_to_rows_inside_the_box_changes_no_number(tmp_path, cfg, W):
             chains[compact] = (s.chain, s.lnprobability)
         eng.tune("compact", 1)
         assert np.array_equal(chains[1][0], chains[0][0]) and np.array_equal(chains[1][1], chains[0][1])
+
+
+def test_rows_with_nan_or_infinite_parameters_are_outside_the_box(tmp_path):
+    """src/mcmc.py:275-283: `np.all((X > min) & (X < max), axis=1)` — a comparison with NaN is false, +-inf is outside:
+    such rows get -inf (log_posterior) / -1e300 (finite=True) and never reach the emulators; the other rows of the batch
+    keep their numbers bit for bit, on the host-buffer path and on the compacted device path."""
+    from gpbayestools_hic_amd import synth
+    from gpbayestools_hic_amd.workload import build_chain
+    chain, emu, info = build_chain(1, workdir=str(tmp_path))
+    d = info["d"]
+    X = synth.walkers(96, d, seed=5)
+    clean = chain.log_posterior(X)
+    assert np.all(np.isfinite(clean))
+    bad = X.copy()
+    rows = {3: np.nan, 17: np.inf, 40: -np.inf, 95: np.nan}
+    for r, v in rows.items():
+        bad[r, r % d] = v
+    bad[60, :] = np.nan                                           # every parameter NaN
+    lp = chain.log_posterior(bad)
+    ll = chain.log_likelihood(bad, finite=True)
+    out = np.zeros(96, bool); out[list(rows) + [60]] = True
+    assert np.array_equal(np.isneginf(lp), out) and np.all(ll[out] == -1e300)
+    assert np.array_equal(lp[~out], clean[~out]) and np.all(np.isfinite(ll[~out]))
+    eng = emu._engine_ready()
+    for compact in (0, 1):                                        # evaluating every row / only the rows inside the box
+        eng.tune("compact", compact)
+        assert np.array_equal(chain.log_posterior(bad), lp)
+    eng.tune("compact", 1)
