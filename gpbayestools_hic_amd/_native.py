@@ -73,6 +73,8 @@ DEBUG = {
     "gpb_debug_tune": (C.c_int, [VP, C.c_int, C.c_int]),
     "gpb_debug_has_variants": (C.c_int, []),
     "gpb_debug_fit_piece": (C.c_int, [VP, C.c_int]),
+    "gpb_debug_loopback_group": (C.c_int, [VP, C.c_int]),
+    "gpb_debug_loopback_release": (C.c_int, [VP]),
     "gpb_debug_force_generic_mvn": (C.c_int, [VP, C.c_int]),
     "gpb_debug_tile_trace": (C.c_int, [VP, c_i64]),
     "gpb_debug_tile_trace_read": (C.c_int, [VP, VP, c_i64, VP]),

@@ -7,6 +7,8 @@
 #include <math.h>
 #include <string.h>
 #include <vector>
+#include <mutex>
+#include <condition_variable>
 
 using namespace gpb;
 
@@ -681,8 +683,83 @@ extern "C" int gpb_dist_init(gpb_ctx* ctx, int rank, int nranks, const void* uid
     return 0;
 }
 
+// ---- loopback group (test hook): R contexts of ONE process, each with its own stream and driven by its own host thread, as the
+// ranks of a communicator.  The one-GPU build box cannot form an RCCL communicator of more than one rank (RCCL refuses two
+// ranks on a device), so without this the R > 1 form of gpb_chain_emcee_run — per-rank row shares, offsets into the gathered
+// vector, accept steps fed by the other ranks' log-probabilities — never runs as a whole.  The all-gather is emulated on
+// the ranks' streams: every rank records an event behind its producers, the host threads meet, every rank's stream waits
+// for every peer's event and copies the peer's block, records a second event behind its copies, the threads meet again,
+// and every stream waits for every peer's second event (a peer may still be reading this rank's block).  Same stream
+// semantics as ncclAllGather: in order on the caller's stream, asynchronous to the host after the call.
+struct LoopGroup {
+    int R = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long long gen = 0;
+    std::vector<const double*> send;
+    std::vector<hipEvent_t> ready, done;
+    std::vector<gpb_ctx*> members;
+    void meet() {
+        std::unique_lock<std::mutex> lk(m);
+        const unsigned long long g = gen;
+        if (++arrived == R) { arrived = 0; ++gen; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+
+static int loop_allgather(gpb_ctx* ctx, const double* send_dev, double* recv_dev, int64_t count) {
+    LoopGroup* G = ctx->loop;
+    const int r = ctx->rank, R = G->R;
+    GPB_HIP(hipEventRecord(G->ready[r], ctx->stream));
+    G->send[r] = send_dev;
+    G->meet();
+    for (int q = 0; q < R; ++q) {
+        if (q != r) GPB_HIP(hipStreamWaitEvent(ctx->stream, G->ready[q], 0));
+        double* dst = recv_dev + (int64_t)q * count;
+        if (dst != G->send[q])
+            GPB_HIP(hipMemcpyAsync(dst, G->send[q], sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    GPB_HIP(hipEventRecord(G->done[r], ctx->stream));
+    G->meet();
+    for (int q = 0; q < R; ++q)
+        if (q != r) GPB_HIP(hipStreamWaitEvent(ctx->stream, G->done[q], 0));
+    return 0;                                       // (the next call's first meeting keeps a fast rank from re-recording early)
+}
+
+extern "C" int gpb_debug_loopback_group(gpb_ctx* const* ctxs, int R) {
+    if (!ctxs || R < 1 || R > 64) return GPB_E_ARG;
+    for (int r = 0; r < R; ++r)
+        if (!ctxs[r] || ctxs[r]->comm || ctxs[r]->loop) return GPB_E_ARG;
+    LoopGroup* G = new LoopGroup;
+    G->R = R;
+    G->send.assign((size_t)R, nullptr);
+    G->ready.resize((size_t)R); G->done.resize((size_t)R);
+    for (int r = 0; r < R; ++r) {
+        if (hipEventCreateWithFlags(&G->ready[r], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&G->done[r], hipEventDisableTiming) != hipSuccess) return GPB_E_HIP;
+        G->members.push_back(ctxs[r]);
+    }
+    for (int r = 0; r < R; ++r) {
+        ctxs[r]->loop = G; ctxs[r]->rank = r; ctxs[r]->nranks = R;
+        ctxs[r]->comm = (void*)G;                   // "a communicator is installed": what the step loop asks
+    }
+    return 0;
+}
+
+extern "C" int gpb_debug_loopback_release(gpb_ctx* ctx) {
+    if (!ctx || !ctx->loop) return GPB_E_ARG;
+    LoopGroup* G = ctx->loop;
+    for (gpb_ctx* c : G->members) { (void)hipStreamSynchronize(c->stream); c->loop = nullptr; c->comm = nullptr; c->rank = 0; c->nranks = 1; }
+    for (hipEvent_t e : G->ready) (void)hipEventDestroy(e);
+    for (hipEvent_t e : G->done) (void)hipEventDestroy(e);
+    delete G;
+    return 0;
+}
+
 extern "C" int gpb_dist_allgather(gpb_ctx* ctx, const double* send_dev, double* recv_dev, int64_t count) {
     if (!ctx || !send_dev || !recv_dev || count < 0) return GPB_E_ARG;
+    if (ctx->loop) return loop_allgather(ctx, send_dev, recv_dev, count);
     if (!ctx->comm) GPB_FAIL(GPB_E_STATE, "gpb_dist_allgather before gpb_dist_init");
     if (g_rccl.allgather(send_dev, recv_dev, (size_t)count, NCCL_DOUBLE, ctx->comm, ctx->stream) != 0)
         GPB_FAIL(GPB_E_RCCL, "ncclAllGather failed");
@@ -691,6 +768,7 @@ extern "C" int gpb_dist_allgather(gpb_ctx* ctx, const double* send_dev, double* 
 
 extern "C" int gpb_dist_finalize(gpb_ctx* ctx) {
     if (!ctx) return GPB_E_ARG;
+    if (ctx->loop) return 0;                        // a loopback group is released as a whole (gpb_debug_loopback_release)
     if (ctx->comm && g_rccl.destroy) { g_rccl.destroy(ctx->comm); ctx->comm = nullptr; }
     return 0;
 }

@@ -20,6 +20,7 @@ __host__ __device__ inline int64_t imin64(int64_t a, int64_t b) { return a < b ?
 
 }  // namespace gpb
 
+struct LoopGroup;
 struct gpb_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -167,6 +168,7 @@ struct gpb_ctx {
     // ---- RCCL ---------------------------------------------------------------------
     void* comm = nullptr;
     int rank = 0, nranks = 1;
+    struct LoopGroup* loop = nullptr;   // test hook (gpb_debug_loopback_group): R contexts of ONE process as the ranks of a communicator
 };
 
 #define GPB_HIP(expr)                                                                   \

@@ -86,6 +86,13 @@ int gpb_debug_tune(gpb_ctx* ctx, int key, int value);
  * refuses the values that would select such a variant (waves 8, ticket queues for 64-row tiles, the 128x128 tile without the
  * read-ahead, folded tiles, LDS-DMA tiles, difference-form distances, the earlier K-build kernel, round 1's Cholesky schedule). */
 int gpb_debug_has_variants(void);
+/* test hook: make R contexts of ONE process (each with its own stream, each driven by its own host thread) the ranks 0 .. R-1 of
+ * a loopback communicator: gpb_dist_allgather / the in-stream all-gathers of gpb_chain_emcee_run are then emulated on the
+ * ranks' streams (events + device copies; the host threads meet inside the call, so every rank must make the same calls
+ * concurrently).  What a one-GPU box can run of the R > 1 step loop — everything but the RCCL wire.  Release the group
+ * (any member) before destroying its contexts. */
+int gpb_debug_loopback_group(gpb_ctx* const* ctxs, int R);
+int gpb_debug_loopback_release(gpb_ctx* ctx);
 /* measurement hook: enqueue one piece of gpb_gp_factor alone (0 = K(X,X) assembly, 1 = Cholesky, 2 = triangular inverse,
  * 3 = alpha) on the context's stream; leaves the context without a valid factorisation (call gpb_gp_factor afterwards) */
 int gpb_debug_fit_piece(gpb_ctx* ctx, int piece);

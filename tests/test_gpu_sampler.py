@@ -373,3 +373,57 @@ def test_every_ranks_share_of_the_c_loop_equals_the_host_loop_on_those_rows(tmp_
         assert max(slices) - min(s for s in slices if s) <= 60 and max(slices) <= chunk    # equal slices, within the collective's size
     eng.tune("fuse_accept_propose", 1)
     eng.tune("balance_shards", 0)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("R", [2, 4, 8])
+def test_sharded_c_loop_with_R_ranks_in_one_process(tmp_path, R):
+    """The R > 1 form of gpb_chain_emcee_run as a whole: R contexts (own streams, own host threads) joined by the loopback
+    communicator of gpb_debug_loopback_group — per-rank row shares, in-stream all-gathers, accept steps fed by the other
+    ranks' log-probabilities.  RCCL refuses two ranks on one device, so this is what a one-GPU box can run of it: everything
+    but the wire.  Every rank must hold the ensemble of the unsharded run, bit for bit (replicated draws + gathered values)."""
+    import ctypes
+    import threading
+    from gpbayestools_hic_amd import StretchSampler, synth
+    from gpbayestools_hic_amd.workload import build_chain
+    built = []
+    for r in range(R):
+        (tmp_path / ("r%d" % r)).mkdir()
+        built.append(build_chain(1, workdir=str(tmp_path / ("r%d" % r))))
+    d = built[0][2]["d"]
+    nw, nsteps = 64, 7
+    X0 = synth.walkers(nw, d, seed=31)
+    X0[::5, 0] = 0.999                                               # a few walkers at the edge: proposals leave the box
+    ref = StretchSampler(built[0][0], nw, seed=13)
+    ref.run(X0, nsteps)
+    engs = [b[1]._engine_ready() for b in built]
+    lib = engs[0].lib
+    for b in built:
+        b[0]._prepare_blocks()
+    assert lib.gpb_debug_loopback_group((ctypes.c_void_p * R)(*[e.h for e in engs]), R) == 0
+    try:
+        samplers, errors = [None] * R, []
+
+        def work(r):
+            try:
+                sh = types.SimpleNamespace(world=R, rank=r, direct=engs[r], logprob=lambda fn, X, out: fn(X, out),
+                                           _all_ok=lambda ok: ok)
+                s = StretchSampler(built[r][0], nw, seed=13, sharding=sh)
+                assert s._resident_engine() is not None and s._resident_engine()[0] is engs[r]
+                s.run(X0, nsteps)
+                samplers[r] = s
+            except Exception as e:                                    # a failing rank would leave the others waiting
+                errors.append((r, repr(e)))
+
+        threads = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(R)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        assert not errors and all(not t.is_alive() for t in threads), errors
+        for r in range(R):
+            assert np.array_equal(samplers[r].chain, ref.chain), r
+            assert np.array_equal(samplers[r].lnprobability, ref.lnprobability), r
+            assert np.array_equal(samplers[r].naccept.cpu().numpy(), ref.naccept.cpu().numpy()), r
+    finally:
+        assert lib.gpb_debug_loopback_release(engs[0].h) == 0
