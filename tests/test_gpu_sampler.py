@@ -427,3 +427,55 @@ def test_sharded_c_loop_with_R_ranks_in_one_process(tmp_path, R):
             assert np.array_equal(samplers[r].naccept.cpu().numpy(), ref.naccept.cpu().numpy()), r
     finally:
         assert lib.gpb_debug_loopback_release(engs[0].h) == 0
+
+
+@pytest.mark.timeout(300)
+def test_sharded_c_loop_over_a_chain_of_emulators(tmp_path):
+    """... and the same for a chain of three emulators (mixed kernels, batched cross / predict / likelihood launches) on two
+    and three loopback ranks: the first emulator's context carries the communicator, every rank ends on the unsharded ensemble."""
+    import ctypes
+    import threading
+    from gpbayestools_hic_amd import StretchSampler, synth
+    from gpbayestools_hic_amd.workload import build_multi_chain
+    specs = [(96, 12, 3, "RBF"), (128, 20, 4, "Matern25"), (80, 9, 2, "RBF")]
+    D = 6
+    for R in (2, 3):
+        built = []
+        for r in range(R):
+            wd = tmp_path / ("R%d_r%d" % (R, r)); wd.mkdir()
+            built.append(build_multi_chain(specs, D, workdir=str(wd)))
+        nw, nsteps = 48, 5                                            # 24 rows a batch: 12 / 8 per rank
+        X0 = np.clip(built[0][2]["xstar"] + 0.05 * np.random.default_rng(2).standard_normal((nw, D)), 0.02, 0.98)
+        ref = StretchSampler(built[0][0], nw, seed=21)
+        assert ref._resident_engine()[2] == 3
+        ref.run(X0, nsteps)
+        firsts = [b[1][0]._engine_ready() for b in built]            # the communicator lives on the chain's first context
+        for b in built:
+            b[0]._prepare_blocks()
+        lib = firsts[0].lib
+        assert lib.gpb_debug_loopback_group((ctypes.c_void_p * R)(*[e.h for e in firsts]), R) == 0
+        try:
+            samplers, errors = [None] * R, []
+
+            def work(r):
+                try:
+                    sh = types.SimpleNamespace(world=R, rank=r, direct=firsts[r], logprob=lambda fn, X, out: fn(X, out),
+                                               _all_ok=lambda ok: ok)
+                    s = StretchSampler(built[r][0], nw, seed=21, sharding=sh)
+                    assert s._resident_engine() is not None
+                    s.run(X0, nsteps)
+                    samplers[r] = s
+                except Exception as e:
+                    errors.append((r, repr(e)))
+
+            threads = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(R)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join(timeout=120)
+            assert not errors and all(not t.is_alive() for t in threads), errors
+            for r in range(R):
+                assert np.array_equal(samplers[r].chain, ref.chain), (R, r)
+                assert np.array_equal(samplers[r].lnprobability, ref.lnprobability), (R, r)
+        finally:
+            assert lib.gpb_debug_loopback_release(firsts[0].h) == 0
