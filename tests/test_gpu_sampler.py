@@ -376,12 +376,16 @@ def test_every_ranks_share_of_the_c_loop_equals_the_host_loop_on_those_rows(tmp_
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("balance", [0, 2])
 @pytest.mark.parametrize("R", [2, 4, 8])
-def test_sharded_c_loop_with_R_ranks_in_one_process(tmp_path, R):
+def test_sharded_c_loop_with_R_ranks_in_one_process(tmp_path, R, balance):
     """The R > 1 form of gpb_chain_emcee_run as a whole: R contexts (own streams, own host threads) joined by the loopback
     communicator of gpb_debug_loopback_group — per-rank row shares, in-stream all-gathers, accept steps fed by the other
     ranks' log-probabilities.  RCCL refuses two ranks on one device, so this is what a one-GPU box can run of it: everything
-    but the wire.  Every rank must hold the ensemble of the unsharded run, bit for bit (replicated draws + gathered values)."""
+    but the wire.  Every rank must hold the ensemble of the unsharded run, bit for bit (replicated draws + gathered values).
+    balance = 2: every rank takes an equal slice of the ordered list of ALL rows inside the box (k_balance_gather, tune key
+    36; off by default) instead of the rows inside the box of its own contiguous share — the check a multi-rank run owed
+    before that mode may be switched on."""
     import ctypes
     import threading
     from gpbayestools_hic_amd import StretchSampler, synth
@@ -401,6 +405,8 @@ def test_sharded_c_loop_with_R_ranks_in_one_process(tmp_path, R):
     for b in built:
         b[0]._prepare_blocks()
     assert lib.gpb_debug_loopback_group((ctypes.c_void_p * R)(*[e.h for e in engs]), R) == 0
+    for e in engs:
+        e.tune("balance_shards", balance)
     try:
         samplers, errors = [None] * R, []
 
