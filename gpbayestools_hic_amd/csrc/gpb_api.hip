@@ -747,13 +747,29 @@ extern "C" int gpb_debug_loopback_group(gpb_ctx* const* ctxs, int R) {
     return 0;
 }
 
-extern "C" int gpb_debug_loopback_release(gpb_ctx* ctx) {
-    if (!ctx || !ctx->loop) return GPB_E_ARG;
-    LoopGroup* G = ctx->loop;
-    for (gpb_ctx* c : G->members) { (void)hipStreamSynchronize(c->stream); c->loop = nullptr; c->comm = nullptr; c->rank = 0; c->nranks = 1; }
+static void loop_free(LoopGroup* G) {
     for (hipEvent_t e : G->ready) (void)hipEventDestroy(e);
     for (hipEvent_t e : G->done) (void)hipEventDestroy(e);
     delete G;
+}
+// a member leaves (its context is being destroyed without a release of the group): the group forgets it and goes with its last member
+static void loop_detach(gpb_ctx* ctx) {
+    LoopGroup* G = ctx->loop;
+    bool any = false;
+    for (gpb_ctx*& c : G->members) {
+        if (c == ctx) c = nullptr;
+        any = any || c != nullptr;
+    }
+    ctx->loop = nullptr; ctx->comm = nullptr; ctx->rank = 0; ctx->nranks = 1;
+    if (!any) loop_free(G);
+}
+
+extern "C" int gpb_debug_loopback_release(gpb_ctx* ctx) {
+    if (!ctx || !ctx->loop) return GPB_E_ARG;
+    LoopGroup* G = ctx->loop;
+    for (gpb_ctx* c : G->members)
+        if (c) { (void)hipStreamSynchronize(c->stream); c->loop = nullptr; c->comm = nullptr; c->rank = 0; c->nranks = 1; }
+    loop_free(G);
     return 0;
 }
 
@@ -768,7 +784,7 @@ extern "C" int gpb_dist_allgather(gpb_ctx* ctx, const double* send_dev, double* 
 
 extern "C" int gpb_dist_finalize(gpb_ctx* ctx) {
     if (!ctx) return GPB_E_ARG;
-    if (ctx->loop) return 0;                        // a loopback group is released as a whole (gpb_debug_loopback_release)
+    if (ctx->loop) { loop_detach(ctx); return 0; }  // (normally the group is released as a whole: gpb_debug_loopback_release)
     if (ctx->comm && g_rccl.destroy) { g_rccl.destroy(ctx->comm); ctx->comm = nullptr; }
     return 0;
 }

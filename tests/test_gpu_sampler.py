@@ -485,3 +485,19 @@ def test_sharded_c_loop_over_a_chain_of_emulators(tmp_path):
                 assert np.array_equal(samplers[r].lnprobability, ref.lnprobability), (R, r)
         finally:
             assert lib.gpb_debug_loopback_release(firsts[0].h) == 0
+
+
+def test_loopback_group_survives_a_member_being_destroyed():
+    """test hook hygiene: a context that is destroyed without a release of its loopback group leaves the group; the group goes
+    with its last member or with an explicit release"""
+    import ctypes
+    from gpbayestools_hic_amd import GPEngine
+    a, b, c = GPEngine(0), GPEngine(0), GPEngine(0)
+    lib = a.lib
+    assert lib.gpb_debug_loopback_group((ctypes.c_void_p * 3)(a.h, b.h, c.h), 3) == 0
+    assert lib.gpb_debug_loopback_group((ctypes.c_void_p * 2)(a.h, b.h), 2) < 0        # already members of a group
+    b.close()
+    assert lib.gpb_debug_loopback_release(a.h) == 0
+    assert lib.gpb_debug_loopback_release(a.h) < 0                                     # released: no group
+    assert lib.gpb_debug_loopback_group((ctypes.c_void_p * 2)(a.h, c.h), 2) == 0
+    a.close(); c.close()                                                               # the group goes with its last member
