@@ -1168,9 +1168,14 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev) {
             // a whole-tile count made a rank's ~495 live rows flip between 4 and 5 tiles of 128, i.e. between two shapes
             const double f128 = (double)(GP * ((ctx->Np + 127) / 128)) * (double)Wsel / 128.0 * 256.0 / ctx->num_cu;
             const double f64 = (double)(GP * nI64) * (double)Wsel / 64.0 * 256.0 / ctx->num_cu;
+            // ... and the 64x32 / 64x64 switch point moves with the design size below N = 2048: a tile's K loop is half as
+            // long at N = 1024 and its fixed cost (first loads, reduction, barriers) weighs twice as much, so the wider tile pays
+            // from half as many tiles on (tools/gpu_tile_rule_sweep.py, profiles/r03_tile_rule_sweep.txt: cfg 3 at 512 live
+            // rows 64x64 0.263 ms/step against 64x32 0.287; at 256 rows 64x32 0.179 against 0.199)
+            const double nscale = ctx->Np < 2048 ? (double)ctx->Np / 2048.0 : 1.0;
             if (f128 >= (double)sw128) T = TN = 128;
-            else if (f64 * 0.5 >= (double)swmid) TN = 128;
-            else if (f64 >= (double)swnarrow) TN = 64;
+            else if (f64 * 0.5 >= (double)swmid / nscale) TN = 128;          // (N = 1024: 64x128 from twice as many tiles on)
+            else if (f64 >= (double)swnarrow * nscale) TN = 64;
         } else if (tiles128 * 256 >= sw128 * ctx->num_cu) T = TN = 128;
         else if (tiles64x128 * 256 >= swmid * ctx->num_cu) TN = 128;
         else if (tiles64 * 256 >= swnarrow * ctx->num_cu) TN = 64;
