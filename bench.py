@@ -306,6 +306,14 @@ def main():
         smp = sampler if seed is None else StretchSampler(chain, nwalkers, seed=seed, sharding=sharding, device=local)
         if seed is not None and loop.startswith("host-driven"):
             smp._resident_engine = lambda: None
+        # untimed pre-heat on a scratch sampler (its own ensemble; the same number of steps on every rank): the clocks and —
+        # sharded — RCCL's channels are up before the W warm-up steps, whatever W is.  (A configuration measured first after an
+        # idle gap read 3-5 % slow at sub-millisecond steps: tools/gpu_tile_rule_sweep.py.)
+        heat = StretchSampler(chain, nwalkers, seed=4242, sharding=sharding, device=local)
+        if loop.startswith("host-driven"):
+            heat._resident_engine = lambda: None
+        heat.run(X_start, 100, status=10 ** 9, store=False)
+        del heat
         smp.run(X_start, args.warmup, status=10 ** 9, store=False)
         eng.profile(True)
         barrier()
@@ -381,6 +389,7 @@ def main():
                                    f"fixed hyper-parameters, burnt-in ensemble (ball of relative radius {ball:.1e} "
                                    f"around theta*)", "walkers": nwalkers,
                        "parallelism": f"walker-shard x{world}" if world > 1 else "single GPU", "step_loop": loop,
+                       "untimed_preheat": "100 steps of the same loop on a scratch ensemble before the W warm-up steps (clocks, RCCL channels)",
                        "allgather": None if world == 1 else (
                            "gpb_dist_allgather (ncclAllGather on the kernel stream)" if sharding.direct is not None
                            else "torch.distributed " + dist.get_backend()
