@@ -77,6 +77,11 @@ def main():
     for world in worlds:
         row = {"config": cfg, "walkers": nw, "ranks_simulated": world, "walkers_per_rank_per_batch": nw // 2 // world, "collective_enqueued": comm and world > 1}
         eng.tune("sim_ranks", world if world > 1 else 0)
+        # pre-heat on a scratch ensemble (clocks up whatever the step length: 8 steps of a 0.4 ms step are not enough; the
+        # measured ensemble itself must stay short of ~60 steps from a 1e-13 ball, or it has spread to the box)
+        heat = StretchSampler(chain, nw, seed=99)
+        heat.run(X0, 100, store=False, status=10 ** 9)
+        del heat
         s = StretchSampler(chain, nw, seed=1)
         assert s._resident_engine()[0] is eng
         s.run(X0, 3, store=False, status=10 ** 9)
