@@ -232,6 +232,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--preheat", type=int, default=100, help="untimed steps on a scratch ensemble before the warm-up (clock ramp)")
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--walkers", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -312,7 +313,8 @@ def main():
         heat = StretchSampler(chain, nwalkers, seed=4242, sharding=sharding, device=local)
         if loop.startswith("host-driven"):
             heat._resident_engine = lambda: None
-        heat.run(X_start, 100, status=10 ** 9, store=False)
+        if args.preheat > 0:
+            heat.run(X_start, args.preheat, status=10 ** 9, store=False)
         del heat
         smp.run(X_start, args.warmup, status=10 ** 9, store=False)
         eng.profile(True)
@@ -389,7 +391,7 @@ def main():
                                    f"fixed hyper-parameters, burnt-in ensemble (ball of relative radius {ball:.1e} "
                                    f"around theta*)", "walkers": nwalkers,
                        "parallelism": f"walker-shard x{world}" if world > 1 else "single GPU", "step_loop": loop,
-                       "untimed_preheat": "100 steps of the same loop on a scratch ensemble before the W warm-up steps (clocks, RCCL channels)",
+                       "untimed_preheat": f"{args.preheat} steps of the same loop on a scratch ensemble before the W warm-up steps (clocks, RCCL channels)",
                        "allgather": None if world == 1 else (
                            "gpb_dist_allgather (ncclAllGather on the kernel stream)" if sharding.direct is not None
                            else "torch.distributed " + dist.get_backend()
