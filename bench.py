@@ -343,14 +343,15 @@ def main():
     _, dt, launches, kms, units, units_all = timed_run(X0, None)
     acc = float(sampler.acceptance_fraction.mean())
     inside_frac = (units_all / (launches * P * (nwalkers // 2))) if launches else None      # all ranks' rows
-    if inside_frac is not None and inside_frac < 0.95:          # the same number on every rank: all leave together
-        if rank == 0:
-            print(f"bench.py: only {inside_frac:.3f} of the timed region's proposal rows lay inside the prior box; the "
-                  f"headline must be measured on a burnt-in ensemble (>= 0.95): use fewer --steps / --warmup than "
-                  f"{args.steps} / {args.warmup}", file=sys.stderr)
-        if world > 1:
-            dist.destroy_process_group()
-        sys.exit(3)
+    # The headline is measured on a burnt-in ensemble (>= 0.95 of the proposal rows inside the prior box and evaluated).  The
+    # stretch move grows a ball by ~1.45x per step and this posterior is as wide as the box in ten of its twenty directions
+    # (10 GPs), so beyond ~60 warm-up + timed steps no start keeps every row inside.  Then the line is still printed, but
+    # `value` counts EVALUATED walkers only (= value_evaluated; never rows that cost nothing) and says so.
+    degraded = inside_frac is not None and inside_frac < 0.95      # the same number on every rank
+    if degraded and rank == 0:
+        print(f"bench.py: only {inside_frac:.3f} of the timed region's proposal rows lay inside the prior box "
+              f"(--steps {args.steps} --warmup {args.warmup}: more than ~60 steps in all); `value` counts evaluated "
+              f"walkers only", file=sys.stderr)
     consistent = None
     if world > 1:       # replicated RNG + gathered log-probabilities: every rank must hold the same ensemble
         chk = torch.stack([sampler.pos.sum(), sampler.lp.sum()])
@@ -384,7 +385,7 @@ def main():
         del su
 
     if rank == 0:
-        value = nwalkers * args.steps / dt
+        value = nwalkers * args.steps / dt if not degraded else units_all / P / dt
         alg_flops_per_launch = units / max(launches, 1) * float(N) * float(N)     # N^2 per (GP, walker): the trsm term
         achieved = alg_flops_per_launch / (kms / max(launches, 1) * 1e-3) / 1e12 if launches else None
         gflop_step = flops_per_walker(N, d, P, M, info["kernel"]) * nwalkers / 1e9
@@ -396,7 +397,9 @@ def main():
             "config": {"workload": f"BASELINE config {args.config}: {N} design pts x {d} params x {M} observables, "
                                    f"{P} GPs ({info['kernel']}), {nwalkers} walkers, stretch move, "
                                    f"fixed hyper-parameters, burnt-in ensemble (ball of relative radius {ball:.1e} "
-                                   f"around theta*)", "walkers": nwalkers,
+                                   f"around theta*)"
+                                   + ("; the ensemble reached the box inside the timed region: value = evaluated walkers only"
+                                      if degraded else ""), "walkers": nwalkers,
                        "parallelism": f"walker-shard x{world}" if world > 1 else "single GPU", "step_loop": loop,
                        "untimed_preheat": f"{args.preheat} steps of the same loop on a scratch ensemble before the W warm-up steps (clocks, RCCL channels)",
                        "allgather": None if world == 1 else (
