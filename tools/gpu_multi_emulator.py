@@ -28,7 +28,10 @@ def main():
         if a.startswith("--tune="):                  # e.g. --tune=chain_batch:0 (set on every emulator's engine)
             k, v = a[7:].split(":")
             for e in emus:
-                e._engine_ready().tune(k, int(v))
+                if k == "force_tile":                    # 0 = rule, 32 / 64 / 65 / 128 (65 = 64 rows x 128 walkers)
+                    e._engine_ready().force_tile(int(v))
+                else:
+                    e._engine_ready().tune(k, int(v))
             print(json.dumps({"tune": {k: int(v)}}), flush=True)
     X = torch.as_tensor(synth.walkers(nw // 2, d), device="cuda")
     row = {"emulators": 9, "N": N, "d": d, "observables": chain.nobs, "GPs": sum(s[2] for s in specs), "rows": nw // 2}
