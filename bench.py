@@ -173,20 +173,102 @@ def extras(chain4, emu4, info4):
     # search costs: sk:_gpr.py:537-652): K build, Cholesky, L^-1, alpha, K^-1 = L^-T L^-1, the d + 2 derivative reductions
     th4 = synth.fixed_theta(info4["d"], info4["P"])
     t = timed(lambda: eng4.lml(th4), 5)
-    fl = 4.0 / 3.0 * info4["N"] ** 3 * info4["P"]
+    fpair4 = 3 * info4["d"] + 3 if info4["kernel"] == "RBF" else 3 * info4["d"] + 10
+    fl = info4["P"] * (float(info4["N"]) ** 3 + float(info4["N"]) ** 2 * (fpair4 + 2 * (info4["d"] + 2)))
+    fl_exec = 4.0 / 3.0 * info4["N"] ** 3 * info4["P"]
     out["lml_grad_cfg4"] = {"N": info4["N"], "d": info4["d"], "gps": info4["P"], "ms": t * 1e3,
                             "roofline": {"bound": "mfma", "kernel": "gpb_gp_lml: k_kmat_mfma, Cholesky chain, k_trtri_level, k_kinv, k_lml_grad",
                                          "flops": fl, "achieved": fl / t / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
-                                         "unit": "TFLOP/s", "frac": fl / t / 1e12 / FP64_MFMA_PEAK_TFLOPS},
+                                         "unit": "TFLOP/s", "frac": fl / t / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                         "frac_executed_flops": fl_exec / t / 1e12 / FP64_MFMA_PEAK_TFLOPS},
                             "what": "one LML + gradient evaluation of all GPs incl. the download of value and gradient; "
-                                    "flops = P (N^3/3 Cholesky + N^3/3 inverse + 2N^3/3 K^-1) = 4/3 N^3 P"}
+                                    "algorithmic flops per SURVEY 8(d) = P (N^3 + N^2 (F_pair + 2 (d + 2))) (Cholesky + inverse counted "
+                                    "as N^3); frac_executed_flops counts what the path executes, P 4/3 N^3 (N^3/3 Cholesky + N^3/3 "
+                                    "triangular inverse + 2 N^3/3 K^-1 = L^-T L^-1)"}
     emu4._engine_ready().set_theta(emu4.thetas_)
     emu4._engine_ready().factor()
+
+    # BASELINE config 3 (1 x MI355X: 1024 design pts x 15 params, emcee stretch move with 1024 walkers, src/mcmc.py:372-412):
+    # the resident step loop on a burnt-in ensemble, every proposal row evaluated, as the headline is measured
+    from gpbayestools_hic_amd.sampler import StretchSampler
+    from gpbayestools_hic_amd.workload import flops_per_walker
+    chain3, emu3, info3 = build_chain(3)
+    eng3 = emu3._engine_ready()
+    nw3, warm3, nst3 = 2 * info3["W"], 3, 40
+    ball3 = float(min(1e-3, max(1e-13, 10.0 ** (-3.0 - 0.16 * (warm3 + nst3)))))
+    X03 = synth.walkers_ball(nw3, info3["xstar"], ball3, lo=info3["lo"], hi=info3["hi"])
+    heat = StretchSampler(chain3, nw3, seed=4242)
+    heat.run(X03, 100, status=10 ** 9, store=False)
+    del heat
+    s3 = StretchSampler(chain3, nw3, seed=12345)
+    assert s3._resident_engine() is not None
+    s3.run(X03, warm3, status=10 ** 9, store=False)
+    eng3.profile(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s3.run(None, nst3, status=10 ** 9, store=False)
+    torch.cuda.synchronize()
+    dt3 = (time.perf_counter() - t0) / nst3
+    n_l, ms_l, u_l = eng3.profile_read()
+    eng3.profile(False)
+    inside3 = u_l / (n_l * info3["P"] * (nw3 // 2)) if n_l else None
+    mf3 = flops_per_walker(info3["N"], info3["d"], info3["P"], info3["M"], info3["kernel"])
+    tfk3 = u_l / n_l * float(info3["N"]) ** 2 / (ms_l / n_l * 1e-3) / 1e12 if n_l else None
+    out["cfg3_step"] = {"N": info3["N"], "d": info3["d"], "gps": info3["P"], "observables": info3["M"], "walkers": nw3,
+                        "steps": nst3, "warmup": warm3, "ms_per_step": dt3 * 1e3, "walker_evals_per_s": nw3 / dt3,
+                        "rows_inside_box_fraction": inside3, "acceptance_fraction": float(s3.acceptance_fraction.mean()),
+                        "mflop_per_walker_algorithmic": mf3 / 1e6,
+                        "tflops_algorithmic": mf3 * nw3 * (inside3 or 1.0) / dt3 / 1e12,
+                        "frac_of_peak_whole_step": mf3 * nw3 * (inside3 or 1.0) / dt3 / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                        "roofline": {"bound": "mfma", "kernel": "k_predict (512-row batches)", "achieved": tfk3,
+                                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": tfk3 / FP64_MFMA_PEAK_TFLOPS if tfk3 else None, "launches": n_l,
+                                     "avg_launch_ms": ms_l / max(n_l, 1)},
+                        "what": "BASELINE config 3: stretch-move steps of 1024 walkers (two 512-row log-posterior batches each) through "
+                                "gpb_chain_emcee_run, burnt-in ensemble, behind 100 untimed pre-heat steps; algorithmic flops per SURVEY "
+                                "8(d) (11.05 MF per walker); roofline = k_predict's N^2 per (GP, row) over its HIP-event times"}
+    del s3
+    emu3._engine.close()
+
+    # BASELINE config 5 (pocoMC: 8192 particles, Matern-5/2, 4096-pt design): the call pocoMC makes,
+    # log_likelihood(X[8192, d], finite=True) with vectorize=True (src/mcmc.py:798-805) — device-resident and through numpy
+    chain5, emu5, info5 = build_chain(5)
+    eng5c = emu5._engine_ready()
+    W5 = info5["W"]
+    Xh5 = synth.walkers(W5, info5["d"], seed=synth.SEED + 11)             # pocoMC's particles lie inside the prior box
+    Xd5 = torch.as_tensor(Xh5, device="cuda")
+    lp5 = torch.empty(W5, dtype=torch.float64, device="cuda")
+    for _ in range(2):
+        chain5.log_prob_device(Xd5, lp5, outside=-1e300)
+    torch.cuda.synchronize()
+    eng5c.profile(True)
+    t5 = timed(lambda: chain5.log_prob_device(Xd5, lp5, outside=-1e300), 5)
+    n_l, ms_l, u_l = eng5c.profile_read()
+    eng5c.profile(False)
+    ths = []
+    for _ in range(3):
+        t0 = time.perf_counter(); ll5 = chain5.log_likelihood(Xh5, finite=True); ths.append(time.perf_counter() - t0)
+    assert ll5.shape == (W5,) and np.all(np.isfinite(ll5)) and np.all(ll5 > -1e299)
+    mf5 = flops_per_walker(info5["N"], info5["d"], info5["P"], info5["M"], info5["kernel"])
+    tfk5 = u_l / n_l * float(info5["N"]) ** 2 / (ms_l / n_l * 1e-3) / 1e12 if n_l else None
+    out["cfg5_batch"] = {"N": info5["N"], "d": info5["d"], "gps": info5["P"], "observables": info5["M"], "kernel": info5["kernel"],
+                         "rows_per_batch": W5, "ms_per_batch": t5 * 1e3, "batches_per_s": 1.0 / t5, "rows_per_s": W5 / t5,
+                         "host_call_ms_per_batch": sorted(ths)[1] * 1e3, "host_call_rows_per_s": W5 / sorted(ths)[1],
+                         "mflop_per_row_algorithmic": mf5 / 1e6, "tflops_algorithmic": mf5 * W5 / t5 / 1e12,
+                         "frac_of_peak_whole_batch": mf5 * W5 / t5 / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                         "roofline": {"bound": "mfma", "kernel": "k_predict (8192-row batches, N = 4096)", "achieved": tfk5,
+                                      "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": tfk5 / FP64_MFMA_PEAK_TFLOPS if tfk5 else None, "launches": n_l,
+                                      "avg_launch_ms": ms_l / max(n_l, 1)},
+                         "what": "BASELINE config 5: Chain.log_likelihood(X[8192, 20], finite=True) batches as pocoMC calls them "
+                                 "(vectorize=True), every row inside the prior box; ms_per_batch: rows and results resident in HBM; "
+                                 "host_call: numpy in, numpy out (PCIe inclusive, median of three); algorithmic flops per SURVEY 8(d) "
+                                 "(171.0 MF per row)"}
+    emu5._engine.close()
 
     # a chain at the size of the reference's real analyses: nine emulators with their own designs, kernels and numbers of
     # GPs over one 20-parameter space, 540 observables, block-diagonal covariance (src/mcmc.py:153-166,
     # examples/RunBayesianAnalysis.ipynb:35-48), 4096 walkers, the whole step loop in gpb_chain_emcee_run
-    from gpbayestools_hic_amd.sampler import StretchSampler
     from gpbayestools_hic_amd.workload import build_multi_chain
     specs = [(1000, 60, 6 + i % 3, ("RBF", "Matern25", "RBF")[i % 3]) for i in range(9)]
     mchain, memus, minfo = build_multi_chain(specs, 20)
@@ -218,15 +300,16 @@ def extras(chain4, emu4, info4):
         # all nine designs pad to Np = 1024, so ONE predict launch per half-step covers the 63 GPs (k_predict_multi) and the
         # first context counts units for all of them; launched one by one (tune chain_batch 0) it counts its own GPs only
         live_rows = u0 / (gps if nl == n0 else specs[0][2])
-        units = gps * live_rows * 1024.0 ** 2      # (GP, row) pairs x Np^2 (1000 design points pad to 1024)
+        units = gps * live_rows * 1000.0 ** 2      # (GP, row) pairs x N^2: the algorithmic count (the kernel multiplies Np = 1024)
         nine[tag] = {"ms_per_step": dtm * 1e3, "walker_evals_per_s": nwm / dtm,
-                     "rows_inside_box_fraction": units / 1024.0 ** 2 / (gps * nwm * nst),
+                     "rows_inside_box_fraction": live_rows / (nwm * nst),
+                     "tflops_algorithmic_step": gps * live_rows / nst * 1000.0 ** 2 / dtm / 1e12,
                      "k_predict_launches_per_step": nl / nst, "k_predict_ms_per_step": kms / nst,
                      "k_predict_tflops": units / (kms * 1e-3) / 1e12 if kms else None,
                      "k_predict_frac_of_peak": units / (kms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS if kms else None}
         del sm
     nine["what"] = ("stretch-move steps of a nine-emulator chain through gpb_chain_emcee_run; k_predict figures: algorithmic "
-                    "flops Np^2 per evaluated (GP, row) over the HIP-event times of the predict launches (one per half-step for all nine "
+                    "flops N^2 = 1000^2 per evaluated (GP, row) over the HIP-event times of the predict launches (one per half-step for all nine "
                     "emulators: k_predict_multi)")
     out["nine_emulator_chain"] = nine
     for e in memus:

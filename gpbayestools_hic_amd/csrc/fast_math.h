@@ -11,12 +11,16 @@ namespace gpb {
 // exp(x) for x <= 0 without the library's special-case selects, its coefficients in SGPRs (scalar loads from constant
 // memory: as immediates the compiler re-materialised them in VGPRs with two v_mov_b32 each — 12 per evaluation, a sixth of
 // the kernel's vector instructions).  n = rint(x log2 e), r = x - n ln 2 (two-term), e^r by the Taylor polynomial of degree
-// 13 (|r| <= ln 2 / 2: truncation 4e-18), 2^n by v_ldexp_f64 (underflows to 0 for n < -1074: x = -inf gives 0).
+// 13 (|r| <= ln 2 / 2: truncation 4e-18), 2^n by v_ldexp_f64 (underflows to 0 for n < -1074).  x is clamped at -746 first
+// (exp(-746) rounds to 0): without the clamp n = rint(x log2 e) stops being exact beyond |x| ~ 2^53, r stops being small, the
+// polynomial overflows and x = -inf gives NaN (fma(-inf, -ln 2, -inf)) where the library exp of k_kcross gives 0 — extreme
+// theta then left NaN in K(X,X) and 0 in K*.
 // 1-2 ulp; numpy's exp, which sklearn calls, is within 1 ulp: 4e-16 relative between the two (the G1 / G2 bars: 1e-13, 1e-11).
 static __constant__ double EXP_C[16] = {1.4426950408889634, -6.93147180369123816490e-01, -1.90821492927058770002e-10,
                                  1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0,
                                  1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0 / 3.0};
 __device__ __forceinline__ double exp_nonpos(double x) {
+    x = fmax(x, -746.0);
     const double n = __builtin_rint(x * EXP_C[0]);
     double r = fma(n, EXP_C[1], x);
     r = fma(n, EXP_C[2], r);

@@ -129,7 +129,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     gpb_dist_finalize(ctx);
     free(ctx->h_theta);
     dev_free(&ctx->lr_R); dev_free(&ctx->lr_v0);
-    dev_free(&ctx->xmean); dev_free(&ctx->muS); dev_free(&ctx->Xc); dev_free(&ctx->dnorm);
+    dev_free(&ctx->xmean); dev_free(&ctx->muS); dev_free(&ctx->Xc); dev_free(&ctx->dnorm); dev_free(&ctx->gpform);
     dev_free(&ctx->X); dev_free(&ctx->Xsc); dev_free(&ctx->ls); dev_free(&ctx->amp); dev_free(&ctx->noise);
     dev_free(&ctx->Z); dev_free(&ctx->K); dev_free(&ctx->Linv); dev_free(&ctx->LinvT); dev_free(&ctx->T); dev_free(&ctx->yv);
     dev_free(&ctx->alpha); dev_free(&ctx->apart); dev_free(&ctx->info); dev_free(&ctx->lmlbuf);
@@ -228,9 +228,45 @@ extern "C" int gpb_gp_set(gpb_ctx* ctx, int64_t N, int64_t d, int64_t P, const d
         for (int64_t i = 0; i < N; ++i) sum += X_host[i * d + k];
         xm[k] = sum / (double)N;
     }
+    ctx->h_ext.assign((size_t)d, 0.0);                // column extents: what a length scale is compared with (choose_forms)
+    for (int64_t k = 0; k < d; ++k) {
+        double lo = X_host[k], hi = X_host[k];
+        for (int64_t i = 1; i < N; ++i) { lo = fmin(lo, X_host[i * d + k]); hi = fmax(hi, X_host[i * d + k]); }
+        ctx->h_ext[(size_t)k] = hi - lo;
+    }
+    ctx->h_form.assign((size_t)P, 0);
+    ctx->n_diff = 0;
+    if ((rc = dev_alloc(ctx, &ctx->gpform, P))) return rc;
+    GPB_HIP(hipMemset(ctx->gpform, 0, sizeof(int) * P));
     GPB_HIP(hipMemcpy(ctx->xmean, xm.data(), sizeof(double) * xm.size(), hipMemcpyHostToDevice));
     GPB_HIP(hipMemcpy(ctx->X, xp.data(), sizeof(double) * xp.size(), hipMemcpyHostToDevice));
     GPB_HIP(hipMemcpy(ctx->Z, zp.data(), sizeof(double) * zp.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// The distance form of every GP, from theta and the design's extents alone — never from a batch's size or a rank's share, so a
+// walker's bits do not depend on how the ensemble is split.  S_p = sum_k (extent_k / l_pk)^2 bounds |a|^2 and, for queries
+// inside the design's box, |b|^2 of the centred Gram form, whose cancellation error in r^2 is ~eps (|a|^2 + |b|^2); the
+// kernels' slope |dk / d r^2| is at most 1/2 (RBF), 3/2 (Matern-3/2), 5/6 (Matern-5/2).  At S <= 1024 the Gram form keeps K and K*
+// within ~2e-13; at the reference's Matern lower bound (l = 1e-3 x extent: S = 1e6, src/emulator.py:292-297) it would lose
+// 3e-10 in K* and 2.5e-9 in the predictive variance, and those GPs take sklearn's own difference form.
+int gpb::choose_forms(gpb_ctx* ctx) {
+    const int64_t P = ctx->P, d = ctx->d;
+    int ndiff = 0;
+    for (int64_t p = 0; p < P; ++p) {
+        const double* th = ctx->h_theta + p * (d + 2);
+        double S = 0.0;
+        for (int64_t k = 0; k < d; ++k) {
+            const double q = ctx->h_ext[(size_t)k] / exp(th[1 + k]);
+            S += q * q;
+        }
+        const int f = ctx->kcross_dot == 0 ? 1 : (ctx->kcross_dot == 2 ? 0 : ((S > ctx->gram_limit || !(S == S)) ? 1 : 0));
+        ctx->h_form[(size_t)p] = f;
+        ndiff += f;
+    }
+    ctx->n_diff = ndiff;
+    GPB_HIP(hipMemcpyAsync(ctx->gpform, ctx->h_form.data(), sizeof(int) * P, hipMemcpyHostToDevice, ctx->stream));
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
@@ -254,8 +290,9 @@ extern "C" int gpb_gp_set_theta(gpb_ctx* ctx, const double* theta_host) {
     GPB_HIP(hipMemcpy(ctx->ls, ls.data(), sizeof(double) * ls.size(), hipMemcpyHostToDevice));
     GPB_HIP(hipMemcpy(ctx->amp, amp.data(), sizeof(double) * P, hipMemcpyHostToDevice));
     GPB_HIP(hipMemcpy(ctx->noise, noise.data(), sizeof(double) * P, hipMemcpyHostToDevice));
-    int rc = launch_scale_design(ctx);
+    int rc = choose_forms(ctx);
     if (rc) return rc;
+    if ((rc = launch_scale_design(ctx))) return rc;
     ctx->have_theta = true;
     ctx->factored = false;
     return 0;
@@ -301,6 +338,22 @@ extern "C" int gpb_gp_get(gpb_ctx* ctx, int what, double* out_host) {
     if (what == GPB_GET_ALPHA) {
         for (int64_t p = 0; p < P; ++p)
             GPB_HIP(hipMemcpy(out_host + p * N, ctx->alpha + p * Np, sizeof(double) * N, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    if (what == GPB_GET_FORM) {
+        for (int64_t p = 0; p < P; ++p) out_host[p] = (double)ctx->h_form[(size_t)p];
+        return 0;
+    }
+    if (what == GPB_GET_KSTAR) {                       // KsT is [P][Np][Wld], walker fastest: transposed on the host
+        const int64_t W = ctx->last_W, Wld = ctx->Wld;
+        if (W <= 0 || !ctx->KsT) GPB_FAIL(GPB_E_STATE, "gpb_gp_get(GPB_GET_KSTAR): no batch has been evaluated");
+        std::vector<double> tmp((size_t)(N * W));
+        for (int64_t p = 0; p < P; ++p) {
+            GPB_HIP(hipMemcpy2D(tmp.data(), sizeof(double) * W, ctx->KsT + p * Np * Wld, sizeof(double) * Wld,
+                                sizeof(double) * W, (size_t)N, hipMemcpyDeviceToHost));
+            for (int64_t w = 0; w < W; ++w)
+                for (int64_t n = 0; n < N; ++n) out_host[(p * W + w) * N + n] = tmp[(size_t)(n * W + w)];
+        }
         return 0;
     }
     const double* src = (what == GPB_GET_K || what == GPB_GET_L) ? ctx->K : (what == GPB_GET_LINV ? ctx->Linv : nullptr);
@@ -833,7 +886,7 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
     // the product library holds only the kernels its own rules select: the keys that switch to a measured-and-rejected
     // variant exist in the debug build (libgpbayes_debug.so, -DGPB_DEBUG_VARIANTS) and are refused here
     {
-        const bool variant = (key == 2 && value != 4) || (key == 5 && value == 0) || (key == 18 && value != 1) ||
+        const bool variant = (key == 2 && value != 4) || (key == 5 && value == 0) ||
                              (key == 21 && value != 1) || (key == 24 && value != 1) || (key == 37 && value != 1) ||
                              (key == 38 && value != 0) || (key == 39 && value != 1) || (key == 41 && value != 0);
         if (variant) GPB_FAIL(GPB_E_ARG, "gpb_debug_tune: this value selects a kernel variant of the debug build only");
@@ -852,7 +905,14 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 9: if (value != 64 && value != 128) return GPB_E_ARG; ctx->chol_inner_tile = value; break;
         case 10: if (value < 0 || value > 1) return GPB_E_ARG; ctx->tile_priority = value; break;
         case 17: if (value < 0 || value > 1) return GPB_E_ARG; ctx->tri_skip = value; break;
-        case 18: if (value < 0 || value > 1) return GPB_E_ARG; ctx->kcross_dot = value; break;
+        case 18:
+            if (value < 0 || value > 2) return GPB_E_ARG;
+            ctx->kcross_dot = value;
+            if (ctx->have_theta) {                  // the forms follow at once; K(X,X) takes them at the next factorisation
+                const int rc = choose_forms(ctx);
+                if (rc) return rc;
+            }
+            break;
         case 19: if (value < 0 || value > 64) return GPB_E_ARG; ctx->kcross_chunks = value; break;
         case 20: if (value < 1 || value > 2) return GPB_E_ARG; ctx->kcross_wpl = value; break;
         case 21: if (value < 0 || value > 1) return GPB_E_ARG; ctx->static64 = value; break;

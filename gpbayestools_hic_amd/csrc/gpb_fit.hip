@@ -72,17 +72,22 @@ int launch_scale_design(gpb_ctx* ctx) {
 }
 
 // ------------------------------------------------------------------ K(X,X)
-#ifdef GPB_DEBUG_VARIANTS       // round 1/2's kernel (tune key 39 = 0), for A/B
+// The difference form r^2 = sum_k (a_k - b_k)^2 on X / l, operation for operation sklearn's (pdist on X / length_scale,
+// sk:kernels.py:1556,1711): the kernel of the GPs whose length scales are far below the design's extent (gpb_ctx::gpform = 1,
+// choose_forms in gpb_api.hip — at the reference's Matern lower bound 1e-3 x extent the Gram form of k_kmat_mfma loses 3e-10
+// in K); rounds 1-2 built every K with it (debug build: tune key 39 = 0).
 // One 64x64 tile per workgroup, tiles of the lower block triangle only (the factorisation reads nothing above
 // it); scaled design rows staged in LDS; HBM-write bound (4*Np^2 bytes per GP).  Diagonal: c*1 + sigma_n^2 + alpha (sk:kernels.py:1559-1560,
 // 1401-1412; sk:_gpr.py:347).  Padding rows/cols: identity.
 template <int KIND>
 __global__ __launch_bounds__(256) void k_kmat(const double* __restrict__ Xsc, const double* __restrict__ amp,
                                               const double* __restrict__ noise, double alpha_reg,
-                                              double* __restrict__ K, int64_t N, int64_t Np, int dpad) {
+                                              double* __restrict__ K, int64_t N, int64_t Np, int dpad,
+                                              const int* __restrict__ form) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int p = blockIdx.z;
     if (blockIdx.x > blockIdx.y) return;               // lower block triangle only: nothing reads K above it
+    if (form && form[p] != 1) return;                  // a Gram-form GP: k_kmat_mfma's
     const int64_t i0 = (int64_t)blockIdx.y * 64, j0 = (int64_t)blockIdx.x * 64;
     const int ldx = dpad + 1;
     double* Xi = sm;
@@ -129,9 +134,7 @@ __global__ __launch_bounds__(256) void k_kmat(const double* __restrict__ Xsc, co
         }
 }
 
-#endif  // GPB_DEBUG_VARIANTS
-
-// The same matrix, organised for throughput (the default; tune key 39 = 0 selects the kernel above for A/B):
+// The same matrix, organised for throughput (the GPs in the Gram form: all of them unless a length scale is extreme):
 //   * a 1-D grid over the tiles of the lower block triangle only (no empty workgroups);
 //   * r^2 = |a|^2 + |b|^2 - 2 a.b on the centred, length-scaled design (Xc / dnorm, as k_kcross): d multiply-adds per pair
 //     instead of d subtractions + d multiply-adds, and the a.b of a 32x32 wave tile as 4 x dpad/4 fp64 MFMAs whose
@@ -144,7 +147,9 @@ __global__ __launch_bounds__(256) void k_kmat(const double* __restrict__ Xsc, co
 template <int KIND, int DPAD>
 __global__ __launch_bounds__(256) void k_kmat_mfma(const double* __restrict__ Xc, const double* __restrict__ dnorm,
                                                    const double* __restrict__ amp, const double* __restrict__ noise,
-                                                   double alpha_reg, double* __restrict__ K, int64_t N, int64_t Np) {
+                                                   double alpha_reg, double* __restrict__ K, int64_t N, int64_t Np,
+                                                   const int* __restrict__ form) {
+    if (form && form[blockIdx.y] != 0) return;         // a difference-form GP: k_kmat's
     // the tile's two operand blocks (64 design rows x DPAD each, contiguous in Xc) are staged in LDS by coalesced 16-byte
     // loads — fragment-shaped loads straight from global memory touched sixteen 32-byte pieces per instruction, 1920 cache
     // line requests per workgroup — and read back as MFMA fragments (row stride DPAD + 1 doubles: conflict-free)
@@ -240,7 +245,7 @@ static void launch_kmat_mfma(gpb_ctx* ctx) {
     dim3 grid((unsigned)(nb * (nb + 1) / 2), (unsigned)ctx->P);
 #define GPB_KM(DP)                                                                                                  \
     hipLaunchKernelGGL((k_kmat_mfma<KIND, DP>), grid, dim3(256), 0, ctx->stream, ctx->Xc, ctx->dnorm, ctx->amp,     \
-                       ctx->noise, ctx->alpha_reg, ctx->K, ctx->N, ctx->Np)
+                       ctx->noise, ctx->alpha_reg, ctx->K, ctx->N, ctx->Np, ctx->n_diff > 0 ? ctx->gpform : nullptr)
     switch (ctx->dpad) {
         case 8: GPB_KM(8); break;
         case 16: GPB_KM(16); break;
@@ -253,28 +258,35 @@ static void launch_kmat_mfma(gpb_ctx* ctx) {
 #undef GPB_KM
 }
 
-int launch_kmat(gpb_ctx* ctx) {
-    if (ctx->kmat_mfma) {
-        if (ctx->kind == GPB_KERNEL_RBF) launch_kmat_mfma<GPB_KERNEL_RBF>(ctx);
-        else if (ctx->kind == GPB_KERNEL_MATERN15) launch_kmat_mfma<GPB_KERNEL_MATERN15>(ctx);
-        else launch_kmat_mfma<GPB_KERNEL_MATERN25>(ctx);
-        GPB_HIP(hipGetLastError());
-        return 0;
-    }
-#ifdef GPB_DEBUG_VARIANTS
+static void launch_kmat_diff(gpb_ctx* ctx, const int* form) {
     dim3 grid((unsigned)(ctx->Np / 64), (unsigned)(ctx->Np / 64), (unsigned)ctx->P);
     const size_t sh = 2 * 64 * (ctx->dpad + 1) * sizeof(double);
 #define GPB_KMAT(KIND)                                                                          \
     hipLaunchKernelGGL(k_kmat<KIND>, grid, dim3(256), sh, ctx->stream, ctx->Xsc, ctx->amp,       \
-                       ctx->noise, ctx->alpha_reg, ctx->K, ctx->N, ctx->Np, (int)ctx->dpad)
+                       ctx->noise, ctx->alpha_reg, ctx->K, ctx->N, ctx->Np, (int)ctx->dpad, form)
     if (ctx->kind == GPB_KERNEL_RBF) GPB_KMAT(GPB_KERNEL_RBF);
     else if (ctx->kind == GPB_KERNEL_MATERN15) GPB_KMAT(GPB_KERNEL_MATERN15);
     else GPB_KMAT(GPB_KERNEL_MATERN25);
 #undef GPB_KMAT
+}
+
+int launch_kmat(gpb_ctx* ctx) {
+    if (ctx->kmat_mfma) {                              // each GP in its distance form (gpform); a launch with no GP is left out
+        if (ctx->n_diff < ctx->P) {
+            if (ctx->kind == GPB_KERNEL_RBF) launch_kmat_mfma<GPB_KERNEL_RBF>(ctx);
+            else if (ctx->kind == GPB_KERNEL_MATERN15) launch_kmat_mfma<GPB_KERNEL_MATERN15>(ctx);
+            else launch_kmat_mfma<GPB_KERNEL_MATERN25>(ctx);
+        }
+        if (ctx->n_diff > 0) launch_kmat_diff(ctx, ctx->n_diff < ctx->P ? ctx->gpform : nullptr);
+        GPB_HIP(hipGetLastError());
+        return 0;
+    }
+#ifdef GPB_DEBUG_VARIANTS                               // tune key 39 = 0: every GP by k_kmat (A/B against rounds 1-2)
+    launch_kmat_diff(ctx, nullptr);
     GPB_HIP(hipGetLastError());
     return 0;
 #else
-    GPB_FAIL(GPB_E_STATE, "gpb: internal: k_kmat is a debug-build variant");
+    GPB_FAIL(GPB_E_STATE, "gpb: internal: k_kmat for every GP is a debug-build variant");
 #endif
 }
 

@@ -39,6 +39,15 @@ struct gpb_ctx {
     double* muS = nullptr;         // [P][dpad] xmean / length_scale_p
     double* Xc = nullptr;          // [P][Np][dpad] Xsc - muS: centred scaled design (dot-product form of k_kcross)
     double* dnorm = nullptr;       // [P][Np] squared norms of the rows of Xc
+    // Distance form per GP (chosen from theta alone: gpb_gp_set_theta -> choose_forms).  0 = Gram form r^2 = |a|^2 + |b|^2 - 2 a.b
+    // on the centred design (k_kcross<DOT>, k_kmat_mfma), 1 = difference form sum ((a_k - b_k))^2 on X / l as sklearn's cdist
+    // computes it (sk:kernels.py:1556,1564,1711-1716).  The Gram form's cancellation costs ~eps (|a|^2 + |b|^2) absolute in
+    // r^2: a GP whose S = sum_k (extent_k / l_k)^2 exceeds gram_limit takes the difference form.
+    std::vector<double> h_ext;     // host [d] column extents (max - min) of the design
+    std::vector<int> h_form;       // host [P]
+    int* gpform = nullptr;         // device [P]
+    int n_diff = 0;                // GPs in the difference form
+    double gram_limit = 1024.0;    // S above this: difference form (r^2 within ~1e-13 absolute, K within ~2e-13, below it)
     double* ls = nullptr;          // [P][dpad]    length scales (1 in pad columns)
     double* amp = nullptr;         // [P] c
     double* noise = nullptr;       // [P] sigma_n^2
@@ -59,6 +68,7 @@ struct gpb_ctx {
 
     // ---- predict workspace ------------------------------------------------------
     int64_t Wcap = 0;              // padded capacity (multiple of WPAD)
+    int64_t last_W = 0;            // rows of the most recent K*^T batch (gpb_gp_get GPB_GET_KSTAR)
     int64_t Wld = 0;               // leading dimension of the current batch's workspaces (set by launch_predict: the padded batch)
     double* Xs = nullptr;          // [Wcap][d] staged inputs (when caller passes host memory)
     double* estd = nullptr;        // [Wcap]
@@ -142,7 +152,8 @@ struct gpb_ctx {
     int tile_priority = 1;         // k_predict: wave priority by K-loop length (s_setprio)
     int kcross_chunks = 0;         // 64-row chunks of the design per k_kcross workgroup (0 = by grid size)
     int kcross_wpl = 2;            // walkers per lane of k_kcross (1 or 2)
-    int kcross_dot = 1;            // k_kcross: r^2 = |a|^2 + |b|^2 - 2 a.b (d fma) instead of d differences (2d ops)
+    int kcross_dot = 1;            // tune key 18: distance form of k_kcross / K(X,X): 1 = per GP by theta (see gpform), 0 = every GP the
+                                   // difference form, 2 = every GP the Gram form (tests: what the rule protects against)
     int tri_skip = 1;              // k_predict: skip the all-zero half of the diagonal block's second half
     int force_tile = 0;           // test hook: 0 = auto, 64 / 128 / 32 (= 64x32) force the k_predict tile
     int force_xcd = -1;             // tuning hook: -1 auto, 0 / 1 = k_predict XCD affinity by walker tile / row block
@@ -189,6 +200,7 @@ struct gpb_ctx {
 namespace gpb {
 // fit side (gpb_fit.hip)
 int launch_scale_design(gpb_ctx* ctx);
+int choose_forms(gpb_ctx* ctx);                        // gpb_api.hip: per-GP distance form from h_theta and the design's extents
 int launch_kmat(gpb_ctx* ctx);
 int launch_potrf(gpb_ctx* ctx);
 int launch_trtri(gpb_ctx* ctx);

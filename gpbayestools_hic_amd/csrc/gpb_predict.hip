@@ -36,8 +36,10 @@ __device__ __forceinline__ double shape_fn_p(double r2) {
 // VALU; 78 -> 58 instructions per design row).  Centring at the design's column means keeps |a|, |b| small: the
 // cancellation costs ~1e-16 (|a|^2 + |b|^2) absolute in r^2, <= 1e-15 relative in K* for length scales down to a
 // tenth of the design's extent (2e-13 at sklearn's lower search bound); measured against the oracle the two forms
-// are indistinguishable (1e-13 between them).  One form for every batch size, so a walker's result still does not
-// depend on how the ensemble is split.
+// are indistinguishable (1e-13 between them).  The form is chosen PER GP from theta alone (choose_forms, gpb_api.hip: the
+// difference form — sklearn's own — for a GP with a length scale far below the design's extent, e.g. at the Matern lower
+// search bound 1e-3 x extent, where the Gram form loses 3e-10 in K*), never from the batch, so a walker's result still
+// does not depend on how the ensemble is split.
 // LDS of a k_kcross workgroup (the kernels own it; the body below is shared by the one-emulator and the chain kernels)
 template <int DPAD, int WPL>
 struct KxLds {
@@ -213,7 +215,11 @@ __global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, i
                                                 double* __restrict__ KsT, double* __restrict__ mpart,
                                                 int64_t N, int64_t Np, int64_t Wld, int P,
                                                 const double* __restrict__ dnorm, const double* __restrict__ muS,
-                                                int chunks_per_wg, const int* __restrict__ nrows) {
+                                                int chunks_per_wg, const int* __restrict__ nrows,
+                                                const int* __restrict__ form) {
+    // form (optional): the per-GP distance form (gpb_ctx::gpform); this launch computes the GPs of ITS form, the workgroups
+    // of the others leave at once (their launch is the other instantiation, on the same stream)
+    if (form && form[blockIdx.y] != (DOT ? 0 : 1)) return;
     __shared__ KxLds<DPAD, WPL> lds;
     kcross_body<KIND, DPAD, DOT, WPL>(lds, Xs, W, d, Xsc, ls, amp, alpha, KsT, mpart, N, Np, Wld, P, dnorm, muS,
                                       chunks_per_wg, nrows, (int)blockIdx.y);
@@ -992,7 +998,7 @@ static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int
     // partials and their order do not depend on it; measured, cfg 4: 1 / 2 / 4 chunks at 512 / 1024 / 2048+ walkers)
     // two walkers per lane (every LDS broadcast feeds two multiply-adds) for d <= 32 and batches that are a whole
     // number of 128-walker tiles (always: WPAD = 128)
-    const int wpl = (ctx->kcross_dot && ctx->kcross_wpl == 2 && ctx->dpad <= 32 && Wuse >= 256 && Wuse % 128 == 0) ? 2 : 1;
+    const int wpl = (ctx->kcross_wpl == 2 && ctx->dpad <= 32 && Wuse >= 256 && Wuse % 128 == 0) ? 2 : 1;
     int cpw = ctx->kcross_chunks;
     if (cpw <= 0) {
         // compacted batches: about half of a stretch move's proposals from a spread-out ensemble are live (the count is
@@ -1003,27 +1009,23 @@ static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int
         while (cpw < 8 && wgs1 / (2 * cpw) >= 4 * (int64_t)ctx->num_cu) cpw *= 2;
     }
     dim3 grid((unsigned)((nchunk + cpw - 1) / cpw), (unsigned)ctx->P, (unsigned)(Wuse / (64 * wpl)));
-#ifdef GPB_DEBUG_VARIANTS       // the difference form of the distance (tune key 18 = 0): A/B and the parity test of both forms
-#define GPB_KX_DIFF(DP)                                                                                          \
-    hipLaunchKernelGGL((k_kcross<KIND, DP, false, 1>), grid, dim3(256), 0, ctx->stream, Xs_dev, W, (int)ctx->d,  \
-                       ctx->Xsc, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT, ctx->mpart, ctx->N, ctx->Np, ctx->Wld, \
-                       (int)ctx->P, ctx->dnorm, ctx->muS, cpw, nrows_dev)
-#else
-#define GPB_KX_DIFF(DP) ((void)0)
-#endif
+    // two instantiations, one per distance form; each launch computes the GPs of its form (ctx->gpform, chosen from theta:
+    // choose_forms) and is left out when no GP has it — the usual case is the Gram launch alone, with no form table to read
+    const int* form = (ctx->n_diff > 0 && ctx->n_diff < ctx->P) ? ctx->gpform : nullptr;
+    const bool gram = ctx->n_diff < ctx->P, diff = ctx->n_diff > 0;
+#define GPB_KX_LAUNCH(DP, DOT_, WPL_, XD)                                                                         \
+    hipLaunchKernelGGL((k_kcross<KIND, DP, DOT_, WPL_>), grid, dim3(256), 0, ctx->stream, Xs_dev, W, (int)ctx->d, \
+                       XD, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT, ctx->mpart, ctx->N, ctx->Np, ctx->Wld,       \
+                       (int)ctx->P, ctx->dnorm, ctx->muS, cpw, nrows_dev, form)
 #define GPB_KX(DP)                                                                                               \
     do {                                                                                                         \
-        if (ctx->kcross_dot && wpl == 2)                                                                    \
-            hipLaunchKernelGGL((k_kcross<KIND, DP, true, (DP <= 32 ? 2 : 1)>), grid, dim3(256), 0, ctx->stream,  \
-                               Xs_dev, W, (int)ctx->d, ctx->Xc, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT,         \
-                               ctx->mpart, ctx->N, ctx->Np, ctx->Wld, (int)ctx->P, ctx->dnorm, ctx->muS, cpw,   \
-                               nrows_dev);                                                                       \
-        else if (ctx->kcross_dot)                                                                                \
-            hipLaunchKernelGGL((k_kcross<KIND, DP, true, 1>), grid, dim3(256), 0, ctx->stream, Xs_dev, W,        \
-                               (int)ctx->d, ctx->Xc, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT, ctx->mpart,        \
-                               ctx->N, ctx->Np, ctx->Wld, (int)ctx->P, ctx->dnorm, ctx->muS, cpw, nrows_dev);   \
-        else                                                                                                     \
-            GPB_KX_DIFF(DP);                                                                                     \
+        if (wpl == 2) {                                                                                          \
+            if (gram) GPB_KX_LAUNCH(DP, true, (DP <= 32 ? 2 : 1), ctx->Xc);                                      \
+            if (diff) GPB_KX_LAUNCH(DP, false, (DP <= 32 ? 2 : 1), ctx->Xsc);                                    \
+        } else {                                                                                                 \
+            if (gram) GPB_KX_LAUNCH(DP, true, 1, ctx->Xc);                                                       \
+            if (diff) GPB_KX_LAUNCH(DP, false, 1, ctx->Xsc);                                                     \
+        }                                                                                                        \
     } while (0)
     switch (ctx->dpad) {
         case 8: GPB_KX(8); break;
@@ -1035,7 +1037,7 @@ static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int
         default: GPB_KX(64); break;
     }
 #undef GPB_KX
-#undef GPB_KX_DIFF
+#undef GPB_KX_LAUNCH
     return 0;
 }
 
@@ -1048,6 +1050,7 @@ int launch_kcross(gpb_ctx* ctx, const double* Xs_dev, int64_t W, const int* nrow
     // capacity — with the capacity left at 4096 by an earlier call a 256-walker batch read its 64-walker tile rows
     // 32 KB apart and k_predict_static ran 13 % slower (117 -> 133 us), k_kcross 24 % (20 -> 25 us)
     ctx->Wld = Wuse;
+    ctx->last_W = W;
     if (ctx->kind == GPB_KERNEL_RBF) launch_kcross_kind<GPB_KERNEL_RBF>(ctx, Xs_dev, W, Wuse, nrows_dev);
     else if (ctx->kind == GPB_KERNEL_MATERN15) launch_kcross_kind<GPB_KERNEL_MATERN15>(ctx, Xs_dev, W, Wuse, nrows_dev);
     else launch_kcross_kind<GPB_KERNEL_MATERN25>(ctx, Xs_dev, W, Wuse, nrows_dev);
@@ -1057,13 +1060,13 @@ int launch_kcross(gpb_ctx* ctx, const double* Xs_dev, int64_t W, const int* nrow
 
 // K*^T and the mean partials for E contexts of a chain in ONE launch (k_kcross_multi): all with the same padded design size,
 // the same number of GP inputs and the same batch; Xs[e] = context e's input rows (its parameter map's output, or the chain's
-// gathered rows).  Falls back to one launch per context when the group does not qualify (difference-form debug variant,
-// more contexts than the table holds).
+// gathered rows).  Falls back to one launch per context when the group does not qualify (a GP in the difference form,
+// more contexts than the table holds): a context's own launch computes the same bits.
 int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, int64_t W, const int* nrows_dev) {
     gpb_ctx* ctx = ctxs[0];
-    bool ok = E > 1 && E <= MAX_KX_CTX && ctx->kcross_dot;
-    for (int e = 0; e < E && ok; ++e)
-        ok = ctxs[e]->Np == ctx->Np && ctxs[e]->d == ctx->d && ctxs[e]->dpad == ctx->dpad && ctxs[e]->stream == ctx->stream;
+    bool ok = E > 1 && E <= MAX_KX_CTX;
+    for (int e = 0; e < E && ok; ++e)           // (the shared launch is the Gram form's: a context with a difference-form GP takes its own)
+        ok = ctxs[e]->n_diff == 0 && ctxs[e]->Np == ctx->Np && ctxs[e]->d == ctx->d && ctxs[e]->dpad == ctx->dpad && ctxs[e]->stream == ctx->stream;
     if (!ok) {
         for (int e = 0; e < E; ++e) {
             const int rc = launch_kcross(ctxs[e], Xs[e], W, nrows_dev);
@@ -1079,6 +1082,7 @@ int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, in
         if (!c->factored) GPB_FAIL(GPB_E_STATE, "gpb: predict before gpb_gp_factor");
         if (W > c->Wcap) GPB_FAIL(GPB_E_STATE, "gpb: internal: W exceeds workspace");
         c->Wld = Wuse;
+        c->last_W = W;
         tab.c[e] = KxCtx{Xs[e], c->Xc, c->ls, c->amp, c->alpha, c->dnorm, c->muS, c->KsT, c->mpart, (int)c->N, (int)c->P,
                          c->kind, G};
         G += (int)c->P;

@@ -165,9 +165,16 @@ class GPEngine:
                 f"(leading minor {rc}); try increasing alpha")
         return info
 
-    def get(self, what):
-        sel = {"K": 0, "L": 1, "Linv": 2, "alpha": 3}[what]
-        shape = (self.P, self.N) if what == "alpha" else (self.P, self.N, self.N)
+    def get(self, what, W=None):
+        """K / L / Linv [P,N,N], alpha [P,N], "Kstar" [P,W,N] (K(X*, X) of the most recent batch of W rows), "form" [P]
+        (0 = Gram form, 1 = difference form of the distances: chosen per GP from theta, gpbayes.h GPB_GET_FORM)."""
+        sel = {"K": 0, "L": 1, "Linv": 2, "alpha": 3, "Kstar": 4, "form": 5}[what]
+        if what == "Kstar":
+            shape = (self.P, int(W), self.N)
+        elif what == "form":
+            shape = (self.P,)
+        else:
+            shape = (self.P, self.N) if what == "alpha" else (self.P, self.N, self.N)
         out = np.empty(shape)
         self._ck(self.lib.gpb_gp_get(self.h, sel, nat.ptr(out)))
         return out

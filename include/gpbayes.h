@@ -54,6 +54,10 @@ extern "C" {
 #define GPB_GET_L      1  /* [P,N,N] lower Cholesky factor, upper zeroed  == GPR.L_     */
 #define GPB_GET_LINV   2  /* [P,N,N] L^-1 (lower)                                       */
 #define GPB_GET_ALPHA  3  /* [P,N]   K^-1 z                               == GPR.alpha_ */
+#define GPB_GET_KSTAR  4  /* [P,W,N] K(X*,X) of the most recent predict / likelihood batch of W rows == kernel_(X*, X_train_)  sk:_gpr.py:443 */
+#define GPB_GET_FORM   5  /* [P]     distance form each GP's kernel matrices are built in, chosen from theta alone: 0 = Gram form
+                           *         |a|^2+|b|^2-2a.b on the centred design, 1 = sklearn's difference form (length scales far below the
+                           *         design's extent: sum_k (extent_k/l_k)^2 > 1024, e.g. the Matern lower search bound, src/emulator.py:292-297) */
 
 typedef struct gpb_ctx gpb_ctx;
 

@@ -83,6 +83,102 @@ def test_hyperparameters_at_the_edges_of_the_search_box(kind, c, ell, noise):
     eng.close()
 
 
+@pytest.mark.parametrize("kind,ell,where", [
+    ("Matern15", 1e-3, "one"), ("Matern15", 1e-3, "all"), ("Matern15", 1e-2, "one"), ("Matern15", 1e-2, "all"),
+    ("Matern25", 1e-3, "one"), ("Matern25", 1e-3, "all"), ("Matern25", 1e-2, "one"), ("Matern25", 1e-2, "all"),
+    ("RBF", 0.1, "one"), ("RBF", 0.1, "all"),
+])
+def test_length_scales_at_the_lower_bound_of_the_references_search_box(kind, ell, where):
+    """The reference lets L-BFGS-B take a length scale down to 1e-3 x the design's extent for "Matern" and 0.1 x for RBF
+    (src/emulator.py:286-297).  There the Gram form of the squared distance, |a|^2 + |b|^2 - 2 a.b with |a|^2 ~ 2.5e5, loses
+    ~1e-9 absolute in r^2 (3e-10 in K*, 2.5e-9 in the predictive variance), so such GPs are built in sklearn's difference
+    form — chosen per GP from theta alone (gpbayes.h GPB_GET_FORM).  Queries sit within a length scale of design points
+    along the short dimension(s), where K* is O(1) and r small: element-wise K*, mean, variance, K, LML and gradient."""
+    from gpbayestools_hic_amd import GPEngine, synth
+    from oracle import gp_oracle as O
+    N, d, W = 1024, 20, 256
+    kid = O.KIND_NAMES[kind]
+    rng = np.random.default_rng(7)
+    X = synth.lhs(N, d, seed=5)
+    ptp = X.max(0) - X.min(0)
+    ls = np.ones(d)
+    short = np.arange(d) if where == "all" else np.array([4])
+    ls[short] = ell * ptp[short]
+    th = np.concatenate([[0.0], np.log(ls), [np.log(0.05)]])
+    z = np.sin(X @ rng.standard_normal(d)) + 0.3 * rng.standard_normal(N)
+    idx = rng.integers(0, N, W)
+    Xs = X[idx] + rng.uniform(-0.02, 0.02, (W, d))
+    Xs[:, short] = X[idx][:, short] + rng.uniform(-1.0, 1.0, (W, short.size)) * ls[short] * (0.25 if where == "all" else 1.0)
+    Xs[:8] = X[idx[:8]]                                             # and a few queries ON design points (r = 0)
+    S = float(np.sum((ptp / ls) ** 2))
+    eng = GPEngine(0)
+    eng.set_data(X, z[None, :], kind, 0.1); eng.set_theta(th[None, :])
+    assert eng.get("form")[0] == (1.0 if S > 1024.0 else 0.0)
+    assert S > 1024.0 or (kind == "RBF" and where == "one")         # every Matern case here is beyond the Gram form's range
+    Ko = O.kernel_train(X, th, kid, 0.1)
+    L, a = O.gp_factor(X, z, th, kid, 0.1)
+    eng.fit_piece("kmat")                                           # K(X,X) alone (gpb_gp_factor overwrites it with L)
+    Kg = eng.get("K")[0]
+    assert np.max(np.abs(np.tril(Kg) - np.tril(Ko))) <= 1e-13
+    eng.factor()
+    m, v = eng.predict(Xs)
+    Ks = eng.get("Kstar", W)[0]
+    Kso = O.kernel_cross(Xs, X, th, kid)
+    assert np.max(np.abs(Ks - Kso)) <= 1e-13                        # element-wise, c = 1
+    assert Kso.max(1).min() > 0.05                                  # the queries do see their design points
+    mo, vo = O.gp_predict(Xs, X, th, L, a, kid)
+    assert np.max(np.abs(m[:, 0] - mo)) <= 1e-11 * np.max(np.abs(mo))
+    assert np.max(np.abs(v[:, 0] - vo) / np.abs(vo)) < 1e-10
+    val, grad = eng.lml(th[None, :])
+    vo_, go_ = O.lml(th, X, z, kid, 0.1, eval_gradient=True)
+    assert abs(val[0] - vo_) <= 1e-10 * abs(vo_)
+    assert np.max(np.abs(grad[0] - go_)) <= 1e-9 * max(np.max(np.abs(go_)), 1.0)
+    if kind == "Matern15" and ell == 1e-3 and where == "one":
+        # what the rule protects against: the same GP forced into the Gram form misses the K* bar by orders of magnitude
+        eng.tune("kcross_dot", 2)
+        assert eng.get("form")[0] == 0.0
+        eng.factor(); eng.predict(Xs)
+        assert np.max(np.abs(eng.get("Kstar", W)[0] - Kso)) > 1e-11
+        eng.tune("kcross_dot", 1)
+        assert eng.get("form")[0] == 1.0
+    eng.close()
+
+
+def test_gps_of_one_emulator_in_different_distance_forms():
+    """three GPs, the middle one beyond the Gram form's range: each is built in its own form (two cross-kernel and two K
+    launches, each leaving the other's GPs alone), results as if each were alone, and no bit depends on the batch cut"""
+    from gpbayestools_hic_amd import GPEngine, synth
+    from oracle import gp_oracle as O
+    N, d, P, W = 300, 6, 3, 333
+    rng = np.random.default_rng(11)
+    X = synth.lhs(N, d, seed=3)
+    Z = rng.standard_normal((P, N))
+    th = synth.fixed_theta(d, P, ell=0.8)
+    th[1, 1 + 2] = np.log(2e-3)
+    idx = rng.integers(0, N, W)
+    Xs = np.clip(X[idx] + rng.uniform(-1e-3, 1e-3, (W, d)), 0.0, 1.0)
+    for kind in ("RBF", "Matern15", "Matern25"):
+        eng = GPEngine(0)
+        eng.set_data(X, Z, kind, 0.1); eng.set_theta(th); eng.factor()
+        assert eng.get("form").tolist() == [0.0, 1.0, 0.0]
+        m, v = eng.predict(Xs)
+        Ks = eng.get("Kstar", W)
+        for p in range(P):
+            L, a = O.gp_factor(X, Z[p], th[p], O.KIND_NAMES[kind], 0.1)
+            mo, vo = O.gp_predict(Xs, X, th[p], L, a, O.KIND_NAMES[kind])
+            assert np.max(np.abs(Ks[p] - O.kernel_cross(Xs, X, th[p], O.KIND_NAMES[kind]))) <= 1e-13
+            assert np.max(np.abs(m[:, p] - mo)) <= 1e-11 * np.max(np.abs(mo))
+            assert np.max(np.abs(v[:, p] - vo) / np.abs(vo)) < 1e-10
+        for sl in (slice(0, 1), slice(5, 133), slice(200, 333)):
+            ms, vs = eng.predict(Xs[sl])
+            assert np.array_equal(ms, m[sl]) and np.array_equal(vs, v[sl])
+        single = GPEngine(0)                                         # GP 1 alone: the same bits as in the mixed emulator
+        single.set_data(X, Z[1:2], kind, 0.1); single.set_theta(th[1:2]); single.factor()
+        m1, v1 = single.predict(Xs)
+        assert np.array_equal(m1[:, 0], m[:, 1]) and np.array_equal(v1[:, 0], v[:, 1])
+        single.close(); eng.close()
+
+
 def test_argument_errors_are_reported_not_crashes():
     from gpbayestools_hic_amd import GPEngine
     from gpbayestools_hic_amd._native import GPBError

@@ -351,7 +351,7 @@ def test_predict_tile_sizes_are_bit_identical(eng):
         eng.tune("xcd", -1); eng.tune("resident", 2)
         if not full:
             from gpbayestools_hic_amd._native import GPBError
-            for key, val in (("waves", 8), ("resident", 0), ("fold_tiles", 1), ("kcross_dot", 0), ("mma_pipe", 0),
+            for key, val in (("waves", 8), ("resident", 0), ("fold_tiles", 1), ("mma_pipe", 0),
                              ("chol_algo", 0), ("kmat_mfma", 0), ("predict_dma", 1)):
                 with pytest.raises(GPBError, match="debug build"):
                     eng.tune(key, val)                    # refused, not silently ignored

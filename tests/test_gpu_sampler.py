@@ -386,9 +386,7 @@ def test_sharded_c_loop_with_R_ranks_in_one_process(tmp_path, R, balance):
     balance = 2: every rank takes an equal slice of the ordered list of ALL rows inside the box (k_balance_gather, tune key
     36; off by default) instead of the rows inside the box of its own contiguous share — the check a multi-rank run owed
     before that mode may be switched on."""
-    import ctypes
-    import threading
-    from gpbayestools_hic_amd import StretchSampler, synth
+    from gpbayestools_hic_amd import synth
     from gpbayestools_hic_amd.workload import build_chain
     built = []
     for r in range(R):
@@ -398,6 +396,14 @@ def test_sharded_c_loop_with_R_ranks_in_one_process(tmp_path, R, balance):
     nw, nsteps = 64, 7
     X0 = synth.walkers(nw, d, seed=31)
     X0[::5, 0] = 0.999                                               # a few walkers at the edge: proposals leave the box
+    _loopback_ranks_reproduce_the_unsharded_run(built, nw, nsteps, X0, balance)
+
+
+def _loopback_ranks_reproduce_the_unsharded_run(built, nw, nsteps, X0, balance=0):
+    import ctypes
+    import threading
+    from gpbayestools_hic_amd import StretchSampler
+    R = len(built)
     ref = StretchSampler(built[0][0], nw, seed=13)
     ref.run(X0, nsteps)
     engs = [b[1]._engine_ready() for b in built]
@@ -433,6 +439,38 @@ def test_sharded_c_loop_with_R_ranks_in_one_process(tmp_path, R, balance):
             assert np.array_equal(samplers[r].naccept.cpu().numpy(), ref.naccept.cpu().numpy()), r
     finally:
         assert lib.gpb_debug_loopback_release(engs[0].h) == 0
+    return ref
+
+
+@pytest.mark.timeout(300)
+def test_sharded_c_loop_when_the_gps_differ_in_their_distance_form(tmp_path):
+    """The distance form of a GP's kernel matrices is chosen from theta alone (Gram form, or sklearn's difference form when a
+    length scale is far below the design's extent: gpbayes.h GPB_GET_FORM): with one GP of the emulator on either side of the
+    rule — two cross-kernel launches per batch — two loopback ranks still end on the unsharded ensemble bit for bit, and the
+    ensemble is not the one the all-Gram emulator gives."""
+    from gpbayestools_hic_amd import synth
+    from gpbayestools_hic_amd.workload import build_chain
+    R = 2
+    built = []
+    for r in range(R):
+        (tmp_path / ("r%d" % r)).mkdir()
+        chain, emu, info = build_chain(1, workdir=str(tmp_path / ("r%d" % r)))
+        th = synth.fixed_theta(info["d"], info["P"])
+        th[1, 1 + 3] = np.log(0.004)                                 # GP 1: parameter 3 at 0.004 of its extent, S = 6e4
+        th[2, 1:1 + info["d"]] = np.log(0.11)                        # GP 2: every length scale short, S = 8 / 0.11^2 = 661: Gram
+        emu.trainEmulator([True] * emu.nev, kernel_type=info["kernel_type"], thetas=th)
+        built.append((chain, emu, info))
+    eng = built[0][1]._engine_ready()
+    assert eng.get("form").tolist() == [0.0, 1.0, 0.0, 0.0]
+    d = built[0][2]["d"]
+    nw = 64
+    X0 = synth.walkers(nw, d, seed=31)
+    X0[::5, 0] = 0.999
+    ref = _loopback_ranks_reproduce_the_unsharded_run(built, nw, 7, X0)
+    lp = built[0][0].log_posterior(X0)                               # and batch cuts change no bit either
+    for sl in (slice(0, 1), slice(3, 40), slice(40, 64)):
+        assert np.array_equal(built[0][0].log_posterior(X0[sl]), lp[sl])
+    assert np.all(np.isfinite(ref.lnprobability))
 
 
 @pytest.mark.timeout(300)
