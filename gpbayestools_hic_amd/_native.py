@@ -33,6 +33,8 @@ BOUNDARY = {
     "gpb_last_error": (C.c_char_p, [VP]),
     "gpb_stream": (VP, [VP]),
     "gpb_gp_set": (C.c_int, [VP, c_i64, c_i64, c_i64, VP, VP, C.c_int, C.c_double]),
+    "gpb_gp_set_multi": (C.c_int, [VP, c_i64, c_i64, VP, VP, VP, C.c_int, C.c_double]),
+    "gpb_gp_lml_subset": (C.c_int, [VP, c_i64, VP, VP, VP, VP, VP]),
     "gpb_gp_set_theta": (C.c_int, [VP, VP]),
     "gpb_gp_factor": (C.c_int, [VP, VP]),
     "gpb_gp_get": (C.c_int, [VP, C.c_int, VP]),

@@ -129,7 +129,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     gpb_dist_finalize(ctx);
     free(ctx->h_theta);
     dev_free(&ctx->lr_R); dev_free(&ctx->lr_v0);
-    dev_free(&ctx->xmean); dev_free(&ctx->muS); dev_free(&ctx->Xc); dev_free(&ctx->dnorm); dev_free(&ctx->gpform);
+    dev_free(&ctx->xmean); dev_free(&ctx->muS); dev_free(&ctx->Xc); dev_free(&ctx->dnorm); dev_free(&ctx->gpform); dev_free(&ctx->gpN); dev_free(&ctx->gpmap);
     dev_free(&ctx->X); dev_free(&ctx->Xsc); dev_free(&ctx->ls); dev_free(&ctx->amp); dev_free(&ctx->noise);
     dev_free(&ctx->Z); dev_free(&ctx->K); dev_free(&ctx->Linv); dev_free(&ctx->LinvT); dev_free(&ctx->T); dev_free(&ctx->yv);
     dev_free(&ctx->alpha); dev_free(&ctx->apart); dev_free(&ctx->info); dev_free(&ctx->lmlbuf);
@@ -167,16 +167,18 @@ extern "C" const char* gpb_last_error(gpb_ctx* ctx) { return ctx ? ctx->err.c_st
 extern "C" void* gpb_stream(gpb_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 // ---------------------------------------------------------------------------- GP state
-extern "C" int gpb_gp_set(gpb_ctx* ctx, int64_t N, int64_t d, int64_t P, const double* X_host,
-                          const double* Z_host, int kernel_id, double alpha) {
-    if (!ctx) return GPB_E_ARG;
-    if (N < 1 || d < 1 || P < 1 || !X_host || !Z_host) GPB_FAIL(GPB_E_ARG, "gpb_gp_set: bad sizes or null input");
-    if (kernel_id < 0 || kernel_id > 2) GPB_FAIL(GPB_E_ARG, "gpb_gp_set: unknown kernel_id");
+// P GPs over one design (gpb_gp_set: every X_p the same pointer, stored once) or each over its own (gpb_gp_set_multi: the GPs
+// of several emulators, or the restarts of a hyper-parameter search, side by side in one batch; all padded to the same Np)
+static int gp_set_impl(gpb_ctx* ctx, int64_t P, int64_t d, const int64_t* N_p, const double* const* X_p,
+                       const double* const* Z_p, bool multi, int kernel_id, double alpha) {
     const int dpad = pick_dpad(d);
     if (dpad < 0) GPB_FAIL(GPB_E_ARG, "gpb_gp_set: d > 64 not supported");
+    int64_t N = 0;
+    for (int64_t p = 0; p < P; ++p) N = N_p[p] > N ? N_p[p] : N;
     GPB_HIP(hipSetDevice(ctx->device));
     GPB_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->N = N; ctx->d = d; ctx->P = P; ctx->dpad = dpad; ctx->kind = kernel_id; ctx->alpha_reg = alpha;
+    ctx->N = N; ctx->d = d; ctx->P = ctx->Pstore = P; ctx->dpad = dpad; ctx->kind = kernel_id; ctx->alpha_reg = alpha;
+    ctx->multi = multi; ctx->subset = false;
     ctx->Np = round_up(N, NB);
     ctx->have_theta = ctx->factored = false;
     // whatever was installed for the previous GPs (observable transform sized [old P][M], likelihood block, low-rank
@@ -187,16 +189,16 @@ extern "C" int gpb_gp_set(gpb_ctx* ctx, int64_t N, int64_t d, int64_t P, const d
     dev_free(&ctx->Cexp); dev_free(&ctx->lr_R); dev_free(&ctx->lr_v0); dev_free(&ctx->pmap_int); dev_free(&ctx->pmap_tab);
     ctx->h_A.clear(); ctx->h_mu.clear(); ctx->h_C0.clear();
     ctx->pmap_d_in = ctx->pmap_d_out = 0; ctx->pmap_groups = ctx->pmap_maxpc = 0;
-    const int64_t Np = ctx->Np;
+    const int64_t Np = ctx->Np, PX = multi ? P : 1;
     // workspaces sized by (Np, P) are stale now
     dev_free(&ctx->KsT); dev_free(&ctx->mpart); dev_free(&ctx->spart); dev_free(&ctx->mean_pc);
     dev_free(&ctx->var_pc); dev_free(&ctx->Xs); dev_free(&ctx->estd); dev_free(&ctx->cmp_idx); dev_free(&ctx->cmp_X);
-    ctx->Wcap = 0; ctx->cmp_X_cap = 0;
+    ctx->Wcap = 0; ctx->cmp_X_cap = 0; ctx->last_W = 0;
     int rc;
-    if ((rc = dev_alloc(ctx, &ctx->X, Np * dpad))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->X, PX * Np * dpad))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->Xsc, P * Np * dpad))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->ls, P * dpad))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->xmean, dpad))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->xmean, PX * dpad))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->muS, P * dpad))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->Xc, P * Np * dpad))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->dnorm, P * Np))) return rc;
@@ -215,33 +217,70 @@ extern "C" int gpb_gp_set(gpb_ctx* ctx, int64_t N, int64_t d, int64_t P, const d
     if ((rc = dev_alloc(ctx, &ctx->alpha, P * Np))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->info, P))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->lmlbuf, P * 4 + P * (d + 2)))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->gpN, P))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->gpmap, P))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->gpform, P))) return rc;
     free(ctx->h_theta);
     ctx->h_theta = (double*)calloc((size_t)(P * (d + 2)), sizeof(double));
-    std::vector<double> xp((size_t)(Np * dpad), 0.0), zp((size_t)(P * Np), 0.0);
-    for (int64_t i = 0; i < N; ++i)
-        for (int64_t k = 0; k < d; ++k) xp[i * dpad + k] = X_host[i * d + k];
-    for (int64_t p = 0; p < P; ++p)
-        for (int64_t i = 0; i < N; ++i) zp[p * Np + i] = Z_host[p * N + i];
-    std::vector<double> xm((size_t)dpad, 0.0);        // column means: the centre of k_kcross's dot-product form
-    for (int64_t k = 0; k < d; ++k) {
-        double sum = 0.0;
-        for (int64_t i = 0; i < N; ++i) sum += X_host[i * d + k];
-        xm[k] = sum / (double)N;
+    std::vector<double> xp((size_t)(PX * Np * dpad), 0.0), zp((size_t)(P * Np), 0.0), xm((size_t)(PX * dpad), 0.0);
+    ctx->h_ext.assign((size_t)(PX * d), 0.0);
+    ctx->h_N.assign((size_t)P, 0);
+    for (int64_t p = 0; p < P; ++p) {
+        ctx->h_N[(size_t)p] = (int)N_p[p];
+        for (int64_t i = 0; i < N_p[p]; ++i) zp[p * Np + i] = Z_p[p][i];
     }
-    ctx->h_ext.assign((size_t)d, 0.0);                // column extents: what a length scale is compared with (choose_forms)
-    for (int64_t k = 0; k < d; ++k) {
-        double lo = X_host[k], hi = X_host[k];
-        for (int64_t i = 1; i < N; ++i) { lo = fmin(lo, X_host[i * d + k]); hi = fmax(hi, X_host[i * d + k]); }
-        ctx->h_ext[(size_t)k] = hi - lo;
+    for (int64_t q = 0; q < PX; ++q) {
+        const double* Xq = X_p[q];
+        const int64_t Nq = N_p[q];
+        for (int64_t i = 0; i < Nq; ++i)
+            for (int64_t k = 0; k < d; ++k) xp[(q * Np + i) * dpad + k] = Xq[i * d + k];
+        for (int64_t k = 0; k < d; ++k) {
+            // column means: the centre of the Gram form (k_kcross, k_kmat_mfma); column extents: what a length scale is
+            // compared with when the distance form is chosen (choose_forms)
+            double sum = 0.0, lo = Xq[k], hi = Xq[k];
+            for (int64_t i = 0; i < Nq; ++i) {
+                const double v = Xq[i * d + k];
+                sum += v; lo = fmin(lo, v); hi = fmax(hi, v);
+            }
+            xm[(size_t)(q * dpad + k)] = sum / (double)Nq;
+            ctx->h_ext[(size_t)(q * d + k)] = hi - lo;
+        }
     }
     ctx->h_form.assign((size_t)P, 0);
+    ctx->h_map.clear();
     ctx->n_diff = 0;
-    if ((rc = dev_alloc(ctx, &ctx->gpform, P))) return rc;
     GPB_HIP(hipMemset(ctx->gpform, 0, sizeof(int) * P));
+    GPB_HIP(hipMemcpy(ctx->gpN, ctx->h_N.data(), sizeof(int) * P, hipMemcpyHostToDevice));
     GPB_HIP(hipMemcpy(ctx->xmean, xm.data(), sizeof(double) * xm.size(), hipMemcpyHostToDevice));
     GPB_HIP(hipMemcpy(ctx->X, xp.data(), sizeof(double) * xp.size(), hipMemcpyHostToDevice));
     GPB_HIP(hipMemcpy(ctx->Z, zp.data(), sizeof(double) * zp.size(), hipMemcpyHostToDevice));
     return 0;
+}
+
+extern "C" int gpb_gp_set(gpb_ctx* ctx, int64_t N, int64_t d, int64_t P, const double* X_host,
+                          const double* Z_host, int kernel_id, double alpha) {
+    if (!ctx) return GPB_E_ARG;
+    if (N < 1 || d < 1 || P < 1 || !X_host || !Z_host) GPB_FAIL(GPB_E_ARG, "gpb_gp_set: bad sizes or null input");
+    if (kernel_id < 0 || kernel_id > 2) GPB_FAIL(GPB_E_ARG, "gpb_gp_set: unknown kernel_id");
+    std::vector<int64_t> Ns((size_t)P, N);
+    std::vector<const double*> Xs((size_t)P, X_host), Zs((size_t)P);
+    for (int64_t p = 0; p < P; ++p) Zs[(size_t)p] = Z_host + p * N;
+    return gp_set_impl(ctx, P, d, Ns.data(), Xs.data(), Zs.data(), false, kernel_id, alpha);
+}
+
+extern "C" int gpb_gp_set_multi(gpb_ctx* ctx, int64_t P, int64_t d, const int64_t* N_host, const double* const* X_host,
+                                const double* const* Z_host, int kernel_id, double alpha) {
+    if (!ctx) return GPB_E_ARG;
+    if (P < 1 || d < 1 || !N_host || !X_host || !Z_host) GPB_FAIL(GPB_E_ARG, "gpb_gp_set_multi: bad sizes or null input");
+    if (kernel_id < 0 || kernel_id > 2) GPB_FAIL(GPB_E_ARG, "gpb_gp_set_multi: unknown kernel_id");
+    int64_t Np = 0;
+    for (int64_t p = 0; p < P; ++p) {
+        if (N_host[p] < 1 || !X_host[p] || !Z_host[p]) GPB_FAIL(GPB_E_ARG, "gpb_gp_set_multi: bad size or null design / targets");
+        const int64_t np_ = round_up(N_host[p], NB);
+        if (p > 0 && np_ != Np) GPB_FAIL(GPB_E_ARG, "gpb_gp_set_multi: the designs must pad to the same multiple of 64 points");
+        Np = np_;
+    }
+    return gp_set_impl(ctx, P, d, N_host, X_host, Z_host, true, kernel_id, alpha);
 }
 
 // The distance form of every GP, from theta and the design's extents alone — never from a batch's size or a rank's share, so a
@@ -255,9 +294,10 @@ int gpb::choose_forms(gpb_ctx* ctx) {
     int ndiff = 0;
     for (int64_t p = 0; p < P; ++p) {
         const double* th = ctx->h_theta + p * (d + 2);
+        const int64_t gq = ctx->multi ? (ctx->subset ? ctx->h_map[(size_t)p] : p) : 0;      // whose design
         double S = 0.0;
         for (int64_t k = 0; k < d; ++k) {
-            const double q = ctx->h_ext[(size_t)k] / exp(th[1 + k]);
+            const double q = ctx->h_ext[(size_t)(gq * d + k)] / exp(th[1 + k]);
             S += q * q;
         }
         const int f = ctx->kcross_dot == 0 ? 1 : (ctx->kcross_dot == 2 ? 0 : ((S > ctx->gram_limit || !(S == S)) ? 1 : 0));
@@ -370,9 +410,7 @@ extern "C" int gpb_gp_get(gpb_ctx* ctx, int what, double* out_host) {
     return 0;
 }
 
-extern "C" int gpb_gp_lml(gpb_ctx* ctx, const double* theta_host, double* lml_host, double* grad_host,
-                          int* info_host) {
-    if (!ctx || !theta_host || !lml_host) return GPB_E_ARG;
+static int lml_impl(gpb_ctx* ctx, const double* theta_host, double* lml_host, double* grad_host, int* info_host) {
     int rc = gpb_gp_set_theta(ctx, theta_host);
     if (rc) return rc;
     std::vector<int> info((size_t)ctx->P, 0);
@@ -397,6 +435,38 @@ extern "C" int gpb_gp_lml(gpb_ctx* ctx, const double* theta_host, double* lml_ho
     ctx->factored = true;
     for (int64_t p = 0; p < P; ++p) if (info[p] != 0) ctx->factored = false;     // see gpb_gp_factor
     return 0;
+}
+
+extern "C" int gpb_gp_lml(gpb_ctx* ctx, const double* theta_host, double* lml_host, double* grad_host,
+                          int* info_host) {
+    if (!ctx || !theta_host || !lml_host) return GPB_E_ARG;
+    return lml_impl(ctx, theta_host, lml_host, grad_host, info_host);
+}
+
+// n of the stored GPs, evaluated in the first n slots of the workspaces: the kernels that read a GP's inputs (design, column
+// means, targets, design size) look the stored GP up through gpmap; everything a launch produces is indexed by slot.  A GP's
+// numbers do not depend on its slot or on the other GPs of the launch (per-GP kernels, fixed-order reductions).
+extern "C" int gpb_gp_lml_subset(gpb_ctx* ctx, int64_t n, const int32_t* gp_index, const double* theta_host,
+                                 double* lml_host, double* grad_host, int* info_host) {
+    if (!ctx || !gp_index || !theta_host || !lml_host) return GPB_E_ARG;
+    if (ctx->N == 0) GPB_FAIL(GPB_E_STATE, "gpb_gp_lml_subset before gpb_gp_set");
+    if (n < 1 || n > ctx->Pstore) GPB_FAIL(GPB_E_ARG, "gpb_gp_lml_subset: bad subset size");
+    ctx->h_map.assign((size_t)n, 0);
+    for (int64_t a = 0; a < n; ++a) {
+        if (gp_index[a] < 0 || gp_index[a] >= ctx->Pstore) GPB_FAIL(GPB_E_ARG, "gpb_gp_lml_subset: GP index out of range");
+        ctx->h_map[(size_t)a] = gp_index[a];
+    }
+    GPB_HIP(hipSetDevice(ctx->device));
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    GPB_HIP(hipMemcpy(ctx->gpmap, ctx->h_map.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    ctx->P = n;
+    ctx->subset = true;
+    const int rc = lml_impl(ctx, theta_host, lml_host, grad_host, info_host);
+    ctx->P = ctx->Pstore;
+    ctx->subset = false;
+    // the workspaces hold the subset's factorisation in their first slots and theta is the subset's: nothing to predict from
+    ctx->have_theta = ctx->factored = false;
+    return rc;
 }
 
 extern "C" int gpb_gp_predict(gpb_ctx* ctx, const double* Xs, int64_t W, int on_device, double* mean,

@@ -30,22 +30,23 @@ __device__ __forceinline__ double shape_fn(double r2) {
 // ------------------------------------------------------------------ design scaling
 // Xsc[p][n][k] = X[n][k] / l_p[k]   (sklearn divides: sk:kernels.py:1556,1564)
 __global__ void k_scale_design(const double* __restrict__ X, const double* __restrict__ ls,
-                               double* __restrict__ Xsc, int64_t Np, int dpad) {
+                               double* __restrict__ Xsc, int64_t Np, int dpad, const GpSel sel) {
     const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int p = blockIdx.y;
     if (idx >= Np * dpad) return;
     const int k = idx % dpad;
-    Xsc[(int64_t)p * Np * dpad + idx] = X[idx] / ls[p * dpad + k];
+    Xsc[(int64_t)p * Np * dpad + idx] = X[sel.q(p) * sel.x_stride + idx] / ls[p * dpad + k];
 }
 
 // Centred copy for the dot-product form of the cross kernel (k_kcross): Xc = X/l - mean/l row by row, and the
 // rows' squared norms.  The walkers are shifted by the same muS, so the distances are those of the scaled design.
 __global__ void k_center_design(const double* __restrict__ Xsc, const double* __restrict__ xmean,
                                 const double* __restrict__ ls, double* __restrict__ muS, double* __restrict__ Xc,
-                                double* __restrict__ dnorm, int64_t Np, int dpad) {
+                                double* __restrict__ dnorm, int64_t Np, int dpad, const GpSel sel) {
     const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int p = blockIdx.y;
     if (n >= Np) return;
+    xmean += sel.q(p) * sel.xm_stride;
     const double* src = Xsc + ((int64_t)p * Np + n) * dpad;
     double* dst = Xc + ((int64_t)p * Np + n) * dpad;
     double s = 0.0;
@@ -63,10 +64,10 @@ int launch_scale_design(gpb_ctx* ctx) {
     const int64_t tot = ctx->Np * ctx->dpad;
     dim3 grid((unsigned)((tot + 255) / 256), (unsigned)ctx->P);
     hipLaunchKernelGGL(k_scale_design, grid, dim3(256), 0, ctx->stream, ctx->X, ctx->ls, ctx->Xsc,
-                       ctx->Np, (int)ctx->dpad);
+                       ctx->Np, (int)ctx->dpad, ctx->sel());
     dim3 grid2((unsigned)((ctx->Np + 255) / 256), (unsigned)ctx->P);
     hipLaunchKernelGGL(k_center_design, grid2, dim3(256), 0, ctx->stream, ctx->Xsc, ctx->xmean, ctx->ls, ctx->muS,
-                       ctx->Xc, ctx->dnorm, ctx->Np, (int)ctx->dpad);
+                       ctx->Xc, ctx->dnorm, ctx->Np, (int)ctx->dpad, ctx->sel());
     GPB_HIP(hipGetLastError());
     return 0;
 }
@@ -82,10 +83,11 @@ int launch_scale_design(gpb_ctx* ctx) {
 template <int KIND>
 __global__ __launch_bounds__(256) void k_kmat(const double* __restrict__ Xsc, const double* __restrict__ amp,
                                               const double* __restrict__ noise, double alpha_reg,
-                                              double* __restrict__ K, int64_t N, int64_t Np, int dpad,
+                                              double* __restrict__ K, const GpSel sel, int64_t Np, int dpad,
                                               const int* __restrict__ form) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int p = blockIdx.z;
+    const int64_t N = sel.Nq(sel.q(p));
     if (blockIdx.x > blockIdx.y) return;               // lower block triangle only: nothing reads K above it
     if (form && form[p] != 1) return;                  // a Gram-form GP: k_kmat_mfma's
     const int64_t i0 = (int64_t)blockIdx.y * 64, j0 = (int64_t)blockIdx.x * 64;
@@ -147,9 +149,10 @@ __global__ __launch_bounds__(256) void k_kmat(const double* __restrict__ Xsc, co
 template <int KIND, int DPAD>
 __global__ __launch_bounds__(256) void k_kmat_mfma(const double* __restrict__ Xc, const double* __restrict__ dnorm,
                                                    const double* __restrict__ amp, const double* __restrict__ noise,
-                                                   double alpha_reg, double* __restrict__ K, int64_t N, int64_t Np,
+                                                   double alpha_reg, double* __restrict__ K, const GpSel sel, int64_t Np,
                                                    const int* __restrict__ form) {
     if (form && form[blockIdx.y] != 0) return;         // a difference-form GP: k_kmat's
+    const int64_t N = sel.Nq(sel.q(blockIdx.y));
     // the tile's two operand blocks (64 design rows x DPAD each, contiguous in Xc) are staged in LDS by coalesced 16-byte
     // loads — fragment-shaped loads straight from global memory touched sixteen 32-byte pieces per instruction, 1920 cache
     // line requests per workgroup — and read back as MFMA fragments (row stride DPAD + 1 doubles: conflict-free)
@@ -245,7 +248,7 @@ static void launch_kmat_mfma(gpb_ctx* ctx) {
     dim3 grid((unsigned)(nb * (nb + 1) / 2), (unsigned)ctx->P);
 #define GPB_KM(DP)                                                                                                  \
     hipLaunchKernelGGL((k_kmat_mfma<KIND, DP>), grid, dim3(256), 0, ctx->stream, ctx->Xc, ctx->dnorm, ctx->amp,     \
-                       ctx->noise, ctx->alpha_reg, ctx->K, ctx->N, ctx->Np, ctx->n_diff > 0 ? ctx->gpform : nullptr)
+                       ctx->noise, ctx->alpha_reg, ctx->K, ctx->sel(), ctx->Np, ctx->n_diff > 0 ? ctx->gpform : nullptr)
     switch (ctx->dpad) {
         case 8: GPB_KM(8); break;
         case 16: GPB_KM(16); break;
@@ -263,7 +266,7 @@ static void launch_kmat_diff(gpb_ctx* ctx, const int* form) {
     const size_t sh = 2 * 64 * (ctx->dpad + 1) * sizeof(double);
 #define GPB_KMAT(KIND)                                                                          \
     hipLaunchKernelGGL(k_kmat<KIND>, grid, dim3(256), sh, ctx->stream, ctx->Xsc, ctx->amp,       \
-                       ctx->noise, ctx->alpha_reg, ctx->K, ctx->N, ctx->Np, (int)ctx->dpad, form)
+                       ctx->noise, ctx->alpha_reg, ctx->K, ctx->sel(), ctx->Np, (int)ctx->dpad, form)
     if (ctx->kind == GPB_KERNEL_RBF) GPB_KMAT(GPB_KERNEL_RBF);
     else if (ctx->kind == GPB_KERNEL_MATERN15) GPB_KMAT(GPB_KERNEL_MATERN15);
     else GPB_KMAT(GPB_KERNEL_MATERN25);
@@ -598,11 +601,11 @@ int launch_trtri(gpb_ctx* ctx) {
 // ------------------------------------------------------------------ alpha = L^-T (L^-1 z)
 // y_i = sum_{k<=i} Linv[i][k] z_k : one wave per row, fixed-order shuffle reduction.
 __global__ __launch_bounds__(256) void k_lower_matvec(const double* __restrict__ Linv, const double* __restrict__ z,
-                                                      double* __restrict__ y, int64_t Np) {
+                                                      double* __restrict__ y, int64_t Np, const GpSel sel) {
     const int p = blockIdx.y, lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const double* row = Linv + (int64_t)p * Np * Np + i * Np;
-    const double* zp = z + (int64_t)p * Np;
+    const double* zp = z + (int64_t)sel.q(p) * Np;
     double s = 0.0;
     for (int64_t k = lane; k <= i; k += 64) s = fma(row[k], zp[k], s);
 #pragma unroll
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(64 * MVT_WAVES) void k_lower_matvec_t(const double*
 
 int launch_alpha(gpb_ctx* ctx) {
     hipLaunchKernelGGL(k_lower_matvec, dim3((unsigned)(ctx->Np / 4), (unsigned)ctx->P), dim3(256), 0, ctx->stream,
-                       ctx->Linv, ctx->Z, ctx->yv, ctx->Np);
+                       ctx->Linv, ctx->Z, ctx->yv, ctx->Np, ctx->sel());
     hipLaunchKernelGGL(k_lower_matvec_t, dim3((unsigned)(ctx->Np / 64), (unsigned)ctx->P), dim3(64 * MVT_WAVES), 0,
                        ctx->stream, ctx->Linv, ctx->yv, ctx->alpha, ctx->Np);
     GPB_HIP(hipGetLastError());
@@ -654,13 +657,15 @@ int launch_alpha(gpb_ctx* ctx) {
 // lml = -1/2 z.alpha - sum log L_ii - N/2 log 2pi   (sk:_gpr.py:609-611)
 __global__ __launch_bounds__(256) void k_lml_value(const double* __restrict__ L, const double* __restrict__ z,
                                                    const double* __restrict__ alpha, double* __restrict__ out,
-                                                   int64_t N, int64_t Np) {
+                                                   const GpSel sel, int64_t Np) {
     __shared__ double r1[256], r2[256];
     const int p = blockIdx.x, tid = threadIdx.x;
+    const int q = sel.q(p);
+    const int64_t N = sel.Nq(q);
     const double* Lp = L + (int64_t)p * Np * Np;
     double s1 = 0.0, s2 = 0.0;
     for (int64_t i = tid; i < Np; i += 256) {
-        s1 = fma(z[(int64_t)p * Np + i], alpha[(int64_t)p * Np + i], s1);
+        s1 = fma(z[(int64_t)q * Np + i], alpha[(int64_t)p * Np + i], s1);
         s2 += log(Lp[i * Np + i]);
     }
     r1[tid] = s1; r2[tid] = s2;
@@ -678,7 +683,7 @@ __global__ __launch_bounds__(256) void k_lml_value(const double* __restrict__ L,
 
 int launch_lml_value(gpb_ctx* ctx) {
     hipLaunchKernelGGL(k_lml_value, dim3((unsigned)ctx->P), dim3(256), 0, ctx->stream, ctx->K, ctx->Z, ctx->alpha,
-                       ctx->lmlbuf, ctx->N, ctx->Np);
+                       ctx->lmlbuf, ctx->sel(), ctx->Np);
     GPB_HIP(hipGetLastError());
     return 0;
 }
@@ -709,10 +714,11 @@ template <int KIND, int DPAD>
 __global__ __launch_bounds__(256) void k_lml_grad(const double* __restrict__ Xsc, const double* __restrict__ amp,
                                                   const double* __restrict__ noise,
                                                   const double* __restrict__ alpha, const double* __restrict__ Kinv,
-                                                  double* __restrict__ gpart, int64_t N, int64_t Np, int d,
+                                                  double* __restrict__ gpart, const GpSel sel, int64_t Np, int d,
                                                   int ntiles) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int p = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+    const int64_t N = sel.Nq(sel.q(p));
     int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     while (ti * (ti + 1) / 2 > t) --ti;
@@ -825,7 +831,7 @@ static int launch_grad_kind(gpb_ctx* ctx, int ntiles, double* gfinal) {
     dim3 grid((unsigned)ntiles, (unsigned)ctx->P);
 #define GPB_GRAD(DP)                                                                              \
     hipLaunchKernelGGL((k_lml_grad<KIND, DP>), grid, dim3(256), (128 * (DP + 1) + 4 * (DP + 2)) * sizeof(double), \
-                       ctx->stream, ctx->Xsc, ctx->amp, ctx->noise, ctx->alpha, ctx->T, ctx->gpart, ctx->N,        \
+                       ctx->stream, ctx->Xsc, ctx->amp, ctx->noise, ctx->alpha, ctx->T, ctx->gpart, ctx->sel(),   \
                        ctx->Np, (int)ctx->d, ntiles)
     switch (ctx->dpad) {
         case 8: GPB_GRAD(8); break;

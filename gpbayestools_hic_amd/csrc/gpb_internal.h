@@ -20,6 +20,19 @@ __host__ __device__ inline int64_t imin64(int64_t a, int64_t b) { return a < b ?
 
 }  // namespace gpb
 
+// Which stored GP the compact slot `a` of a fit launch stands for, and that GP's design size.  A context normally holds P GPs
+// over ONE design (gpb_gp_set: map = n = nullptr); gpb_gp_set_multi gives every GP its own design (the GPs of several
+// emulators, or the restarts of a hyper-parameter search, in one batch: n = per-GP sizes, all padded to the same Np) and
+// gpb_gp_lml_subset evaluates a subset of the stored GPs in the first slots of the workspaces (map = slot -> stored GP).
+struct GpSel {
+    const int* map;
+    const int* n;
+    int N;
+    int64_t x_stride, xm_stride;   // per-GP strides of the design / its column means (0: one design for all GPs)
+    __device__ __forceinline__ int q(int a) const { return map ? map[a] : a; }
+    __device__ __forceinline__ int64_t Nq(int qq) const { return n ? (int64_t)n[qq] : (int64_t)N; }
+};
+
 struct LoopGroup;
 struct gpb_ctx {
     int device = 0;
@@ -33,9 +46,19 @@ struct gpb_ctx {
     double alpha_reg = 0.0;
     bool have_theta = false, factored = false;
     double* h_theta = nullptr;     // host [P][d+2]
-    double* X = nullptr;           // [Np][dpad]   raw design (pad rows/cols zero)
+    bool multi = false;            // gpb_gp_set_multi: every GP has its own design (fit-only context: no predict / likelihood)
+    int64_t Pstore = 0;            // GPs stored (P is the number a launch covers: Pstore, or the subset's size inside gpb_gp_lml_subset)
+    int* gpN = nullptr;            // device [Pstore] design points per GP (multi)
+    int* gpmap = nullptr;          // device [Pstore] slot -> stored GP of the current subset evaluation
+    bool subset = false;           // inside gpb_gp_lml_subset
+    std::vector<int> h_N;          // host [Pstore]
+    std::vector<int> h_map;        // host [P] of the current subset
+    GpSel sel() const {
+        return GpSel{subset ? gpmap : nullptr, multi ? gpN : nullptr, (int)N, multi ? Np * dpad : 0, multi ? dpad : 0};
+    }
+    double* X = nullptr;           // [Np][dpad]   raw design (pad rows/cols zero); multi: [Pstore][Np][dpad]
     double* Xsc = nullptr;         // [P][Np][dpad] design / length_scale_p
-    double* xmean = nullptr;       // [dpad] column means of the design (0 in the padding)
+    double* xmean = nullptr;       // [dpad] column means of the design (0 in the padding); multi: [Pstore][dpad]
     double* muS = nullptr;         // [P][dpad] xmean / length_scale_p
     double* Xc = nullptr;          // [P][Np][dpad] Xsc - muS: centred scaled design (dot-product form of k_kcross)
     double* dnorm = nullptr;       // [P][Np] squared norms of the rows of Xc
@@ -43,7 +66,7 @@ struct gpb_ctx {
     // on the centred design (k_kcross<DOT>, k_kmat_mfma), 1 = difference form sum ((a_k - b_k))^2 on X / l as sklearn's cdist
     // computes it (sk:kernels.py:1556,1564,1711-1716).  The Gram form's cancellation costs ~eps (|a|^2 + |b|^2) absolute in
     // r^2: a GP whose S = sum_k (extent_k / l_k)^2 exceeds gram_limit takes the difference form.
-    std::vector<double> h_ext;     // host [d] column extents (max - min) of the design
+    std::vector<double> h_ext;     // host [d] column extents (max - min) of the design; multi: [Pstore][d]
     std::vector<int> h_form;       // host [P]
     int* gpform = nullptr;         // device [P]
     int n_diff = 0;                // GPs in the difference form

@@ -1043,6 +1043,7 @@ static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int
 
 // K*^T and the mean partials of a batch: Xs_dev [W][d] on the device.  Sets the leading dimension of the batch's workspaces.
 int launch_kcross(gpb_ctx* ctx, const double* Xs_dev, int64_t W, const int* nrows_dev) {
+    if (ctx->multi) GPB_FAIL(GPB_E_STATE, "gpb: a gpb_gp_set_multi context is fit-only (its GPs have different designs)");
     if (!ctx->factored) GPB_FAIL(GPB_E_STATE, "gpb: predict before gpb_gp_factor");
     if (W > ctx->Wcap) GPB_FAIL(GPB_E_STATE, "gpb: internal: W exceeds workspace");
     const int64_t Wuse = round_up(W, WPAD);
@@ -1065,6 +1066,8 @@ int launch_kcross(gpb_ctx* ctx, const double* Xs_dev, int64_t W, const int* nrow
 int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, int64_t W, const int* nrows_dev) {
     gpb_ctx* ctx = ctxs[0];
     bool ok = E > 1 && E <= MAX_KX_CTX;
+    for (int e = 0; e < E; ++e)
+        if (ctxs[e]->multi) GPB_FAIL(GPB_E_STATE, "gpb: a gpb_gp_set_multi context is fit-only (its GPs have different designs)");
     for (int e = 0; e < E && ok; ++e)           // (the shared launch is the Gram form's: a context with a difference-form GP takes its own)
         ok = ctxs[e]->n_diff == 0 && ctxs[e]->Np == ctx->Np && ctxs[e]->d == ctx->d && ctxs[e]->dpad == ctx->dpad && ctxs[e]->stream == ctx->stream;
     if (!ok) {

@@ -254,6 +254,17 @@ class Emulator:
     def trainEmulator(self, eventMask, kernel_type="RBF", thetas=None):
         """Fit one GP per principal component (src/emulator.py:257-363).  `thetas` (optional,
         [npc, d+2]) skips the hyper-parameter search and factorises at the given values."""
+        self._prepare_training(eventMask, kernel_type)
+        eng = self._new_engine()
+        if thetas is not None:
+            thetas = np.array(thetas, dtype=np.float64).reshape(self._ngp, -1)
+            lml = eng.lml(thetas, eval_gradient=False)
+        else:
+            thetas, lml = self._optimise(eng, kernel_type)
+        self._finish_training(eng, thetas, lml)
+
+    def _prepare_training(self, eventMask, kernel_type):
+        """the host part in front of the GP fits: scaler, PCA, targets (src/emulator.py:257-285)"""
         if kernel_type not in _KERNELS:
             raise ValueError("Unknown kernel type: {}".format(kernel_type))
         mask = np.asarray(eventMask, dtype=bool)
@@ -269,12 +280,10 @@ class Emulator:
         self._Z_train = np.ascontiguousarray(Z.T, dtype=np.float64)       # [P, N]
         self.kernel_type_ = kernel_type
         self._ngp = self._Z_train.shape[0]
-        eng = self._new_engine()
-        if thetas is not None:
-            self.thetas_ = np.array(thetas, dtype=np.float64).reshape(self._ngp, -1)
-            self.lml_ = eng.lml(self.thetas_, eval_gradient=False)
-        else:
-            self.thetas_, self.lml_ = self._optimise(eng, kernel_type)
+
+    def _finish_training(self, eng, thetas, lml):
+        """the final factorisation at theta*, the observable transform and the per-GP scores (src/emulator.py:316-363)"""
+        self.thetas_, self.lml_ = thetas, lml
         eng.set_theta(self.thetas_)
         eng.factor()
         self._build_transform()
@@ -292,16 +301,31 @@ class Emulator:
                          self.pca.explained_variance_ratio_[n], gp.log_marginal_likelihood_value_,
                          self.gp_scores_[n], gp.kernel_)
 
+    def _search_engine(self, idx, copies):
+        """a fit-only context holding the GPs `idx` of this emulator `copies` times (the starts of their searches)"""
+        return _SearchEngine(self.device, [self._X_train] * len(idx), [self._Z_train[i] for i in idx],
+                             _KERNELS[self.kernel_type_][0], self.alpha, copies)
+
     def _optimise(self, eng, kernel_type):
-        """argmax LML per GP with scipy L-BFGS-B (sk:_gpr.py:296-337,654-670).  The P searches
-        are independent; they run in lock-step threads so that every objective call is ONE
-        batched device evaluation of all P log-marginal likelihoods and gradients."""
+        """argmax LML per GP with scipy L-BFGS-B (sk:_gpr.py:296-337,654-670).  The P searches — and, with
+        nrestarts > 0, the 1 + nrestarts starts of each — are independent; they run in lock-step threads so that every
+        objective call is ONE batched device evaluation of the log-marginal likelihoods and gradients of all searches
+        still running."""
         theta0, bounds = self._theta0_bounds(kernel_type)
         sh = self.fit_sharding
+        copies = 1 + int(self.nrestarts)
+        Np = -(-self._X_train.shape[0] // 64) * 64
+        if copies * self._ngp * 3 * 8 * Np * Np > (96 << 30):     # the batch of all starts would not fit comfortably: start by start
+            copies = 1
         if sh is None or sh.world == 1:
-            return search_hyperparameters(lambda idx: eng, self._ngp, theta0, bounds, self.nrestarts)
+            if copies == 1:
+                return search_hyperparameters(lambda idx: eng, self._ngp, theta0, bounds, self.nrestarts)
+            return search_hyperparameters(lambda idx: self._search_engine(idx, copies), self._ngp, theta0, bounds,
+                                          self.nrestarts, close=True)
 
         def sub_engine(idx):            # this rank's GPs only: same design, a subset of the target rows
+            if copies > 1:
+                return self._search_engine(idx, copies)
             sub = GPEngine(self.device)
             sub.set_data(self._X_train, self._Z_train[idx], _KERNELS[kernel_type][0], self.alpha)
             return sub
@@ -456,29 +480,105 @@ class Emulator:
         return self._holdout(nTestPoints, on_training=True, thetas=thetas)
 
 
+def train_emulators(emulators, eventMasks=None, kernel_type="RBF"):
+    """Train the emulators of a chain TOGETHER: what `for emu in emulators: emu.trainEmulator(mask, kernel_type)` does
+    (the reference fits dataset after dataset and GP after GP: examples/EmulatorTraining.ipynb:124-138,
+    src/emulator.py:309-315), with the hyper-parameter searches of all GPs of all emulators — and all their restarts — in
+    ONE lock-step batch per group of emulators whose designs pad to the same number of points (same number of parameters):
+    at N ~ 1000 a fit is bound by the latency of its Cholesky chain, so 63 matrices per launch cost little more than 7.
+    Every GP's search is the one its emulator's own training runs (same start points: numpy's global RandomState is drawn
+    emulator after emulator, GP after GP; same objective values bit for bit), so theta* is identical.  `eventMasks`: one
+    mask per emulator (default: all events)."""
+    emulators = list(emulators)
+    if eventMasks is None:
+        eventMasks = [[True] * e.nev for e in emulators]
+    for emu, mask in zip(emulators, eventMasks):
+        emu._prepare_training(mask, kernel_type)
+    kern = _KERNELS[kernel_type][0]
+    # restart points in the order sequential trainings would draw them
+    t0b = [emu._theta0_bounds(kernel_type) for emu in emulators]
+    rs = _check_random_state(None)
+    draws = [np.array([[rs.uniform(b[:, 0], b[:, 1]) for _ in range(int(emu.nrestarts))] for _ in range(emu._ngp)])
+             for emu, (_, b) in zip(emulators, t0b)]
+    groups = {}
+    for i, emu in enumerate(emulators):
+        sharded = emu.fit_sharding is not None and emu.fit_sharding.world > 1
+        key = ("alone", i) if sharded else (emu.device, emu._X_train.shape[1], -(-emu._X_train.shape[0] // 64), float(emu.alpha))
+        groups.setdefault(key, []).append(i)
+    results = [None] * len(emulators)
+    for key, members in groups.items():
+        if key[0] == "alone":
+            i = members[0]
+            emu = emulators[i]
+            results[i] = search_hyperparameters(lambda idx, emu=emu: emu._search_engine(idx, 1), emu._ngp, t0b[i][0], t0b[i][1],
+                                                0, emu.fit_sharding, close=True) if emu.nrestarts == 0 else None
+            if results[i] is None:
+                raise NotImplementedError("train_emulators: a sharded fit with restarts trains through trainEmulator")
+            continue
+        Xs, Zs, start, bnd, owner = [], [], [], [], []
+        smax = 1 + max(int(emulators[i].nrestarts) for i in members)
+        for s_ in range(smax):                       # virtual GPs start-major: the first block is every GP's theta0 start
+            for i in members:
+                emu = emulators[i]
+                if s_ > int(emu.nrestarts):
+                    continue
+                for g in range(emu._ngp):
+                    Xs.append(emu._X_train); Zs.append(emu._Z_train[g])
+                    start.append(t0b[i][0] if s_ == 0 else draws[i][g, s_ - 1])
+                    bnd.append(t0b[i][1]); owner.append((i, g, s_))
+        eng = GPEngine(emulators[members[0]].device)
+        try:
+            eng.set_data_multi(Xs, Zs, kern, float(emulators[members[0]].alpha))
+            th, val = _batched_lbfgsb(eng, np.array(start), np.array(bnd))
+        finally:
+            eng.close()
+        for i in members:
+            emu = emulators[i]
+            results[i] = (np.tile(t0b[i][0], (emu._ngp, 1)), np.full(emu._ngp, np.inf))
+        for v, (i, g, s_) in enumerate(owner):       # start-major = sklearn's order per GP: the first of equal optima wins
+            if val[v] < results[i][1][g]:
+                results[i][0][g], results[i][1][g] = th[v], val[v]
+        for i in members:
+            results[i] = (results[i][0], -results[i][1])
+    for emu, (thetas, lml) in zip(emulators, results):
+        emu._finish_training(emu._new_engine(), thetas, lml)
+    return emulators
+
+
 def search_hyperparameters(make_engine, P, theta0, bounds, nrestarts=0, sharding=None, close=False, rng=None):
     """theta*[P, d+2] and LML*[P]: L-BFGS-B from `theta0` plus `nrestarts` log-uniform starts per GP
     (sk:_gpr.py:296-337); `rng`: None (numpy's global RandomState, as sklearn), an int seed or a RandomState.  `make_engine(idx)` returns an object whose `.lml(theta[len(idx), d+2],
     eval_gradient=True)` serves the GPs `idx`.  With `sharding` (dist.GPSharding, SURVEY §8e "fit-side") the
     P searches are dealt round-robin to the ranks and ONE all-gather puts every result on every rank; a GP's
-    search does not depend on which other GPs share its batch, so the result is the unsharded one."""
+    search does not depend on which other GPs share its batch, so the result is the unsharded one.
+
+    All 1 + nrestarts starts of all GPs run as ONE lock-step batch when the engine offers `restart_batch(n)` (an engine
+    holding n copies of every GP: `_RestartEngine`): the fit is bound by the latency of its Cholesky chain, so (1 + nrestarts) P
+    matrices per launch cost little more than P (the reference, like sklearn, runs start after start and GP after GP,
+    src/emulator.py:309-315); searches that have converged leave the batch."""
     idx = np.arange(P) if sharding is None else sharding.mine(P)
-    k = theta0.size
     # restart points as sklearn draws them: GPR(random_state=None) takes numpy's GLOBAL RandomState (np.random.seed
     # makes a fit reproducible) and draws, GP after GP, one log-uniform theta per restart (sk:_gpr.py:259,318-325).
     # Every rank draws all P x nrestarts points and keeps its own, so a sharded fit equals the unsharded one.
     rs = _check_random_state(rng)
-    draws = np.array([[rs.uniform(bounds[:, 0], bounds[:, 1]) for _ in range(int(nrestarts))] for _ in range(P)])
-    restart_points = [draws[:, r, :] for r in range(int(nrestarts))]
+    nrestarts = int(nrestarts)
+    draws = np.array([[rs.uniform(bounds[:, 0], bounds[:, 1]) for _ in range(nrestarts)] for _ in range(P)])
     best_theta = np.tile(theta0, (idx.size, 1))
     best_val = np.full(idx.size, np.inf)
     if idx.size:
         eng = make_engine(idx)
         try:
             starts = [np.tile(theta0, (idx.size, 1))]
-            starts += [s[idx] for s in restart_points]
-            for start in starts:
-                th, val = _batched_lbfgsb(eng, start, bounds)
+            starts += [draws[idx, r, :] for r in range(nrestarts)]
+            batch = getattr(eng, "restart_batch", None)
+            if batch is not None and nrestarts > 0:
+                # virtual GP v = s * n + i: start s of GP i (the engine holds the GPs' data once per start)
+                th, val = _batched_lbfgsb(batch(1 + nrestarts), np.concatenate(starts, axis=0), bounds)
+                results = [(th[s * idx.size:(s + 1) * idx.size], val[s * idx.size:(s + 1) * idx.size])
+                           for s in range(1 + nrestarts)]
+            else:
+                results = [_batched_lbfgsb(eng, start, bounds) for start in starts]
+            for th, val in results:                    # in sklearn's order: the first of equal optima wins (np.argmin)
                 better = val < best_val
                 best_theta[better], best_val[better] = th[better], val[better]
         finally:
@@ -489,18 +589,51 @@ def search_hyperparameters(make_engine, P, theta0, bounds, nrestarts=0, sharding
     return sharding.gather(P, idx, best_theta, -best_val)
 
 
+class _SearchEngine:
+    """The GPs of a hyper-parameter search on one fit-only device context (gpb_gp_set_multi): `Xs[i]`, `Zs[i]` the design and
+    targets of GP i — of one emulator or of several — each stored `copies` times (the starts of its search).  `.lml(theta[V])`
+    evaluates all V = copies x n virtual GPs, `.lml_active(idx, theta)` the ones still searching."""
+
+    def __init__(self, device, Xs, Zs, kernel, alpha, copies=1):
+        self.n = len(Xs)
+        self.copies = int(copies)
+        self.eng = GPEngine(device)
+        self.eng.set_data_multi(list(Xs) * self.copies, list(Zs) * self.copies, kernel, alpha)
+
+    def restart_batch(self, copies):
+        assert copies == self.copies
+        return self
+
+    def lml(self, theta, eval_gradient=True):
+        return self.eng.lml(theta, eval_gradient)
+
+    def lml_active(self, idx, theta):
+        return self.eng.lml_subset(idx, theta, True)
+
+    def close(self):
+        self.eng.close()
+
+
 def _batched_lbfgsb(eng, start, bounds):
     """Run P independent scipy L-BFGS-B minimisations of -LML_p(theta_p) in lock-step threads;
-    each round of objective calls is served by one batched gpb_gp_lml evaluation."""
+    each round of objective calls is served by one batched device evaluation — of the searches still running when the
+    engine can evaluate a subset (`lml_active`), else of all P (`lml`; a finished search's theta stays where it ended)."""
     P = start.shape[0]
     cur = start.copy()
     results = [None] * P
     cond = threading.Condition()
     state = {"waiting": 0, "active": P, "round": 0, "val": None, "grad": None, "err": None}
+    alive = np.ones(P, dtype=bool)
+    subset = getattr(eng, "lml_active", None)
 
     def evaluate_round():
         try:
-            v, g = eng.lml(cur, eval_gradient=True)
+            if subset is not None and not alive.all():
+                ids = np.flatnonzero(alive)
+                v = np.full(P, np.nan); g = np.full((P, cur.shape[1]), np.nan)
+                v[ids], g[ids] = subset(ids, cur[ids])
+            else:
+                v, g = eng.lml(cur, eval_gradient=True)
             state["val"], state["grad"] = v, g
         except Exception as e:  # propagate to every waiting thread
             state["err"] = e
@@ -525,13 +658,14 @@ def _batched_lbfgsb(eng, start, bounds):
     def worker(p):
         try:
             res = scipy.optimize.minimize(lambda th: objective(p, th), start[p], method="L-BFGS-B",
-                                          jac=True, bounds=bounds)
+                                          jac=True, bounds=bounds[p] if bounds.ndim == 3 else bounds)
             results[p] = (res.x, res.fun)
         except Exception as e:
             results[p] = e
         finally:
             with cond:
                 state["active"] -= 1
+                alive[p] = False
                 if state["active"] > 0 and state["waiting"] == state["active"]:
                     evaluate_round()
 

@@ -151,6 +151,40 @@ class GPEngine:
         self.M, self.pmap_d_in, self.pmap_d_out = 0, -1, -1       # gpb_gp_set drops the transform, likelihood and map
         self._ck(self.lib.gpb_gp_set(self.h, self.N, self.d, self.P, nat.ptr(X), nat.ptr(Z), kid, float(alpha)))
 
+    def set_data_multi(self, Xs, Zs, kernel="RBF", alpha=0.1):
+        """P GPs, each over its own design: Xs[p] [N_p, d], Zs[p] [N_p] (gpb_gp_set_multi: the GPs of several emulators or
+        the restarts of a search side by side; the designs must pad to the same multiple of 64 points).  Fit-only."""
+        self._check_pid()
+        import ctypes
+        Xs = [nat.f64(x) for x in Xs]
+        Zs = [nat.f64(z).reshape(-1) for z in Zs]
+        self.P = len(Xs)
+        assert self.P >= 1 and len(Zs) == self.P
+        self.d = Xs[0].shape[1]
+        for x, z in zip(Xs, Zs):
+            assert x.ndim == 2 and x.shape[1] == self.d and z.shape[0] == x.shape[0]
+        Ns = np.array([x.shape[0] for x in Xs], dtype=np.int64)
+        self.N = int(Ns.max())
+        kid = KERNEL_IDS[kernel] if isinstance(kernel, str) else int(kernel)
+        self.M, self.pmap_d_in, self.pmap_d_out = 0, -1, -1
+        xp = (ctypes.c_void_p * self.P)(*[x.ctypes.data for x in Xs])
+        zp = (ctypes.c_void_p * self.P)(*[z.ctypes.data for z in Zs])
+        self._ck(self.lib.gpb_gp_set_multi(self.h, self.P, self.d, nat.ptr(Ns), xp, zp, kid, float(alpha)))
+
+    def lml_subset(self, idx, theta, eval_gradient=True):
+        """LML (and gradient) of the stored GPs `idx` at theta[len(idx), d+2] in one launch sequence (gpb_gp_lml_subset);
+        the context is left without a factorisation."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        n = idx.shape[0]
+        theta = nat.f64(theta).reshape(n, self.d + 2)
+        val = np.empty(n)
+        grad = np.empty((n, self.d + 2)) if eval_gradient else None
+        info = np.zeros(n, dtype=np.int32)
+        self._ck(self.lib.gpb_gp_lml_subset(self.h, n, nat.ptr(idx), nat.ptr(theta), nat.ptr(val), nat.ptr(grad), nat.ptr(info)))
+        return (val, grad) if eval_gradient else val
+
+    lml_active = lml_subset          # the name the lock-step search driver looks for (emulator._batched_lbfgsb)
+
     def set_theta(self, theta):
         theta = nat.f64(theta).reshape(self.P, self.d + 2)
         self._ck(self.lib.gpb_gp_set_theta(self.h, nat.ptr(theta)))

@@ -85,6 +85,19 @@ void* gpb_stream(gpb_ctx* ctx);
 int gpb_gp_set(gpb_ctx* ctx, int64_t N, int64_t d, int64_t P,
                const double* X_host /*[N,d]*/, const double* Z_host /*[P,N]*/,
                int kernel_id, double alpha);
+/* gpb_gp_set_multi: P GPs, each over ITS OWN design — the GPs of several emulators of a chain (the reference fits dataset
+ * after dataset and GP after GP: examples/EmulatorTraining.ipynb:124-138, src/emulator.py:309-315) or the 1 + n_restarts
+ * starts of every GP's hyper-parameter search (sk:_gpr.py:318-337) side by side in one batch.  All designs must pad to the
+ * same multiple of 64 points.  Such a context is fit-only: gpb_gp_set_theta, gpb_gp_factor, gpb_gp_get, gpb_gp_lml and
+ * gpb_gp_lml_subset work on it, the predict / likelihood entry points return GPB_E_STATE.
+ * gpb_gp_lml_subset: log-marginal likelihood (+ gradient) of n of the stored GPs — the searches still running — at
+ * theta[n, d+2]; a GP's values do not depend on which other GPs share the call (bit for bit).  Works on any context; leaves
+ * it without a factorisation (gpb_gp_set_theta + gpb_gp_factor afterwards). */
+int gpb_gp_set_multi(gpb_ctx* ctx, int64_t P, int64_t d, const int64_t* N_host /*[P]*/,
+                     const double* const* X_host /*[P] pointers to [N_p,d]*/,
+                     const double* const* Z_host /*[P] pointers to [N_p]*/, int kernel_id, double alpha);
+int gpb_gp_lml_subset(gpb_ctx* ctx, int64_t n, const int32_t* gp_index /*[n]*/, const double* theta_host /*[n,d+2]*/,
+                      double* lml_host /*[n]*/, double* grad_host /*[n,d+2] or NULL*/, int* info_host /*[n] or NULL*/);
 int gpb_gp_set_theta(gpb_ctx* ctx, const double* theta_host /*[P,d+2]*/);
 int gpb_gp_factor(gpb_ctx* ctx, int* info_host /*[P], may be NULL*/);
 int gpb_gp_get(gpb_ctx* ctx, int what, double* out_host);
