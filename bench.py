@@ -346,6 +346,13 @@ def main():
     N, d, M, P = info["N"], info["d"], info["M"], info["P"]
     nwalkers = args.walkers or 2 * info["W"]
     sharding = WalkerSharding() if world > 1 else None
+    if sharding is not None:
+        # every rank has just trained the same emulator on the same synthetic data — but the host part of a training (scaler
+        # + PCA: an N x M SVD in numpy) rounds differently under a different BLAS threading, so the replicas are rank 0's
+        # (broadcast of its fitted host state; each rank rebuilds its factorisation from it), and StretchSampler.run has all
+        # ranks prove their state digests equal before the first step
+        sharding.replicate(chain)
+        info["yexp"] = chain.expdata[0].copy()
     sampler = StretchSampler(chain, nwalkers, seed=12345, sharding=sharding, device=local)
     # burnt-in start: a ball around theta*, small enough that the stretch move (which grows a concentrated ensemble by
     # about 1.4x per step towards the posterior's width) keeps every proposal inside the prior box over warm-up + timed steps

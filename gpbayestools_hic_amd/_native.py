@@ -12,8 +12,13 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# GPB_DEBUG_LIB=1 (the sweeps in tools/): the build with every measured-and-rejected kernel variant behind its tune key
-LIB_PATH = os.path.join(HERE, "libgpbayes_debug.so" if os.environ.get("GPB_DEBUG_LIB") == "1" else "libgpbayes.so")
+# libgpbayes.so: the product library (exports include/gpbayes.h, nothing else).  libgpbayes_debug.so: the same sources with
+# -DGPB_DEBUG_VARIANTS — the measured-and-rejected kernel variants behind their option keys plus the test hooks of
+# include/gpbayes_debug.h.  GPB_DEBUG_LIB=1 makes the debug build the default of a process (the sweeps in tools/);
+# debug_library() does so for a block (tests that need a hook); both can be loaded side by side (-Bsymbolic, RTLD_LOCAL).
+LIB_PATHS = {False: os.path.join(HERE, "libgpbayes.so"), True: os.path.join(HERE, "libgpbayes_debug.so")}
+_default_debug = os.environ.get("GPB_DEBUG_LIB") == "1"
+LIB_PATH = LIB_PATHS[_default_debug]
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -65,55 +70,91 @@ BOUNDARY = {
     "gpb_dist_init": (C.c_int, [VP, C.c_int, C.c_int, VP]),
     "gpb_dist_allgather": (C.c_int, [VP, VP, VP, c_i64]),
     "gpb_dist_finalize": (C.c_int, [VP]),
+    "gpb_ctx_option": (C.c_int, [VP, C.c_int, C.c_int]),
+    "gpb_debug_has_variants": (C.c_int, []),
+    "gpb_profile_enable": (C.c_int, [VP, C.c_int]),
+    "gpb_profile_read": (C.c_int, [VP, VP, VP, VP]),
+    "gpb_profile_fit_piece": (C.c_int, [VP, C.c_int]),
 }
 DEBUG = {
     "gpb_test_split_perm": (C.c_int, [VP, c_i64, c_u64, c_u64, VP]),
     "gpb_test_philox": (C.c_int, [VP, c_i64, VP, VP]),
     "gpb_test_stretch_draws": (C.c_int, [VP, c_i64, C.c_int, c_u64, c_u64, C.c_int, VP, VP, VP, VP]),
     "gpb_test_gemm": (C.c_int, [VP, c_i64, c_i64, c_i64, VP, VP, VP, C.c_int]),
-    "gpb_debug_force_tile": (C.c_int, [VP, C.c_int, c_i64]),
-    "gpb_debug_tune": (C.c_int, [VP, C.c_int, C.c_int]),
-    "gpb_debug_has_variants": (C.c_int, []),
-    "gpb_debug_fit_piece": (C.c_int, [VP, C.c_int]),
     "gpb_debug_loopback_group": (C.c_int, [VP, C.c_int]),
     "gpb_debug_loopback_release": (C.c_int, [VP]),
-    "gpb_debug_force_generic_mvn": (C.c_int, [VP, C.c_int]),
     "gpb_debug_tile_trace": (C.c_int, [VP, c_i64]),
     "gpb_debug_tile_trace_read": (C.c_int, [VP, VP, c_i64, VP]),
-    "gpb_profile_enable": (C.c_int, [VP, C.c_int]),
-    "gpb_profile_read": (C.c_int, [VP, VP, VP, VP]),
     "gpb_debug_graph_probe": (C.c_int, [VP, C.c_int, VP, VP, c_i64, c_u64, C.c_double, VP, VP, C.c_double, C.c_double, C.c_int, VP, VP]),
     "gpb_probe_fp64": (C.c_int, [VP, C.c_int, VP]),
 }
 PROTOTYPES = dict(BOUNDARY, **DEBUG)
 
-_lib = None
+_libs = {False: None, True: None}
 
 
 class GPBError(RuntimeError):
     pass
 
 
-def load():
-    """Load libgpbayes.so (raises if it has not been built)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _debug_only(name):
+    def stub(*_a, **_k):
+        raise GPBError(f"{name} is a hook of the debug build (libgpbayes_debug.so: `python -m gpbayestools_hic_amd.build "
+                       "--debug-variants`, then GPB_DEBUG_LIB=1 or _native.debug_library())")
+    return stub
+
+
+class _Lib:
+    """the loaded library: its entry points as attributes; in the product library the debug hooks are stubs that raise"""
+
+    def __init__(self, cdll, debug):
+        self._cdll, self.is_debug = cdll, debug
+        for name, (res, args) in BOUNDARY.items():
+            fn = getattr(cdll, name)
+            fn.restype, fn.argtypes = res, args
+            setattr(self, name, fn)
+        for name, (res, args) in DEBUG.items():
+            if debug:
+                fn = getattr(cdll, name)
+                fn.restype, fn.argtypes = res, args
+                setattr(self, name, fn)
+            else:
+                setattr(self, name, _debug_only(name))
+
+
+def load(debug=None):
+    """Load libgpbayes.so — or, debug=True / GPB_DEBUG_LIB=1 / inside debug_library(), libgpbayes_debug.so (raises if it has
+    not been built)."""
+    debug = _default_debug if debug is None else bool(debug)
+    if _libs[debug] is not None:
+        return _libs[debug]
+    path = LIB_PATHS[debug]
+    if not os.path.exists(path):
         raise GPBError(
-            f"{LIB_PATH} not found: build it with `python -m gpbayestools_hic_amd.build` "
-            "(there is no CPU fallback)")
+            f"{path} not found: build it with `python -m gpbayestools_hic_amd.build"
+            + (" --debug-variants`" if debug else "`") + " (there is no CPU fallback)")
     try:
         import torch  # noqa: F401  (one shared HIP runtime per process)
     except Exception:  # pragma: no cover
         pass
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-    for name, (res, args) in PROTOTYPES.items():
-        fn = getattr(lib, name)
-        fn.restype = res
-        fn.argtypes = args
-    _lib = lib
-    return lib
+    _libs[debug] = _Lib(C.CDLL(path), debug)
+    return _libs[debug]
+
+
+class debug_library:
+    """with debug_library(): engines created inside the block bind libgpbayes_debug.so (test hooks, kernel variants); engines
+    created before keep the library they were created with."""
+
+    def __enter__(self):
+        global _default_debug
+        load(True)
+        self._prev, _default_debug = _default_debug, True
+        return self
+
+    def __exit__(self, *exc):
+        global _default_debug
+        _default_debug = self._prev
+        return False
 
 
 def ptr(a):

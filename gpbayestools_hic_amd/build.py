@@ -21,8 +21,9 @@ def _stale(lib=LIB):
 
 def build_native(force=False, verbose=False, debug_variants=False):
     """libgpbayes.so: the product library (the kernels its own rules select).  debug_variants=True: libgpbayes_debug.so,
-    the same sources with -DGPB_DEBUG_VARIANTS — every measured-and-rejected kernel variant behind its gpb_debug_tune key,
-    for the sweeps in tools/ and the variant tests (loaded with GPB_DEBUG_LIB=1)."""
+    the same sources with -DGPB_DEBUG_VARIANTS — every measured-and-rejected kernel variant behind its gpb_ctx_option key and
+    the test hooks of include/gpbayes_debug.h, for the sweeps in tools/ and the tests that need them (GPB_DEBUG_LIB=1, or
+    _native.debug_library() for one test)."""
     lib = LIB_DEBUG if debug_variants else LIB
     if not force and not _stale(lib):
         return lib
@@ -33,7 +34,9 @@ def build_native(force=False, verbose=False, debug_variants=False):
     os.makedirs(bdir, exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
+        # -fvisibility=hidden: the library exports the entry points of include/gpbayes.h (GPB_API) and, in the debug build,
+        # include/gpbayes_debug.h — nothing of the C++ inside
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-c",
                os.path.join(CSRC, src), "-o", obj] + (["-DGPB_DEBUG_VARIANTS"] if debug_variants else [])
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
@@ -43,7 +46,9 @@ def build_native(force=False, verbose=False, debug_variants=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
+    # -Bsymbolic: the entry points call each other inside their own library, so that the product and the debug build can be
+    # loaded into one process side by side (tests that need the debug hooks, _native.debug_library())
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", lib] + objs + ["-ldl"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stdout.decode()))

@@ -806,61 +806,92 @@ extern "C" int gpb_dist_init(gpb_ctx* ctx, int rank, int nranks, const void* uid
     return 0;
 }
 
-// ---- loopback group (test hook): R contexts of ONE process, each with its own stream and driven by its own host thread, as the
-// ranks of a communicator.  The one-GPU build box cannot form an RCCL communicator of more than one rank (RCCL refuses two
-// ranks on a device), so without this the R > 1 form of gpb_chain_emcee_run — per-rank row shares, offsets into the gathered
-// vector, accept steps fed by the other ranks' log-probabilities — never runs as a whole.  The all-gather is emulated on
-// the ranks' streams: every rank records an event behind its producers, the host threads meet, every rank's stream waits
-// for every peer's event and copies the peer's block, records a second event behind its copies, the threads meet again,
+#ifdef GPB_DEBUG_VARIANTS
+// ---- loopback group (test hook, debug build only): R contexts of ONE process, each with its own stream and driven by its own
+// host thread, as the ranks of a communicator.  The one-GPU build box cannot form an RCCL communicator of more than one rank
+// (RCCL refuses two ranks on a device), so without this the R > 1 form of gpb_chain_emcee_run — per-rank row shares, offsets
+// into the gathered vector, accept steps fed by the other ranks' log-probabilities — never runs as a whole.  The all-gather is
+// emulated on the ranks' streams: every rank records an event behind its producers, the host threads meet, every rank's stream
+// waits for every peer's event and copies the peer's block, records a second event behind its copies, the threads meet again,
 // and every stream waits for every peer's second event (a peer may still be reading this rank's block).  Same stream
 // semantics as ncclAllGather: in order on the caller's stream, asynchronous to the host after the call.
+// A rank whose HIP call fails still keeps BOTH appointments of the call (its peers would wait for it for good otherwise) and
+// marks the group aborted: every member's current and later calls then return GPB_E_STATE.  Releasing the group wakes whoever
+// still waits and frees it only when nobody is inside a meeting.
 struct LoopGroup {
     int R = 0;
     std::mutex m;
     std::condition_variable cv;
-    int arrived = 0;
+    int arrived = 0, inside = 0;
+    bool aborted = false;
     unsigned long long gen = 0;
     std::vector<const double*> send;
     std::vector<hipEvent_t> ready, done;
     std::vector<gpb_ctx*> members;
-    void meet() {
+    bool meet() {                                     // false: the group was aborted (by a failing rank or by its release)
         std::unique_lock<std::mutex> lk(m);
+        ++inside;
         const unsigned long long g = gen;
         if (++arrived == R) { arrived = 0; ++gen; cv.notify_all(); }
-        else cv.wait(lk, [&] { return gen != g; });
+        else cv.wait(lk, [&] { return gen != g || aborted; });
+        --inside;
+        if (aborted) cv.notify_all();                 // (a release waiting for `inside` to drain)
+        return !aborted;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lk(m);
+        aborted = true;
+        cv.notify_all();
     }
 };
 
 static int loop_allgather(gpb_ctx* ctx, const double* send_dev, double* recv_dev, int64_t count) {
     LoopGroup* G = ctx->loop;
     const int r = ctx->rank, R = G->R;
-    GPB_HIP(hipEventRecord(G->ready[r], ctx->stream));
+    hipError_t e = hipEventRecord(G->ready[r], ctx->stream);
     G->send[r] = send_dev;
-    G->meet();
-    for (int q = 0; q < R; ++q) {
-        if (q != r) GPB_HIP(hipStreamWaitEvent(ctx->stream, G->ready[q], 0));
+    if (e != hipSuccess) G->abort();
+    bool ok = G->meet() && e == hipSuccess;
+    for (int q = 0; q < R && ok; ++q) {
+        if (q != r) e = hipStreamWaitEvent(ctx->stream, G->ready[q], 0);
         double* dst = recv_dev + (int64_t)q * count;
-        if (dst != G->send[q])
-            GPB_HIP(hipMemcpyAsync(dst, G->send[q], sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, ctx->stream));
+        if (e == hipSuccess && dst != G->send[q])
+            e = hipMemcpyAsync(dst, G->send[q], sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, ctx->stream);
+        ok = e == hipSuccess;
     }
-    GPB_HIP(hipEventRecord(G->done[r], ctx->stream));
-    G->meet();
-    for (int q = 0; q < R; ++q)
-        if (q != r) GPB_HIP(hipStreamWaitEvent(ctx->stream, G->done[q], 0));
+    if (ok) ok = (e = hipEventRecord(G->done[r], ctx->stream)) == hipSuccess;
+    if (!ok) G->abort();                              // before the second appointment, which this rank still keeps
+    ok = G->meet() && ok;
+    for (int q = 0; q < R && ok; ++q)
+        if (q != r) ok = (e = hipStreamWaitEvent(ctx->stream, G->done[q], 0)) == hipSuccess;
+    if (!ok) {
+        if (e != hipSuccess) { ctx->err = std::string("loopback all-gather: ") + hipGetErrorString(e); return GPB_E_HIP; }
+        GPB_FAIL(GPB_E_STATE, "loopback all-gather: the group was aborted (a member failed or the group was released)");
+    }
     return 0;                                       // (the next call's first meeting keeps a fast rank from re-recording early)
+}
+
+static void loop_free(LoopGroup* G) {
+    for (hipEvent_t e : G->ready) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : G->done) if (e) (void)hipEventDestroy(e);
+    delete G;
 }
 
 extern "C" int gpb_debug_loopback_group(gpb_ctx* const* ctxs, int R) {
     if (!ctxs || R < 1 || R > 64) return GPB_E_ARG;
     for (int r = 0; r < R; ++r)
-        if (!ctxs[r] || ctxs[r]->comm || ctxs[r]->loop) return GPB_E_ARG;
+        if (!ctxs[r] || ctxs[r]->comm || ctxs[r]->loop || ctxs[r]->device != ctxs[0]->device) return GPB_E_ARG;
+    if (hipSetDevice(ctxs[0]->device) != hipSuccess) return GPB_E_HIP;      // single-device test hook: the events live there
     LoopGroup* G = new LoopGroup;
     G->R = R;
     G->send.assign((size_t)R, nullptr);
-    G->ready.resize((size_t)R); G->done.resize((size_t)R);
+    G->ready.assign((size_t)R, nullptr); G->done.assign((size_t)R, nullptr);
     for (int r = 0; r < R; ++r) {
         if (hipEventCreateWithFlags(&G->ready[r], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&G->done[r], hipEventDisableTiming) != hipSuccess) return GPB_E_HIP;
+            hipEventCreateWithFlags(&G->done[r], hipEventDisableTiming) != hipSuccess) {
+            loop_free(G);                           // (with the events created so far)
+            return GPB_E_HIP;
+        }
         G->members.push_back(ctxs[r]);
     }
     for (int r = 0; r < R; ++r) {
@@ -870,10 +901,12 @@ extern "C" int gpb_debug_loopback_group(gpb_ctx* const* ctxs, int R) {
     return 0;
 }
 
-static void loop_free(LoopGroup* G) {
-    for (hipEvent_t e : G->ready) (void)hipEventDestroy(e);
-    for (hipEvent_t e : G->done) (void)hipEventDestroy(e);
-    delete G;
+// wake whoever waits in a meeting and wait until nobody is inside one: only then may the group's mutex go
+static void loop_drain(LoopGroup* G) {
+    std::unique_lock<std::mutex> lk(G->m);
+    G->aborted = true;
+    G->cv.notify_all();
+    G->cv.wait(lk, [&] { return G->inside == 0; });
 }
 // a member leaves (its context is being destroyed without a release of the group): the group forgets it and goes with its last member
 static void loop_detach(gpb_ctx* ctx) {
@@ -884,21 +917,26 @@ static void loop_detach(gpb_ctx* ctx) {
         any = any || c != nullptr;
     }
     ctx->loop = nullptr; ctx->comm = nullptr; ctx->rank = 0; ctx->nranks = 1;
-    if (!any) loop_free(G);
+    if (!any) { loop_drain(G); loop_free(G); }
+    else G->abort();                                // the others can no longer complete a collective
 }
 
 extern "C" int gpb_debug_loopback_release(gpb_ctx* ctx) {
     if (!ctx || !ctx->loop) return GPB_E_ARG;
     LoopGroup* G = ctx->loop;
+    loop_drain(G);
     for (gpb_ctx* c : G->members)
         if (c) { (void)hipStreamSynchronize(c->stream); c->loop = nullptr; c->comm = nullptr; c->rank = 0; c->nranks = 1; }
     loop_free(G);
     return 0;
 }
+#endif  // GPB_DEBUG_VARIANTS
 
 extern "C" int gpb_dist_allgather(gpb_ctx* ctx, const double* send_dev, double* recv_dev, int64_t count) {
     if (!ctx || !send_dev || !recv_dev || count < 0) return GPB_E_ARG;
+#ifdef GPB_DEBUG_VARIANTS
     if (ctx->loop) return loop_allgather(ctx, send_dev, recv_dev, count);
+#endif
     if (!ctx->comm) GPB_FAIL(GPB_E_STATE, "gpb_dist_allgather before gpb_dist_init");
     if (g_rccl.allgather(send_dev, recv_dev, (size_t)count, NCCL_DOUBLE, ctx->comm, ctx->stream) != 0)
         GPB_FAIL(GPB_E_RCCL, "ncclAllGather failed");
@@ -907,11 +945,14 @@ extern "C" int gpb_dist_allgather(gpb_ctx* ctx, const double* send_dev, double* 
 
 extern "C" int gpb_dist_finalize(gpb_ctx* ctx) {
     if (!ctx) return GPB_E_ARG;
+#ifdef GPB_DEBUG_VARIANTS
     if (ctx->loop) { loop_detach(ctx); return 0; }  // (normally the group is released as a whole: gpb_debug_loopback_release)
+#endif
     if (ctx->comm && g_rccl.destroy) { g_rccl.destroy(ctx->comm); ctx->comm = nullptr; }
     return 0;
 }
 
+#ifdef GPB_DEBUG_VARIANTS
 // ---------------------------------------------------------------------------- test hooks
 extern "C" int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K, const double* A_host,
                              const double* B_host, double* C_host, int b_trans) {
@@ -933,12 +974,7 @@ extern "C" int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K, cons
     return rc;
 }
 
-extern "C" int gpb_debug_force_tile(gpb_ctx* ctx, int tile, int64_t switch_tiles) {
-    if (!ctx || (tile != 0 && tile != 32 && tile != 64 && tile != 65 && tile != 128)) return GPB_E_ARG;   // 32 = 64 rows x 32 walkers, 65 = 64 x 128
-    ctx->force_tile = tile;
-    if (switch_tiles > 0) ctx->tile_switch = switch_tiles;
-    return 0;
-}
+#endif  // GPB_DEBUG_VARIANTS
 
 // Launch-geometry knobs (never change a result); the key list is documented with the declaration in
 // include/gpbayes_debug.h and mirrored by GPEngine.tune() in engine.py.
@@ -950,16 +986,17 @@ extern "C" int gpb_debug_has_variants(void) {
 #endif
 }
 
-extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
+extern "C" int gpb_ctx_option(gpb_ctx* ctx, int key, int value) {
     if (!ctx) return GPB_E_ARG;
 #ifndef GPB_DEBUG_VARIANTS
     // the product library holds only the kernels its own rules select: the keys that switch to a measured-and-rejected
-    // variant exist in the debug build (libgpbayes_debug.so, -DGPB_DEBUG_VARIANTS) and are refused here
+    // variant or to a measurement hook (26, 32: one rank's share of a sharded step on a single GPU) exist in the debug build
+    // (libgpbayes_debug.so, -DGPB_DEBUG_VARIANTS) and are refused here
     {
-        const bool variant = (key == 2 && value != 4) || (key == 5 && value == 0) ||
+        const bool variant = (key == 2 && value != 4) || (key == 5 && value == 0) || (key == 26 && value != 0) || (key == 32 && value != 0) ||
                              (key == 21 && value != 1) || (key == 24 && value != 1) || (key == 37 && value != 1) ||
                              (key == 38 && value != 0) || (key == 39 && value != 1) || (key == 41 && value != 0);
-        if (variant) GPB_FAIL(GPB_E_ARG, "gpb_debug_tune: this value selects a kernel variant of the debug build only");
+        if (variant) GPB_FAIL(GPB_E_ARG, "gpb_ctx_option: this value selects a kernel variant or hook of the debug build only");
     }
 #endif
     switch (key) {
@@ -1007,6 +1044,12 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
         case 39: if (value < 0 || value > 1) return GPB_E_ARG; ctx->kmat_mfma = value; break;
         case 40: if (value < 0 || value > 1) return GPB_E_ARG; ctx->chain_batch = value; break;
         case 41: if (value < 0 || value > 1) return GPB_E_ARG; ctx->predict_dma = value; break;
+        case 42:        // force the predict tile: 0 = by rule, 128 / 64 / 32 (= 64 x 32) / 65 (= 64 x 128) — all product shapes, same bits
+            if (value != 0 && value != 32 && value != 64 && value != 65 && value != 128) return GPB_E_ARG;
+            ctx->force_tile = value;
+            break;
+        case 43: if (value < 0 || value > 1) return GPB_E_ARG; ctx->force_generic_mvn = value != 0; break;
+        case 44: if (value < 0) return GPB_E_ARG; ctx->tile_switch = value > 0 ? value : 960; break;
         case 33: if (value < 0) return GPB_E_ARG; ctx->tile_switch_c = value; break;
         case 34: if (value < 0) return GPB_E_ARG; ctx->mid_switch_c = value; break;
         case 35: if (value < 0) return GPB_E_ARG; ctx->narrow_switch_c = value; break;
@@ -1018,9 +1061,9 @@ extern "C" int gpb_debug_tune(gpb_ctx* ctx, int key, int value) {
 // Measurement hook: enqueue ONE piece of the fit on the context's stream (0 = K(X,X) assembly, 1 = blocked Cholesky of the
 // K that is there, 2 = triangular inverse, 3 = alpha) so that bench.py and the profiling tools can time and profile the
 // pieces apart.  The factorisation state is left invalid (call gpb_gp_factor afterwards).
-extern "C" int gpb_debug_fit_piece(gpb_ctx* ctx, int piece) {
+extern "C" int gpb_profile_fit_piece(gpb_ctx* ctx, int piece) {
     if (!ctx) return GPB_E_ARG;
-    if (!ctx->have_theta) GPB_FAIL(GPB_E_STATE, "gpb_debug_fit_piece before gpb_gp_set_theta");
+    if (!ctx->have_theta) GPB_FAIL(GPB_E_STATE, "gpb_profile_fit_piece before gpb_gp_set_theta");
     GPB_HIP(hipSetDevice(ctx->device));
     ctx->factored = false;
     switch (piece) {
@@ -1032,11 +1075,7 @@ extern "C" int gpb_debug_fit_piece(gpb_ctx* ctx, int piece) {
     }
 }
 
-extern "C" int gpb_debug_force_generic_mvn(gpb_ctx* ctx, int on) {
-    if (!ctx) return GPB_E_ARG;
-    ctx->force_generic_mvn = on != 0;
-    return 0;
-}
+
 
 extern "C" int gpb_profile_enable(gpb_ctx* ctx, int on) {
     if (!ctx) return GPB_E_ARG;
@@ -1071,6 +1110,7 @@ extern "C" int gpb_profile_read(gpb_ctx* ctx, int64_t* launches, double* total_m
     return 0;
 }
 
+#ifdef GPB_DEBUG_VARIANTS
 // Debug hook: per-tile placement/timing records of k_predict (where the dispatcher put each tile, when it ran).
 // capacity > 0 arms the trace (and clears it), capacity == 0 disarms.  read copies up to max_records records of
 // 8 uint32 {HW_ID, XCC_ID, gp, row block, walker tile, t_start, t_end (100 MHz ticks), blockIdx} and re-arms.
@@ -1108,3 +1148,4 @@ extern "C" int gpb_probe_fp64(gpb_ctx* ctx, int mode, double* tflops_out) {
     GPB_HIP(hipSetDevice(ctx->device));
     return launch_probe(ctx, mode, tflops_out);
 }
+#endif  // GPB_DEBUG_VARIANTS

@@ -1403,6 +1403,7 @@ __global__ __launch_bounds__(256) void k_balance_gather(const double* __restrict
     }
 }
 
+#ifdef GPB_DEBUG_VARIANTS
 // test hooks: the generator and the draws of a (seed, step, half), for the parity tests against the oracle
 __global__ void k_philox_test(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1431,6 +1432,7 @@ __global__ void k_perm(long long* __restrict__ out, int64_t n, uint64_t seed, ui
     if (i >= n) return;
     out[i] = make_perm(seed, step, n, hb, 1)(i);
 }
+#endif  // GPB_DEBUG_VARIANTS
 
 static int half_bits(int64_t n) {
     int b = 1;
@@ -1837,6 +1839,7 @@ extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev,
     return 0;
 }
 
+#ifdef GPB_DEBUG_VARIANTS
 // Measurement hook: the kernels of ONE step of gpb_chain_emcee_run captured into a HIP graph and replayed `reps` times,
 // against `reps` plain calls of one step (both timed with HIP events on the context's stream).  The replay repeats the
 // same step index — the same draws — so it measures launch overhead, it does not sample; pos / lp are scratch copies.
@@ -1907,6 +1910,8 @@ extern "C" int gpb_debug_graph_probe(gpb_ctx* const* ctxs, int E, const double* 
     return rc;
 }
 
+#endif  // GPB_DEBUG_VARIANTS
+
 extern "C" int gpb_emcee_run(gpb_ctx* ctx, double* pos_dev, double* lp_dev, int64_t nwalkers, int64_t nsteps,
                              uint64_t seed, uint64_t step0, double a, int randomize_split, const double* lo_dev,
                              const double* hi_dev, double outside_value, double inside_const, double* chain_dev,
@@ -1919,6 +1924,7 @@ extern "C" int gpb_emcee_run(gpb_ctx* ctx, double* pos_dev, double* lp_dev, int6
                                outside_value, inside_const, chain_dev, lpchain_dev, naccept_dev);
 }
 
+#ifdef GPB_DEBUG_VARIANTS      // test hooks (include/gpbayes_debug.h)
 extern "C" int gpb_test_split_perm(gpb_ctx* ctx, int64_t n, uint64_t seed, uint64_t step, int64_t* out_dev) {
     if (!ctx || n < 2 || n > (1ll << 30) || !out_dev) return GPB_E_ARG;
     hipLaunchKernelGGL(k_perm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -1954,3 +1960,4 @@ extern "C" int gpb_test_stretch_draws(gpb_ctx* ctx, int64_t nwalkers, int half, 
     GPB_HIP(hipGetLastError());
     return 0;
 }
+#endif  // GPB_DEBUG_VARIANTS

@@ -1363,6 +1363,7 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
 }
 
 
+#ifdef GPB_DEBUG_VARIANTS      // self-test and issue-rate probes (include/gpbayes_debug.h)
 // ------------------------------------------------------------------ test hooks
 // MODE: 0 = C = A[M,K] B[K,N]; 1 = C = A[M,K] B[N,K]^T; 2 = C = A[K,M]^T B[K,N]
 template <int T, int MODE>
@@ -1508,5 +1509,7 @@ int launch_probe(gpb_ctx* ctx, int mode, double* tflops) {
     (void)hipFree(d_out);
     return 0;
 }
+
+#endif  // GPB_DEBUG_VARIANTS
 
 }  // namespace gpb

@@ -91,6 +91,50 @@ class WalkerSharding:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
         return int(t.item()) == 1
 
+    # ---- replicated state: every rank must hold THE SAME emulators and experiment -------------------------------------
+    # Walker sharding rests on it: rank r's rows are evaluated with rank r's GP state and accepted on every rank.  The
+    # device side is deterministic (fixed-order reductions), the host side of a training is not across processes: the
+    # scaler / PCA SVD of numpy rounds differently with a different number of BLAS threads (torch.distributed.run sets
+    # OMP_NUM_THREADS=1 for its ranks only), and the GP targets with it.  So the ranks do not each trust their own fit:
+    # `replicate` hands rank `src`'s fitted host state to everybody, `agree_state` proves the replicas equal before a run.
+    def replicate(self, chain, src=0):
+        """Rank `src` broadcasts the host state of the chain's emulators (what their pickles hold: scaler, PCA, design,
+        targets, theta*, transforms) and the chain's experiment block and prior box; the other ranks install it and
+        rebuild their device state from it (set_data, set_theta, factor: milliseconds).  Collective."""
+        box = [None]
+        if self.rank == src:
+            box[0] = ([e.__getstate__() for e in chain.emuList], chain.expdata, chain.expdata_cov, chain.min, chain.max)
+        self.dist.broadcast_object_list(box, src=src, group=self.group)
+        if self.rank != src:
+            states, chain.expdata, chain.expdata_cov, chain.min, chain.max = box[0]
+            if len(states) != len(chain.emuList):
+                raise RuntimeError("replicate: rank %d holds %d emulators, rank %d %d" % (src, len(states), self.rank, len(chain.emuList)))
+            for emu, st in zip(chain.emuList, states):
+                eng = getattr(emu, "_engine", None)
+                if eng is not None:
+                    eng.close()
+                st = dict(st, device=emu.device)           # (each rank keeps its own GPU)
+                emu.__setstate__(st)
+            chain.prior_volume_ = float(__import__("numpy").prod(chain.max - chain.min))
+            chain._like_sig = None
+        return chain
+
+    def agree_state(self, digest):
+        """All ranks hold the same 32-byte state digest (Chain.state_digest): MIN and MAX over the ranks of its four words
+        coincide.  Raises on EVERY rank when they do not.  Collective."""
+        import numpy as np
+        import torch
+        w = np.frombuffer(bytes(digest)[:32].ljust(32, b"\0"), dtype=np.int64).copy()
+        lo = torch.as_tensor(w, device=self._coll_device())
+        hi = lo.clone()
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN, group=self.group)
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX, group=self.group)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("the ranks' replicas of the GP state differ (hyper-parameters, targets, transforms or the "
+                               "experiment block): a sharded run would mix log-probabilities of different models.  Train on "
+                               "one rank and call WalkerSharding.replicate(chain) before sampling.")
+        return True
+
     def _drop_direct(self):
         if self.direct is not None:
             try:

@@ -380,6 +380,20 @@ class Emulator:
             self._push_transform(eng)
         return self._engine
 
+    def state_digest(self):
+        """sha256 over everything the device state is built from (design, targets, theta*, kernel, transform arrays):
+        equal digests = bit-identical replicas (the device side is deterministic)."""
+        import hashlib
+        h = hashlib.sha256()
+        h.update(repr((self.kernel_type_, self._ngp, self.nobs, float(self.alpha), int(self._mode),
+                       bool(self.parameterTrafoPCA_))).encode())
+        arrs = [self._X_train, self._Z_train, self.thetas_, self.scaler.mean_]
+        arrs += [self.scaler.scale_] if self.perform_no_PCA_ else [self._A, self._cov_trunc]
+        for a in arrs:
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            h.update(repr(a.shape).encode()); h.update(a.tobytes())
+        return h.digest()
+
     def __getstate__(self):
         st = dict(self.__dict__)
         st["_engine"] = None

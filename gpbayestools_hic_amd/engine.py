@@ -23,10 +23,12 @@ def _is_torch(x):
 
 
 class GPEngine:
-    def __init__(self, device=0, stream="torch"):
+    def __init__(self, device=0, stream="torch", debug=None):
         """stream: "torch" = enqueue on torch's current stream of `device` (one ordered queue
-        shared with torch copies and collectives), None = private stream, or a hipStream_t."""
-        self.lib = nat.load()
+        shared with torch copies and collectives), None = private stream, or a hipStream_t.
+        debug: True binds libgpbayes_debug.so (test hooks, kernel variants); None = the process default (the product library
+        unless GPB_DEBUG_LIB=1 or inside _native.debug_library())."""
+        self.lib = nat.load(debug)
         if self.lib.gpb_device_count() <= 0:
             raise nat.GPBError("no HIP device visible: the gfx950 kernels cannot run (no CPU fallback)")
         h = nat.VP()
@@ -453,13 +455,16 @@ class GPEngine:
         return Cm
 
     def force_tile(self, tile=0, switch_tiles=0):
-        """test/tuning hook: k_predict tile size (0 auto, 64, 128)."""
-        self._ck(self.lib.gpb_debug_force_tile(self.h, int(tile), int(switch_tiles)))
+        """k_predict tile: 0 = by rule, 128, 64, 32 (64 rows x 32 walkers), 65 (64 x 128) — same bits whatever the shape;
+        switch_tiles > 0: the rule's switch point to 128x128 tiles (tiles per 256 CUs)."""
+        self.tune("force_tile", int(tile))
+        if switch_tiles > 0:
+            self.tune("tile_switch", int(switch_tiles))
 
     def tune(self, key, value):
         """launch-geometry hook of the predict kernel: 'xcd', 'wgs64', 'waves', 'wgs128w8'."""
-        k = {"xcd": 0, "wgs64": 1, "waves": 2, "wgs128w8": 3, "chol_outer": 4, "resident": 5, "wgs32": 6, "narrow_switch": 7, "mvn_wg_switch": 8, "chol_inner_tile": 9, "tile_priority": 10, "fuse_finalize": 11, "trtri_tile": 12, "resident_occ": 13, "syrk_tile": 14, "wgs64x128": 16, "tri_skip": 17, "kcross_dot": 18, "kcross_chunks": 19, "kcross_wpl": 20, "static64": 21, "mid_switch": 22, "lowrank": 23, "chol_algo": 24, "chol_lookahead": 25, "sim_ranks": 26, "compact": 27, "tile_by_live": 28, "premark": 29, "fuse_accept_propose": 30, "sim_rank": 32, "tile_switch_c": 33, "mid_switch_c": 34, "narrow_switch_c": 35, "balance_shards": 36, "mma_pipe": 37, "fold_tiles": 38, "kmat_mfma": 39, "chain_batch": 40, "predict_dma": 41}[key]
-        self._ck(self.lib.gpb_debug_tune(self.h, k, int(value)))
+        k = {"xcd": 0, "wgs64": 1, "waves": 2, "wgs128w8": 3, "chol_outer": 4, "resident": 5, "wgs32": 6, "narrow_switch": 7, "mvn_wg_switch": 8, "chol_inner_tile": 9, "tile_priority": 10, "fuse_finalize": 11, "trtri_tile": 12, "resident_occ": 13, "syrk_tile": 14, "wgs64x128": 16, "tri_skip": 17, "kcross_dot": 18, "kcross_chunks": 19, "kcross_wpl": 20, "static64": 21, "mid_switch": 22, "lowrank": 23, "chol_algo": 24, "chol_lookahead": 25, "sim_ranks": 26, "compact": 27, "tile_by_live": 28, "premark": 29, "fuse_accept_propose": 30, "sim_rank": 32, "tile_switch_c": 33, "mid_switch_c": 34, "narrow_switch_c": 35, "balance_shards": 36, "mma_pipe": 37, "fold_tiles": 38, "kmat_mfma": 39, "chain_batch": 40, "predict_dma": 41, "force_tile": 42, "generic_mvn": 43, "tile_switch": 44}[key]
+        self._ck(self.lib.gpb_ctx_option(self.h, k, int(value)))
 
     @property
     def has_variants(self):
@@ -468,11 +473,11 @@ class GPEngine:
 
     def fit_piece(self, piece):
         """measurement hook: enqueue one piece of factor() alone ('kmat', 'potrf', 'trtri', 'alpha'); call factor() afterwards"""
-        self._ck(self.lib.gpb_debug_fit_piece(self.h, {"kmat": 0, "potrf": 1, "trtri": 2, "alpha": 3}[piece]))
+        self._ck(self.lib.gpb_profile_fit_piece(self.h, {"kmat": 0, "potrf": 1, "trtri": 2, "alpha": 3}[piece]))
 
     def force_generic_mvn(self, on=True):
-        """test hook: bypass the register-resident MVN fast path."""
-        self._ck(self.lib.gpb_debug_force_generic_mvn(self.h, 1 if on else 0))
+        """route the block log-likelihood through the generic Cholesky kernel (what M > 64 takes) whatever M"""
+        self.tune("generic_mvn", 1 if on else 0)
 
     def profile(self, on=True):
         self._ck(self.lib.gpb_profile_enable(self.h, 1 if on else 0))

@@ -86,6 +86,18 @@ class Chain:
         cov = np.diag(errs.flatten() ** 2)
         return vals, cov
 
+    def state_digest(self):
+        """sha256 over the emulators' state digests, the experiment block and the prior box: what the ranks of a walker-
+        sharded run must hold identically (dist.WalkerSharding.agree_state)."""
+        import hashlib
+        h = hashlib.sha256()
+        for e in self.emuList:
+            h.update(e.state_digest() if hasattr(e, "state_digest") else repr(type(e)).encode())
+        for a in (self.expdata, self.expdata_cov, self.min, self.max):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            h.update(repr(a.shape).encode()); h.update(a.tobytes())
+        return h.digest()
+
     def loadEmulator(self, emulatorPathList):
         import dill
         for path in emulatorPathList:

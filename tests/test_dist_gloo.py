@@ -261,3 +261,76 @@ def test_walker_sharding_more_ranks_and_direct_handshake(world):
                 assert "init" in calls, (name, r, calls)
     # in the good case the direct path really carried the even-split batches
     assert all("allgather" in got[r]["ok"][3] for r in range(world))
+
+
+# ---------------------------------------------------------------- replicated state: replicate + agree_state
+class _FakeEmu:
+    """the part of Emulator that WalkerSharding.replicate touches: host state through __getstate__ / __setstate__, a device
+    index of its own, an engine that is dropped when the state is replaced"""
+
+    def __init__(self, device, z):
+        self.device, self.z, self._engine, self.closed = device, np.asarray(z, float), self, 0
+
+    def close(self):
+        self.closed += 1
+
+    def __getstate__(self):
+        return {"device": self.device, "z": self.z, "_engine": None, "closed": 0}
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+
+    def state_digest(self):
+        import hashlib
+        return hashlib.sha256(self.z.tobytes()).digest()
+
+
+def _replica_worker(rank, world, port, q):
+    sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import types
+    from gpbayestools_hic_amd.dist import WalkerSharding, init_from_env
+    from gpbayestools_hic_amd.mcmc import Chain
+    init_from_env(backend="gloo")
+    sh = WalkerSharding()
+    # every rank "trained" its own replica: rank r's targets carry a rounding difference of its own (the SVD under another
+    # BLAS threading), and rank 2's experiment block differs as well
+    chain = types.SimpleNamespace(emuList=[_FakeEmu(rank, [1.0, 2.0 + 1e-16 * 4 * rank]), _FakeEmu(rank, [3.0])],
+                                  expdata=np.array([[0.5 + (rank == 2)]]), expdata_cov=np.eye(1), min=np.zeros(2),
+                                  max=np.ones(2), prior_volume_=1.0, _like_sig="stale")
+    chain.state_digest = lambda: Chain.state_digest(chain)
+    res = {"same": sh.agree_state(b"x" * 32)}
+    try:
+        sh.agree_state(chain.state_digest())
+        res["differ"] = "no error"
+    except RuntimeError as e:                   # on EVERY rank, also on those whose digest equals rank 0's
+        res["differ"] = str(e)
+    sh.replicate(chain)
+    res["after"] = sh.agree_state(chain.state_digest())
+    res["z"] = chain.emuList[0].z.copy()
+    res["dev"] = [e.device for e in chain.emuList]
+    res["exp"] = float(chain.expdata[0, 0])
+    res["closed"] = "closed" in chain.emuList[0].__dict__ and rank != 0
+    res["like_sig"] = chain._like_sig
+    dist.barrier()
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_replicas_are_rank_zeros_and_a_difference_raises_on_every_rank():
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_replica_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert got[r]["same"] is True
+        assert "replicas of the GP state differ" in got[r]["differ"], (r, got[r]["differ"])
+        assert got[r]["after"] is True
+        assert np.array_equal(got[r]["z"], got[0]["z"]) and got[r]["exp"] == 0.5          # rank 0's state everywhere ...
+        assert got[r]["dev"] == [r, r]                                                    # ... on each rank's own device
+        assert got[r]["like_sig"] == ("stale" if r == 0 else None)                        # likelihood blocks are re-installed

@@ -21,11 +21,21 @@ def eng():
     e.close()
 
 
+@pytest.fixture(scope="module")
+def deng():
+    """an engine on the debug library: the self-test GEMM, the tile trace and the measured-and-rejected kernel variants"""
+    from conftest import debug_engine
+    e = debug_engine()
+    yield e
+    e.close()
+
+
 # ---------------------------------------------------------------- MFMA tile engine
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(128, 128, 16), (256, 384, 64), (192, 130, 48), (64, 64, 64), (130, 66, 32)])
-def test_mfma_tile_gemm(eng, mode, shape):
+def test_mfma_tile_gemm(deng, mode, shape):
     """Asymmetric operands catch a transposed C/D fragment map (v_mfma_f64_16x16x4_f64)."""
+    eng = deng
     M, N, K = shape
     rng = np.random.default_rng(M * 7 + N * 3 + K + mode)
     A = rng.standard_normal((M, K)); B = rng.standard_normal((K, N))
@@ -39,7 +49,8 @@ def test_mfma_tile_gemm(eng, mode, shape):
     assert maxrel(got, ref) < 1e-13
 
 
-def test_mfma_exact_integers(eng):
+def test_mfma_exact_integers(deng):
+    eng = deng
     rng = np.random.default_rng(5)
     A = rng.integers(-8, 9, (128, 32)).astype(float); B = rng.integers(-8, 9, (32, 128)).astype(float)
     assert np.array_equal(eng.test_gemm(A, B, 0), A @ B)
@@ -311,7 +322,8 @@ def test_lowrank_logdet_does_not_overflow_for_tiny_c0(eng, c0):
 
 # ---------------------------------------------------------------- 64x64 tile variant (small walker batches / multi-GPU shards)
 @pytest.mark.parametrize("mode", [0, 1, 2])
-def test_mfma_tile_gemm_64(eng, mode):
+def test_mfma_tile_gemm_64(deng, mode):
+    eng = deng
     rng = np.random.default_rng(40 + mode)
     M, N, K = 192, 130, 48
     A = rng.standard_normal((M, K)); B = rng.standard_normal((K, N))
@@ -319,9 +331,11 @@ def test_mfma_tile_gemm_64(eng, mode):
     assert maxrel(eng.test_gemm(*args, mode, tile=64), A @ B) < 1e-13
 
 
-def test_predict_tile_sizes_are_bit_identical(eng):
+@pytest.mark.parametrize("library", ["product", "debug"])
+def test_predict_tile_sizes_are_bit_identical(request, library):
     """Both tile sizes reduce V^2 in the same tree, so the automatic switch (and hence the number of
     ranks a walker ensemble is sharded over) never changes a bit of the variance."""
+    eng = request.getfixturevalue("eng" if library == "product" else "deng")
     from gpbayestools_hic_amd import synth
     rng = np.random.default_rng(8)
     for N in (448, 512):                                  # Np = 448 (odd number of 64-blocks) and 512
@@ -332,7 +346,7 @@ def test_predict_tile_sizes_are_bit_identical(eng):
         Xs = rng.random((300, d))
         eng.force_tile(128); m1, v1 = eng.predict(Xs)
         # The product library holds the shapes its rule selects (128x128 on ticket queues; 64x128, 64x64, 64x32 as static
-        # launches in three orders, two XCD maps).  The debug build (GPB_DEBUG_LIB=1) adds the measured-and-rejected
+        # launches in three orders, two XCD maps).  The debug build (library = "debug") adds the measured-and-rejected
         # variants: 8-wave tiles, ticket queues for the 64-row tiles, two more XCD maps, folded row-block pairs.
         full = eng.has_variants
         for tile, waves in ((64, 4), (64, 8), (128, 8)) if full else ((64, 4),):
@@ -377,8 +391,9 @@ def test_predict_tile_sizes_are_bit_identical(eng):
         eng.force_tile(0)
 
 
-def test_predict_tile_trace_covers_every_tile_once(eng):
+def test_predict_tile_trace_covers_every_tile_once(deng):
     """debug hook: one record per (GP, row block, walker tile), for the static and the ticket-queue launch"""
+    eng = deng
     from gpbayestools_hic_amd import synth
     rng = np.random.default_rng(21)
     N, d, P, W = 512, 5, 3, 256
@@ -397,3 +412,24 @@ def test_predict_tile_trace_covers_every_tile_once(eng):
         assert tiles == {(p, ib, wt) for p in range(P) for ib in range(N // 64) for wt in range(W // 64)}
         assert np.all((rec[:, 6].astype(np.int64) - rec[:, 5].astype(np.int64)) % (1 << 32) < 10_000_000)   # < 0.1 s
     eng.force_tile(0); eng.tune("resident", 2)
+
+
+def test_product_and_debug_libraries_give_the_same_bits(eng, deng):
+    """libgpbayes_debug.so is libgpbayes.so's sources plus hooks and variants: on their defaults the two give identical numbers
+    (so what the hook-driven tests establish on the debug library holds for the product one)"""
+    from gpbayestools_hic_amd import synth
+    rng = np.random.default_rng(77)
+    N, d, P, W = 200, 5, 3, 150
+    X = synth.lhs(N, d, seed=9); Z = rng.standard_normal((P, N)); th = synth.fixed_theta(d, P) + 0.2 * rng.standard_normal((P, d + 2))
+    Xs = rng.random((W, d))
+    out = []
+    for e in (eng, deng):
+        e.set_data(X, Z, "Matern25", 0.1)
+        val, grad = e.lml(th)
+        e.set_theta(th); e.factor()
+        out.append((val, grad, e.get("L"), e.get("alpha")) + tuple(e.predict(Xs)))
+    import os
+    if os.environ.get("GPB_DEBUG_LIB") != "1":             # (under GPB_DEBUG_LIB=1 the default engine is the debug library's too)
+        assert eng.lib is not deng.lib and deng.has_variants and not eng.has_variants
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)

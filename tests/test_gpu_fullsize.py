@@ -96,8 +96,8 @@ def test_fullsize_log_posterior_cfg4_against_oracle_sample():
     assert np.max(np.abs(got[ins] - ref[ins]) / np.abs(ref[ins])) < 1e-10
 
 
-@pytest.mark.parametrize("N", [1024, 2048])
-def test_cholesky_schedules_agree(N):
+@pytest.mark.parametrize("N,library", [(1024, "product"), (2048, "product"), (1024, "debug")])
+def test_cholesky_schedules_agree(N, library):
     """the blocked Cholesky's schedules — two launches per step with the next diagonal block fused into the update
     (default), with and without the lookahead side stream, and round 1's three-launch form — give the same factor bit
     for bit at equal outer panel width (the side stream only touches tiles nobody else touches at that time; the pivot
@@ -106,7 +106,11 @@ def test_cholesky_schedules_agree(N):
     from gpbayestools_hic_amd import GPEngine
     from oracle import gp_oracle as O
     P, d = 3, 12
-    eng = GPEngine(0)
+    if library == "debug":
+        from conftest import debug_engine
+        eng = debug_engine()
+    else:
+        eng = GPEngine(0)
     X, Z, th = _setup(eng, N, d, P, "RBF", seed=3 * N)
     auto_L, auto_X = eng.get("L"), eng.get("Linv")            # the default: panel width chosen by size
     eng.tune("chol_outer", 512)
@@ -116,7 +120,7 @@ def test_cholesky_schedules_agree(N):
     assert np.max(np.abs(auto_X - ref_X)) < 1e-11 * np.max(np.abs(ref_X))
     for algo, outer, look in ((1, 512, 1), (1, 512, 0), (0, 512, 0), (1, 512, 1), (1, 256, 1), (1, 256, 0), (1, 128, 1),
                               (1, 0, 1)):
-        if algo == 0 and not eng.has_variants:             # round 1's three-launch schedule: debug build (GPB_DEBUG_LIB=1)
+        if algo == 0 and not eng.has_variants:             # round 1's three-launch schedule: debug build (library = "debug")
             continue
         eng.tune("chol_algo", algo); eng.tune("chol_outer", outer); eng.tune("chol_lookahead", look)
         eng.factor()

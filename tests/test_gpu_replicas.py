@@ -1,0 +1,78 @@
+"""GPU tier: the replicas of a walker-sharded run.  Two ranks share cuda:0 and rendezvous over gloo (one GPU per box).  Rank 1
+"trains" on observables that differ from rank 0's in the last bits (what numpy's scaler / PCA SVD does under another BLAS
+threading): StretchSampler.run refuses to start — on BOTH ranks — until WalkerSharding.replicate has handed rank 0's fitted
+state to rank 1, and then both hold the single-process ensemble bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _build(workdir, perturb):
+    from gpbayestools_hic_amd import synth
+    from gpbayestools_hic_amd.workload import build_chain
+    chain, emu, info = build_chain(1, workdir=workdir)
+    if perturb:                                        # a replica whose targets differ in the last bits
+        emu.model_data = emu.model_data * (1.0 + 4e-16)
+        emu.trainEmulator([True] * emu.nev, kernel_type=info["kernel_type"], thetas=synth.fixed_theta(info["d"], info["P"]))
+    return chain, emu, info
+
+
+def _run(chain, info, sharding):
+    from gpbayestools_hic_amd import StretchSampler, synth
+    s = StretchSampler(chain, 64, seed=21, sharding=sharding)
+    s.run(synth.walkers(64, info["d"], seed=4), 5)
+    return s.chain, s.lnprobability
+
+
+def _worker(rank, world, port, workdir, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from gpbayestools_hic_amd.dist import WalkerSharding, init_from_env
+    init_from_env(backend="gloo")
+    d = os.path.join(workdir, f"r{rank}"); os.makedirs(d, exist_ok=True)
+    chain, emu, info = _build(d, perturb=(rank == 1))
+    sh = WalkerSharding()
+    digest0 = chain.state_digest()
+    try:
+        _run(chain, info, sh)
+        refused = "ran"
+    except RuntimeError as e:
+        refused = str(e)
+    sh.replicate(chain)
+    out = _run(chain, info, sh)
+    dist.barrier()
+    q.put((rank, refused, digest0, chain.state_digest(), out))
+    dist.destroy_process_group()
+
+
+def test_ranks_refuse_differing_replicas_and_agree_after_replicate(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs: p.start()
+    got = {r[0]: r[1:] for r in (q.get(timeout=600) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    one = tmp_path / "single"; one.mkdir()
+    chain, emu, info = _build(str(one), perturb=False)
+    ref = _run(chain, info, None)
+    assert got[0][1] != got[1][1]                                   # the trainings really differed ...
+    for r in range(world):
+        assert "replicas of the GP state differ" in got[r][0], got[r][0]     # ... and BOTH ranks refused to sample
+        assert got[r][2] == chain.state_digest()                   # after replicate: rank 0's state = the single process's
+        assert np.array_equal(got[r][3][0], ref[0]) and np.array_equal(got[r][3][1], ref[1]), r

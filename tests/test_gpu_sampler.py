@@ -139,8 +139,9 @@ def test_log_posterior_is_batch_independent(tmp_path):
 
 def test_split_permutation_is_a_bijection_and_changes_per_step():
     import torch
-    from gpbayestools_hic_amd import GPEngine, _native as nat
-    eng = GPEngine(0)
+    from conftest import debug_engine
+    from gpbayestools_hic_amd import _native as nat
+    eng = debug_engine()                                           # gpb_test_split_perm: a hook of the debug library
     for n in (2, 6, 64, 100, 4096, 5000):
         outs = []
         for step in (0, 1, 2):
@@ -225,12 +226,28 @@ def test_resident_loop_with_a_one_rank_communicator(tmp_path):
             s2.run(None, 2)
         assert votes == [True] and torch.equal(s2.pos, before)
     eng.dist_finalize()
-    # the measurement hook: one rank's share of a 4-way split (rows it does not evaluate are rejected)
+
+
+def test_one_ranks_share_measurement_hook(tmp_path, debug_lib):
+    """the measurement hook of the debug library (option keys 26 / 32): one rank's share of a 4-way split on a single GPU (the
+    rows it does not evaluate are rejected); the product library refuses the key"""
+    from gpbayestools_hic_amd import GPEngine, StretchSampler, synth
+    from gpbayestools_hic_amd._native import GPBError
+    from gpbayestools_hic_amd.workload import build_chain
+    chain, emu, info = build_chain(1, workdir=str(tmp_path))
+    eng = emu._engine_ready()
+    assert eng.has_variants
+    nw = 32
+    X0 = synth.walkers(nw, info["d"], seed=22)
     eng.tune("sim_ranks", 4)
     m = StretchSampler(chain, nw, seed=9)
     m.run(X0, 4)
     eng.tune("sim_ranks", 0)
     assert m.chain.shape == (nw, 4, info["d"]) and np.all(np.isfinite(m.chain))
+    product = GPEngine(0, debug=False)
+    with pytest.raises(GPBError, match="debug build"):
+        product.tune("sim_ranks", 4)
+    product.close()
 
 
 def test_nan_log_probability_raises_like_emcee(tmp_path):
@@ -318,7 +335,7 @@ def test_box_test_in_the_proposal_kernel_equals_the_marking_kernel(tmp_path):
 
 
 @pytest.mark.parametrize("fuse,balance", [(1, 1), (0, 1), (1, 0), (0, 0)])
-def test_every_ranks_share_of_the_c_loop_equals_the_host_loop_on_those_rows(tmp_path, fuse, balance):
+def test_every_ranks_share_of_the_c_loop_equals_the_host_loop_on_those_rows(tmp_path, fuse, balance, debug_lib):
     """the sharded C loop evaluates one rank's share of every batch — balanced: the r-th of R equal slices of the ordered
     list of ALL rows inside the box (k_balance_gather; the accept kernels find a row's value through its rank in that
     list); contiguous: the rows inside the box of proposals [r chunk, (r + 1) chunk).  Played for every rank r of 3 on one
@@ -378,7 +395,7 @@ def test_every_ranks_share_of_the_c_loop_equals_the_host_loop_on_those_rows(tmp_
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("balance", [0, 2])
 @pytest.mark.parametrize("R", [2, 4, 8])
-def test_sharded_c_loop_with_R_ranks_in_one_process(tmp_path, R, balance):
+def test_sharded_c_loop_with_R_ranks_in_one_process(tmp_path, R, balance, debug_lib):
     """The R > 1 form of gpb_chain_emcee_run as a whole: R contexts (own streams, own host threads) joined by the loopback
     communicator of gpb_debug_loopback_group — per-rank row shares, in-stream all-gathers, accept steps fed by the other
     ranks' log-probabilities.  RCCL refuses two ranks on one device, so this is what a one-GPU box can run of it: everything
@@ -443,7 +460,7 @@ def _loopback_ranks_reproduce_the_unsharded_run(built, nw, nsteps, X0, balance=0
 
 
 @pytest.mark.timeout(300)
-def test_sharded_c_loop_when_the_gps_differ_in_their_distance_form(tmp_path):
+def test_sharded_c_loop_when_the_gps_differ_in_their_distance_form(tmp_path, debug_lib):
     """The distance form of a GP's kernel matrices is chosen from theta alone (Gram form, or sklearn's difference form when a
     length scale is far below the design's extent: gpbayes.h GPB_GET_FORM): with one GP of the emulator on either side of the
     rule — two cross-kernel launches per batch — two loopback ranks still end on the unsharded ensemble bit for bit, and the
@@ -474,7 +491,7 @@ def test_sharded_c_loop_when_the_gps_differ_in_their_distance_form(tmp_path):
 
 
 @pytest.mark.timeout(300)
-def test_sharded_c_loop_over_a_chain_of_emulators(tmp_path):
+def test_sharded_c_loop_over_a_chain_of_emulators(tmp_path, debug_lib):
     """... and the same for a chain of three emulators (mixed kernels, batched cross / predict / likelihood launches) on two
     and three loopback ranks: the first emulator's context carries the communicator, every rank ends on the unsharded ensemble."""
     import ctypes
@@ -525,7 +542,7 @@ def test_sharded_c_loop_over_a_chain_of_emulators(tmp_path):
             assert lib.gpb_debug_loopback_release(firsts[0].h) == 0
 
 
-def test_loopback_group_survives_a_member_being_destroyed():
+def test_loopback_group_survives_a_member_being_destroyed(debug_lib):
     """test hook hygiene: a context that is destroyed without a release of its loopback group leaves the group; the group goes
     with its last member or with an explicit release"""
     import ctypes

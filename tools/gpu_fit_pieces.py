@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the pieces of gpb_gp_factor apart (gpb_debug_fit_piece: K build, Cholesky, triangular inverse, alpha) at the design
+"""Time the pieces of gpb_gp_factor apart (gpb_profile_fit_piece: K build, Cholesky, triangular inverse, alpha) at the design
 sizes of BASELINE configs 2, 4 and 5, 10 GPs, with A/B over the K-build kernel (tune kmat_mfma) and the Cholesky schedule
 (tune chol_algo).    python tools/gpu_fit_pieces.py [N ...]"""
 import json

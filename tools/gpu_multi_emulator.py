@@ -11,6 +11,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPB_DEBUG_LIB", "1")      # measurement hooks and kernel variants: the debug library (libgpbayes_debug.so)
 from gpbayestools_hic_amd import StretchSampler, synth  # noqa: E402
 from gpbayestools_hic_amd.workload import build_multi_chain  # noqa: E402
 
