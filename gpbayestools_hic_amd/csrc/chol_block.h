@@ -8,8 +8,12 @@
 
 namespace gpb {
 
-constexpr int LDP = 66;            // row stride (doubles) of a 64x64 block in LDS: 132 dwords = 4 (mod 64) banks, so the
-                                   // 16 rows x 2 k-columns a half-wave reads for an MFMA fragment hit 32 distinct slots
+constexpr int LDP = 65;            // row stride (doubles) of a 64x64 block in LDS.  The MFMA fragment reads of mma_nt_64 — lane (lr, lk)
+                                   // reads [row lr][k + lk] — are merged by the compiler into ds_read2_b64 (two k-steps per instruction),
+                                   // which the LDS serves in 16-lane groups with banks (a / 4) mod 32: sixteen rows at 130 dwords
+                                   // = 2 (mod 32) apart are conflict-free; at 66 (132 = 4 mod 32) rows r and r + 8 met on a bank:
+                                   // SQ_LDS_BANK_CONFLICT was 43 % of the step kernels' LDS cycles (profiles/r04_fit_pmc.json).
+                                   // Rows are 8-byte aligned only: tiles are stored with ds_write_b64 (load_tile)
 constexpr int CHOL_THREADS = 512;  // 8 waves: two per SIMD, what it takes to keep the f64 MFMA pipe issuing back to back
 
 struct CholLds {
@@ -18,7 +22,7 @@ struct CholLds {
     double tm[32][34];             // scratch of the inverse assembly (one 32x32 block)
     double rdg[64];                // reciprocals of the pivots
     int bad;                       // first non-positive pivot of this block (-1: none)
-};                                 // 76,556 bytes: two workgroups per CU
+};                                 // 75,532 bytes: two workgroups per CU
 
 // Broadcast lane K of every ROW of 16 lanes to the 16 lanes of that row: one v_mov_b64_dpp row_newbcast:K (the only DPP
 // control the 64-bit ALU takes on gfx90a+).  No SGPR round trip as with v_readlane (two per double, plus the
@@ -67,13 +71,22 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
     return fma(y * e, fma(e, 0.375, 0.5), y);
 }
 
-// row-major global tile G[r*ld + c] (64x64) -> S[r][c]; 512 threads, 16-byte loads (ld and the tile origin are even)
+// row-major global tile G[r*ld + c] (64x64) -> S[r][c]; 512 threads, 16-byte loads (ld and the tile origin are even), 8-byte
+// LDS stores (odd rows of S start on an odd double)
 __device__ __forceinline__ void load_tile(const double* __restrict__ G, int64_t ld, double (*S)[LDP], int tid) {
+    d2 v[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int idx = tid + CHOL_THREADS * e;          // 2048 pairs
         const int r = idx >> 5, c = (idx & 31) * 2;
-        *reinterpret_cast<d2*>(&S[r][c]) = *reinterpret_cast<const d2*>(G + (int64_t)r * ld + c);
+        v[e] = *reinterpret_cast<const d2*>(G + (int64_t)r * ld + c);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int idx = tid + CHOL_THREADS * e;
+        const int r = idx >> 5, c = (idx & 31) * 2;
+        S[r][c] = v[e].x;
+        S[r][c + 1] = v[e].y;
     }
 }
 

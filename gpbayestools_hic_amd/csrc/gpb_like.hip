@@ -1708,7 +1708,7 @@ int emcee_plan(gpb_ctx* const* ctxs, int E, int64_t nwalkers, EmceePlan& pl) {
     // Worth its extra launch (k_balance_gather + the rank look-ups of the accept step: +11 us per half-step, measured) only
     // where the ranks' live counts straddle a walker-tile boundary often: 256 proposals per rank hold 120 +- 8 live rows, so
     // at 8 ranks three half-steps in four have a rank with a fifth 64x32 tile (+23 us, measured per tile); at 2 and 4 ranks
-    // the contiguous shares rarely differ by a tile.  1 = from 8 ranks on (default), 2 = always, 0 = never.
+    // the contiguous shares rarely differ by a tile.  0 = never (default), 1 = from 8 ranks on, 2 = always.
     pl.balanced = pl.pre == 2 && R > 1 && nh <= 16384 &&
                   (ctx->balance_shards == 2 || (ctx->balance_shards == 1 && R >= 8));
     if (pl.balanced) {

@@ -1008,6 +1008,9 @@ static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int
         cpw = 1;
         while (cpw < 8 && wgs1 / (2 * cpw) >= 4 * (int64_t)ctx->num_cu) cpw *= 2;
     }
+    // (grid.z, the walker tile, is limited to 65535: 4.19 M rows a call at one walker per lane; the host classes send long
+    // inputs through in slabs of 131072 rows)
+    if (Wuse / (64 * wpl) > 65535) GPB_FAIL(GPB_E_ARG, "gpb: more than 65535 walker tiles (4 million rows) in one batch: split it");
     dim3 grid((unsigned)((nchunk + cpw - 1) / cpw), (unsigned)ctx->P, (unsigned)(Wuse / (64 * wpl)));
     // two instantiations, one per distance form; each launch computes the GPs of its form (ctx->gpform, chosen from theta:
     // choose_forms) and is left out when no GP has it — the usual case is the Gram launch alone, with no form table to read
@@ -1052,9 +1055,11 @@ int launch_kcross(gpb_ctx* ctx, const double* Xs_dev, int64_t W, const int* nrow
     // 32 KB apart and k_predict_static ran 13 % slower (117 -> 133 us), k_kcross 24 % (20 -> 25 us)
     ctx->Wld = Wuse;
     ctx->last_W = W;
-    if (ctx->kind == GPB_KERNEL_RBF) launch_kcross_kind<GPB_KERNEL_RBF>(ctx, Xs_dev, W, Wuse, nrows_dev);
-    else if (ctx->kind == GPB_KERNEL_MATERN15) launch_kcross_kind<GPB_KERNEL_MATERN15>(ctx, Xs_dev, W, Wuse, nrows_dev);
-    else launch_kcross_kind<GPB_KERNEL_MATERN25>(ctx, Xs_dev, W, Wuse, nrows_dev);
+    int rc;
+    if (ctx->kind == GPB_KERNEL_RBF) rc = launch_kcross_kind<GPB_KERNEL_RBF>(ctx, Xs_dev, W, Wuse, nrows_dev);
+    else if (ctx->kind == GPB_KERNEL_MATERN15) rc = launch_kcross_kind<GPB_KERNEL_MATERN15>(ctx, Xs_dev, W, Wuse, nrows_dev);
+    else rc = launch_kcross_kind<GPB_KERNEL_MATERN25>(ctx, Xs_dev, W, Wuse, nrows_dev);
+    if (rc) return rc;
     GPB_HIP(hipGetLastError());
     return 0;
 }
@@ -1100,6 +1105,7 @@ int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, in
         cpw = 1;
         while (cpw < 8 && wgs1 / (2 * cpw) >= 4 * (int64_t)ctx->num_cu) cpw *= 2;
     }
+    if (Wuse / (64 * wpl) > 65535) GPB_FAIL(GPB_E_ARG, "gpb: more than 65535 walker tiles (4 million rows) in one batch: split it");
     dim3 grid((unsigned)((nchunk + cpw - 1) / cpw), (unsigned)G, (unsigned)(Wuse / (64 * wpl)));
 #define GPB_KXM(DP)                                                                                              \
     do {                                                                                                         \

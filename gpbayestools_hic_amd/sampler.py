@@ -203,10 +203,17 @@ class StretchSampler:
                 # status block (one synchronisation): on a NaN the sampler goes back to the state in front of the block
                 bad = self._nan_count(ceng)
                 if bad:
+                    # back to the state in front of the offending status block; the blocks of this call before it stand: their
+                    # samples are kept, so that chain / lnprobability, `iterations` and the acceptance counts all describe
+                    # the same n - m steps (emcee, which checks every step, stops AT the offending step with everything
+                    # before it stored: the difference is the block's granularity, `status`)
                     self._restore(snap)
+                    if store and n - m > 0:
+                        self._chain_dev = cd[:n - m].clone() if self._chain_dev is None else torch.cat([self._chain_dev, cd[:n - m]], 0)
+                        self._lp_dev = ld[:n - m].clone() if self._lp_dev is None else torch.cat([self._lp_dev, ld[:n - m]], 0)
                     raise ValueError("Probability function returned NaN (%d proposal(s) within steps %d..%d of this run; "
-                                     "the sampler is back at its state before step %d and nothing of this call was stored)"
-                                     % (bad, n - m + 1, n, n - m + 1))
+                                     "the sampler is back at its state before step %d: the %d step(s) of this call before it "
+                                     "are kept, stored and counted)" % (bad, n - m + 1, n, n - m + 1, n - m))
                 af = self.acceptance_fraction
                 log.info("step %d: acceptance fraction: mean %.4f, std %.4f, min %.4f, max %.4f",
                          n, af.mean(), af.std(), af.min(), af.max())

@@ -269,7 +269,7 @@ GPB_API int gpb_dist_finalize(gpb_ctx* ctx);
  *   23 low-rank form of the block log-likelihood when it applies; 25 Cholesky lookahead on a side stream; 27 evaluate only the
  *   rows inside the prior box; 28 size the tile rule of a compacted batch by its live rows; 29 / 30 fusions of the resident
  *   step loop (box test and gather in the proposal kernel; accept + next proposal in one launch); 36 balanced row shares of a
- *   sharded step loop (0 off, 1 from 8 ranks on, 2 always); 40 the emulators of a chain share one launch per kernel kind;
+ *   sharded step loop (0 off: default, 1 from 8 ranks on, 2 always); 40 the emulators of a chain share one launch per kernel kind;
  *   42 force the predict tile (0: by rule; 128, 64, 32 = 64 rows x 32 walkers, 65 = 64 x 128: every shape gives the same bits);
  *   43 route the block log-likelihood through the generic LDS / HBM Cholesky kernel (what M > 64 takes) whatever M;
  *   44 the number of 128x128 predict tiles per 256 CUs from which the rule takes them (0: default 960).

@@ -293,6 +293,35 @@ def test_nan_log_probability_raises_like_emcee(tmp_path):
         s3.run(X0, 2)
 
 
+def test_nan_in_a_later_status_block_keeps_the_blocks_before_it():
+    """a NaN in the third status block of a call: the sampler goes back in front of THAT block; the two blocks before it stay —
+    stored samples, step count and acceptance counts describe the same four steps, and the run can be continued"""
+    from gpbayestools_hic_amd import StretchSampler
+    d, nw = 3, 16
+    fake = types.SimpleNamespace(ndim=d, device=0, min=np.full(d, -9.0), max=np.full(d, 9.0), emuList=[])
+    calls = {"n": 0, "poison": True}
+
+    def logprob(X, out):
+        calls["n"] += 1
+        out.copy_(-0.5 * (X * X).sum(1))
+        if calls["poison"] and calls["n"] == 1 + 2 * 4 + 2:      # initial call + two half-steps per step: inside step 5
+            out[0] = float("nan")
+        return out
+
+    X0 = np.random.default_rng(2).normal(size=(nw, d))
+    s = StretchSampler(fake, nw, seed=5, logprob_device=logprob)
+    with pytest.raises(ValueError, match="4 step"):
+        s.run(X0, 8, status=2)
+    assert s.iterations == 4 and s.chain.shape == (nw, 4, d) and s.lnprobability.shape == (nw, 4)
+    assert np.array_equal(s.chain[:, -1], s.pos.cpu().numpy()) and np.array_equal(s.lnprobability[:, -1], s.lp.cpu().numpy())
+    ref = StretchSampler(fake, nw, seed=5, logprob_device=lambda X, out: out.copy_(-0.5 * (X * X).sum(1)))
+    ref.run(X0, 8, status=2)
+    assert np.array_equal(s.chain, ref.chain[:, :4])
+    calls["poison"] = False
+    s.run(None, 4, status=2)                                      # carries on: the whole chain equals the clean run's
+    assert np.array_equal(s.chain, ref.chain) and np.array_equal(s.naccept.cpu().numpy(), ref.naccept.cpu().numpy())
+
+
 def test_box_test_in_the_proposal_kernel_equals_the_marking_kernel(tmp_path):
     """the C-driven loop's proposal kernel takes the prior-box test itself and gathers the rows inside the box (slots
     from a counter, in whatever order the walkers arrive), or leaves 0/1 flags for the gather kernel to rank (several
