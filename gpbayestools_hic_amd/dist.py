@@ -135,6 +135,27 @@ class WalkerSharding:
                                "one rank and call WalkerSharding.replicate(chain) before sampling.")
         return True
 
+    def rows_agree_begin(self, X_dev):
+        """start the check that every rank was handed the same batch: a position-weighted 64-bit checksum of the rows' bits,
+        ONE max-all-reduce of (c, -c) enqueued behind it (asynchronous with nccl); rows_agree_end reads the outcome"""
+        import torch
+        v = X_dev.contiguous().view(torch.int64).reshape(-1)
+        key = (v.numel(), v.device)
+        if getattr(self, "_cs_key", None) != key:
+            self._cs_w = torch.arange(v.numel(), dtype=torch.int64, device=v.device) * 2 + 1
+            self._cs_key = key
+        c = (v * self._cs_w).sum() + v.numel()
+        t = torch.stack([c, -c]).to(self._coll_device())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return t
+
+    def rows_agree_end(self, t):
+        """raises — on every rank — unless max(c) == min(c) over the ranks (synchronises on the two words)"""
+        hi, neg_lo = (int(x) for x in t.cpu())
+        if hi != -neg_lo:
+            raise RuntimeError("the ranks of a sharded log-probability call were handed different rows: the sampler above it "
+                               "must run replicated (same seed, same inputs on every rank)")
+
     def _drop_direct(self):
         if self.direct is not None:
             try:

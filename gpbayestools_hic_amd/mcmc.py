@@ -67,13 +67,32 @@ class Chain:
         self.chain = False
         self.device = device
         self._like_sig = None
+        self.sharding = None                     # dist.WalkerSharding: see shard_over
 
     def __getstate__(self):                      # no device handles in pickles / forked workers
         st = dict(self.__dict__)
         st.pop("_box_dev", None)
         st.pop("_box_key", None)
         st["_like_sig"] = None
+        st["sharding"] = None
+        st.pop("_agreed_sig", None)
         return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self.__dict__.setdefault("sharding", None)
+
+    def shard_over(self, sharding):
+        """Evaluate every log_posterior / log_likelihood batch in row shares over the ranks of `sharding`
+        (dist.WalkerSharding; one process per GPU): rank r takes rows [r chunk, (r + 1) chunk) of the batch, one
+        all-gather of the shares completes the vector on every rank.  This is the multi-GPU form of the call pocoMC makes —
+        log_likelihood(X[n_active, ndim], finite=True) once per batch, src/mcmc.py:798-805 — with the sampler itself
+        replicated: EVERY rank must make the same calls with the same rows (checked: a batch whose rows differ between the
+        ranks raises on all of them), and all ranks must hold the same emulators (WalkerSharding.replicate; checked once per
+        set of device contexts).  A row's value does not depend on the split.  `None` switches it off."""
+        self.sharding = sharding
+        self._agreed_sig = None
+        return self
 
     # ------------------------------------------------------------------ inputs
     def _read_in_exp_data_pickle(self, filepath):
@@ -241,13 +260,29 @@ class Chain:
             # P x N x rows doubles per emulator; a row's result does not depend on how the batch is cut
             per_row = max(8 * e._ngp * e._X_train.shape[0] for e in self.emuList)
             slab = int(min(max((8 << 30) // per_row, 1024), 1 << 17)) // 128 * 128
+            sh = self.sharding if (self.sharding is not None and getattr(self.sharding, "world", 1) > 1) else None
+            if sh is not None:                   # all ranks hold the same model: once per set of device contexts
+                sig = tuple(id(getattr(e, "_engine", None)) for e in self.emuList)
+                if sig != getattr(self, "_agreed_sig", None):
+                    sh.agree_state(self.state_digest())
+                    self._agreed_sig = sig
+
+            def evaluate(Xd):
+                if sh is None:
+                    return self.log_prob_device(Xd, outside=outside)
+                # ... and were handed the same rows: a checksum's all-reduce rides in front of the batch, read after it
+                pending = sh.rows_agree_begin(Xd)
+                out = torch.empty(Xd.shape[0], dtype=torch.float64, device=Xd.device)
+                sh.logprob(lambda Xr, o: self.log_prob_device(Xr, out=o, outside=outside), Xd, out)
+                sh.rows_agree_end(pending)
+                return out
             if X.shape[0] <= slab:
                 Xd = torch.as_tensor(np.ascontiguousarray(X), device=dev)
-                return self.log_prob_device(Xd, outside=outside).cpu().numpy()
+                return evaluate(Xd).cpu().numpy()
             out = np.empty(X.shape[0])
             for i0 in range(0, X.shape[0], slab):
                 Xd = torch.as_tensor(np.ascontiguousarray(X[i0:i0 + slab]), device=dev)
-                out[i0:i0 + slab] = self.log_prob_device(Xd, outside=outside).cpu().numpy()
+                out[i0:i0 + slab] = evaluate(Xd).cpu().numpy()
             return out
         # generic path: foreign emulators predict on the host, the MVN runs on the device
         lp = np.zeros(X.shape[0])

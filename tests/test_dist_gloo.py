@@ -305,6 +305,16 @@ def _replica_worker(rank, world, port, q):
         res["differ"] = "no error"
     except RuntimeError as e:                   # on EVERY rank, also on those whose digest equals rank 0's
         res["differ"] = str(e)
+    # the rows of a sharded batch: one all-reduce of a position-weighted checksum, every rank raises when they differ
+    Xsame = torch.arange(60, dtype=torch.float64).reshape(12, 5) * 0.37
+    sh.rows_agree_end(sh.rows_agree_begin(Xsame))
+    res["rows"] = []
+    for Xr in (Xsame + (1e-12 if rank == 1 else 0.0), Xsame.flip(0) if rank == 2 else Xsame):     # a changed bit; swapped rows
+        try:
+            sh.rows_agree_end(sh.rows_agree_begin(Xr.contiguous()))
+            res["rows"].append("no error")
+        except RuntimeError as e:
+            res["rows"].append(str(e))
     sh.replicate(chain)
     res["after"] = sh.agree_state(chain.state_digest())
     res["z"] = chain.emuList[0].z.copy()
@@ -331,6 +341,7 @@ def test_replicas_are_rank_zeros_and_a_difference_raises_on_every_rank():
         assert got[r]["same"] is True
         assert "replicas of the GP state differ" in got[r]["differ"], (r, got[r]["differ"])
         assert got[r]["after"] is True
+        assert len(got[r]["rows"]) == 2 and all("different rows" in m for m in got[r]["rows"]), got[r]["rows"]
         assert np.array_equal(got[r]["z"], got[0]["z"]) and got[r]["exp"] == 0.5          # rank 0's state everywhere ...
         assert got[r]["dev"] == [r, r]                                                    # ... on each rank's own device
         assert got[r]["like_sig"] == ("stale" if r == 0 else None)                        # likelihood blocks are re-installed

@@ -53,8 +53,21 @@ def _worker(rank, world, port, workdir, q):
         refused = str(e)
     sh.replicate(chain)
     out = _run(chain, info, sh)
+    # the pocoMC call shape, sharded: log_likelihood(X, finite=True) batches in row shares over the ranks (Chain.shard_over)
+    import numpy as np
+    from gpbayestools_hic_amd import synth
+    Xb = synth.walkers(301, info["d"], seed=8)
+    Xb[::7, 1] = 1.25                                               # rows outside the box
+    chain.shard_over(sh)
+    ll = (chain.log_likelihood(Xb, finite=True), chain.log_posterior(Xb[:64]), chain.log_likelihood(Xb[:1], finite=True))
+    try:
+        chain.log_likelihood(Xb + (1e-9 if rank == 1 else 0.0), finite=True)
+        differ = "ran"
+    except RuntimeError as e:
+        differ = str(e)
+    chain.shard_over(None)
     dist.barrier()
-    q.put((rank, refused, digest0, chain.state_digest(), out))
+    q.put((rank, refused, digest0, chain.state_digest(), out, ll, differ))
     dist.destroy_process_group()
 
 
@@ -76,3 +89,12 @@ def test_ranks_refuse_differing_replicas_and_agree_after_replicate(tmp_path):
         assert "replicas of the GP state differ" in got[r][0], got[r][0]     # ... and BOTH ranks refused to sample
         assert got[r][2] == chain.state_digest()                   # after replicate: rank 0's state = the single process's
         assert np.array_equal(got[r][3][0], ref[0]) and np.array_equal(got[r][3][1], ref[1]), r
+    from gpbayestools_hic_amd import synth
+    Xb = synth.walkers(301, info["d"], seed=8)
+    Xb[::7, 1] = 1.25
+    want = (chain.log_likelihood(Xb, finite=True), chain.log_posterior(Xb[:64]), chain.log_likelihood(Xb[:1], finite=True))
+    assert np.all(want[0][::7] == -1e300) and np.all(np.isfinite(want[0]))
+    for r in range(world):
+        for a, b in zip(got[r][4], want):
+            assert np.array_equal(a, b), r                          # sharded batches = the single process's, bit for bit
+        assert "different rows" in got[r][5], got[r][5]             # and both ranks refuse a batch that differs between them
