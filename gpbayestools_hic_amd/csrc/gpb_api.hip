@@ -1049,6 +1049,23 @@ extern "C" int gpb_ctx_option(gpb_ctx* ctx, int key, int value) {
             ctx->force_tile = value;
             break;
         case 43: if (value < 0 || value > 1) return GPB_E_ARG; ctx->force_generic_mvn = value != 0; break;
+#ifdef GPB_DEBUG_VARIANTS
+        case 46: {      // fusion probe (see predict_tile): arms the trace buffer with the probe's sentinel, counters per walker tile
+            if (value < 0 || value > 2) return GPB_E_ARG;      // 1: release + ticket per tile only; 2: and the last tile's tail
+            GPB_HIP(hipSetDevice(ctx->device));
+            GPB_HIP(hipStreamSynchronize(ctx->stream));
+            if (ctx->tile_trace) { (void)hipFree(ctx->tile_trace); ctx->tile_trace = nullptr; }
+            if (value >= 1) {
+                if (ctx->N == 0) GPB_FAIL(GPB_E_STATE, "gpb_ctx_option 46 before gpb_gp_set");
+                const size_t n = 16 + 65536;
+                GPB_HIP(hipMalloc(&ctx->tile_trace, n * sizeof(unsigned)));
+                GPB_HIP(hipMemset(ctx->tile_trace, 0, n * sizeof(unsigned)));
+                const unsigned head[5] = {0u, 0xffffffffu, (unsigned)(ctx->P * (ctx->Np / 64)), 0u, (unsigned)value};
+                GPB_HIP(hipMemcpy(ctx->tile_trace, head, sizeof(head), hipMemcpyHostToDevice));
+            }
+            break;
+        }
+#endif
         case 44: if (value < 0) return GPB_E_ARG; ctx->tile_switch = value > 0 ? value : 960; break;
         case 33: if (value < 0) return GPB_E_ARG; ctx->tile_switch_c = value; break;
         case 34: if (value < 0) return GPB_E_ARG; ctx->mid_switch_c = value; break;

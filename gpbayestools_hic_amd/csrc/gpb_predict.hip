@@ -370,6 +370,36 @@ __device__ __forceinline__ void predict_tile(TileLds<T, TN, KB>& lds, int p, int
     } else {                                    // the two wave rows are the halves of one 64-row block
         if (tid < TN) spart[((int64_t)ib * P + p) * Wld + nb + tid] = red[tid] + red[TN + tid];
     }
+#ifdef GPB_DEBUG_VARIANTS
+    if (trace && trace[1] == 0xffffffffu) {
+        // Fusion probe (option key 46, debug build): what folding the block likelihood into this kernel's tail would ADD to it —
+        // every tile releases its partial sums (agent-scope fence) and takes a ticket of its walker tile; the last tile of a
+        // walker tile acquires, reads every partial of its TN walkers (the likelihood's fixed-order sums: nI x P values of
+        // spart and as many of mpart, stood in for by a second pass over spart) and runs a dependent chain as long as the
+        // P x P factorisation of one walker.  Results of the launch are unchanged; profiles/r04_fusion_probe.txt.
+        __shared__ int last_of_walker_tile;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // (a full __threadfence() here — release AND acquire, i.e. an
+        __syncthreads();                                        // L2 invalidate per tile — cost +190 us at 256 rows)
+        if (tid == 0) last_of_walker_tile = atomicAdd(&trace[16 + wt], 1u) == trace[2] - 1u;
+        __syncthreads();
+        if (last_of_walker_tile && trace[4] == 1u) {            // (option value 1: release + ticket only)
+            if (tid == 0) trace[16 + wt] = 0u;
+        } else if (last_of_walker_tile) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            double s = 0.0;
+            const int64_t nblk = Np / 64;
+            for (int pass = 0; pass < 2; ++pass)
+                for (int e = tid; e < (int)nblk * P * TN; e += 64 * NW) {       // (TN walkers fastest: coalesced rows)
+                    const int col = e % TN, bp = e / TN;
+                    s += __builtin_nontemporal_load(&spart[(int64_t)bp * Wld + nb + col]);
+                }
+            for (int it = 0; it < P * P * P / 3 + 2 * P * P; ++it) s = fma(s, 1.0000001, 1e-9);
+            if (s == 12345.678) trace[3] = 1u;
+            if (tid == 0) trace[16 + wt] = 0u;          // re-armed for the next launch
+        }
+        return;
+    }
+#endif
     if (trace && tid == 0) {
         const unsigned slot = atomicAdd(&trace[0], 1u);
         if (slot < trace[1]) {                  // trace[1] = capacity in records

@@ -40,7 +40,9 @@ GPB_API int gpb_test_gemm(gpb_ctx* ctx, int64_t M, int64_t N, int64_t K,
  * gpb_emcee_run behaves like rank `32` of `26` ranks on a single GPU (evaluates that rank's share of every batch, still issues
  * the collective of a one-rank communicator): one rank's share of a sharded step, tools/gpu_shard_sim.py; 37 = 0: the 128x128
  * predict tile without the fragment read-ahead; 38 = folded pairs of predict row blocks; 39 = 0: K(X,X) by the difference-form
- * kernel for every GP; 41 = 64-row predict tiles staged by LDS-DMA from a k-major copy of L^-1. */
+ * kernel for every GP; 41 = 64-row predict tiles staged by LDS-DMA from a k-major copy of L^-1; 46 = fusion probe: every predict tile
+ * releases its partial sums and takes a ticket of its walker tile (1), and the last tile of a walker tile reads them back as the block
+ * likelihood would (2) — what folding the likelihood into the predict kernel would add (tools/gpu_fusion_probe.py; results unchanged). */
 /* test hook: make R contexts of ONE process (each with its own stream, each driven by its own host thread) the ranks 0 .. R-1 of
  * a loopback communicator: gpb_dist_allgather / the in-stream all-gathers of gpb_chain_emcee_run are then emulated on the
  * ranks' streams (events + device copies; the host threads meet inside the call, so every rank must make the same calls
