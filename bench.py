@@ -266,6 +266,43 @@ def extras(chain4, emu4, info4):
                                  "(171.0 MF per row)"}
     emu5._engine.close()
 
+    # training of the emulators of such a chain with their full hyper-parameter searches (src/emulator.py:286-315 for each of the
+    # nine data sets, examples/EmulatorTraining.ipynb:124-138): one after the other against train_emulators, which runs the 63
+    # searches in ONE lock-step batch (gpb_gp_set_multi / gpb_gp_lml_subset) — same theta*, bit for bit
+    from gpbayestools_hic_amd import Emulator
+    from gpbayestools_hic_amd.emulator import train_emulators
+    import tempfile
+
+    def nine(wd):
+        pf = os.path.join(wd, "par.txt")
+        synth.write_parameter_file(pf, np.zeros(20), np.ones(20))
+        emus = []
+        for i in range(9):
+            Xi = synth.lhs(1000, 20, seed=synth.SEED + 100 + i)
+            tp = os.path.join(wd, "t%d.pkl" % i)
+            synth.write_training_pickle(tp, Xi, synth.observables(Xi, 60, seed=synth.SEED + 200 + i), 0.01)
+            emus.append(Emulator(training_set_path=tp, parameter_file=pf, npc=6 + i % 3))
+        return emus
+    seq, tog = nine(tempfile.mkdtemp(prefix="gpb_tr_")), nine(tempfile.mkdtemp(prefix="gpb_tr_"))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for em in seq:
+        em.trainEmulatorAutoMask()
+    torch.cuda.synchronize()
+    t_seq = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    train_emulators(tog)
+    torch.cuda.synchronize()
+    t_tog = time.perf_counter() - t0
+    out["train_nine_emulators"] = {"emulators": 9, "design_points_each": 1000, "params": 20, "gps": sum(em._ngp for em in seq),
+                                   "one_after_the_other_s": t_seq, "train_emulators_s": t_tog, "speedup": t_seq / t_tog,
+                                   "theta_identical": bool(all(np.array_equal(a.thetas_, b.thetas_) for a, b in zip(seq, tog))),
+                                   "what": "full hyper-parameter searches (L-BFGS-B on the device log-marginal likelihood, no restarts) of nine "
+                                           "emulators: Emulator.trainEmulatorAutoMask one after the other / train_emulators (all 63 GPs in one "
+                                           "lock-step batch, converged searches leaving it); scaler + PCA on the host included"}
+    for em in seq + tog:
+        em._engine.close()
+
     # a chain at the size of the reference's real analyses: nine emulators with their own designs, kernels and numbers of
     # GPs over one 20-parameter space, 540 observables, block-diagonal covariance (src/mcmc.py:153-166,
     # examples/RunBayesianAnalysis.ipynb:35-48), 4096 walkers, the whole step loop in gpb_chain_emcee_run
