@@ -90,6 +90,26 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ G, int64_t 
     }
 }
 
+// the two halves of load_tile, for a tile that is fetched while another one is being multiplied
+struct TileRegs { d2 v[4]; };
+__device__ __forceinline__ void gload_tile(const double* __restrict__ G, int64_t ld, TileRegs& t, int tid) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int idx = tid + CHOL_THREADS * e;
+        const int r = idx >> 5, c = (idx & 31) * 2;
+        t.v[e] = *reinterpret_cast<const d2*>(G + (int64_t)r * ld + c);
+    }
+}
+__device__ __forceinline__ void lstore_tile(double (*S)[LDP], const TileRegs& t, int tid) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int idx = tid + CHOL_THREADS * e;
+        const int r = idx >> 5, c = (idx & 31) * 2;
+        S[r][c] = t.v[e].x;
+        S[r][c + 1] = t.v[e].y;
+    }
+}
+
 // out[i][j] = sum_k A[i][k] * B[j][k] over a 64x64x64 block, operands in LDS.  8 waves as 2 x 4: wave (wm, wn) owns
 // rows 32 wm .. +31 (two 16-row m-tiles) and columns 16 wn .. +15; acc[t] = m-tile t.
 __device__ __forceinline__ void mma_nt_64(const double (*A)[LDP], const double (*B)[LDP], d4 acc[2], int wave, int lane) {

@@ -1066,6 +1066,7 @@ extern "C" int gpb_ctx_option(gpb_ctx* ctx, int key, int value) {
             break;
         }
 #endif
+        case 47: if (value < 0 || value > 2) return GPB_E_ARG; ctx->chol_pair = value; break;
         case 44: if (value < 0) return GPB_E_ARG; ctx->tile_switch = value > 0 ? value : 960; break;
         case 33: if (value < 0) return GPB_E_ARG; ctx->tile_switch_c = value; break;
         case 34: if (value < 0) return GPB_E_ARG; ctx->mid_switch_c = value; break;

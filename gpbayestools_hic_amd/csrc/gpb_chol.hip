@@ -133,6 +133,61 @@ __global__ __launch_bounds__(CHOL_THREADS, 4) void k_chol_update(double* __restr
     store_diag(s, Cp, Linv + (int64_t)p * Np * Np + j * 64 * Np + j * 64, Np, j * 64, info + p);
 }
 
+// Trailing update by TWO block columns at once (K = 128) + the next diagonal block: the second half of a column PAIR (kb, kb + 1).
+// Tiles (i, j), kb + 1 < j, j <= i < nb, numbered column by column; tile 0 = (kb + 2, kb + 2) is the next pair's first diagonal
+// block (kept in LDS, factored and inverted right there, as in k_chol_update).  A tile's C is read and written ONCE for the two
+// columns' updates: half the trailing-matrix traffic of two K = 64 steps — the K = 64 update moves 64 KB of C per 0.5 MFLOP and runs
+// at the HBM's pace (3.7 TB/s of C traffic, matrix pipes 27 % busy: profiles/r04_fit_pmc.json).  The operand tiles of column kb + 1
+// are fetched into registers while column kb's are multiplied.
+__global__ __launch_bounds__(CHOL_THREADS, 4) void k_chol_update2(double* __restrict__ K, double* __restrict__ Linv,
+                                                               int64_t Np, int64_t kb, int* __restrict__ info, unsigned P) {
+    __shared__ CholLds s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = (int)(blockIdx.x % P);               // GP fastest: see k_chol_update
+    const unsigned bx = blockIdx.x / P;
+    const int64_t nb = Np / 64;
+    int64_t j = kb + 2, t = bx;
+    while (t >= nb - j) { t -= nb - j; ++j; }          // column j holds nb - j tiles (rows j .. nb-1)
+    const int64_t i = j + t;
+    double* Kp = K + (int64_t)p * Np * Np;
+    const int64_t c0 = kb * 64, c1 = c0 + 64;
+    const bool diag = i == j;
+    load_tile(Kp + i * 64 * Np + c0, Np, s.a, tid);
+    if (!diag) load_tile(Kp + j * 64 * Np + c0, Np, s.x, tid);
+    TileRegs na, nx;                                   // column kb + 1's operand tiles, in flight under the first product
+    gload_tile(Kp + i * 64 * Np + c1, Np, na, tid);
+    if (!diag) gload_tile(Kp + j * 64 * Np + c1, Np, nx, tid);
+    const int m0 = (wave >> 2) * 32, n0 = (wave & 3) * 16, lr = lane & 15, lk = lane >> 4;
+    double* Cp = Kp + i * 64 * Np + j * 64;
+    d4 c[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[tt][r] = Cp[(int64_t)(m0 + 16 * tt + lk + 4 * r) * Np + n0 + lr];
+    __syncthreads();
+    d4 acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    mma_nt_64(s.a, diag ? s.a : s.x, acc, wave, lane);
+    __syncthreads();                                   // every wave is done reading column kb's operand tiles
+    lstore_tile(s.a, na, tid);
+    if (!diag) lstore_tile(s.x, nx, tid);
+    __syncthreads();
+    mma_nt_64(s.a, diag ? s.a : s.x, acc, wave, lane);  // k continues: one sum over the 128 columns of the pair
+    if (bx != 0) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cp[(int64_t)(m0 + 16 * tt + lk + 4 * r) * Np + n0 + lr] = c[tt][r] - acc[tt][r];
+        return;
+    }
+    __syncthreads();                                   // every wave is done reading the operand tile in s.a
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s.a[m0 + 16 * tt + lk + 4 * r][n0 + lr] = c[tt][r] - acc[tt][r];
+    potf2_inv_64(s);                                   // opens with a barrier
+    store_diag(s, Cp, Linv + (int64_t)p * Np * Np + j * 64 * Np + j * 64, Np, j * 64, info + p);
+}
+
 // declared in gpb_fit.hip: trailing update by the panel [pb, pe): rows >= r0, columns [r0, ce), K = pe - pb
 void launch_syrk_range(gpb_ctx* ctx, hipStream_t stream, int64_t pb, int64_t pe, int64_t r0, int64_t ce);
 
@@ -163,7 +218,38 @@ int ensure_lookahead(gpb_ctx* ctx, size_t nev) {
 // next panel's own columns [pe, pe + NBO), stays on the chain's stream; the FAR part, columns >= pe + NBO, goes to a
 // side stream and runs underneath the next panel's chain, which leaves nine tenths of the matrix cores idle (two events
 // per panel; the far parts of consecutive panels are ordered by the side stream itself).
+// Column PAIRS (option 47, chol_pair): every second step's update is left out and the step after it updates the trailing matrix by
+// both columns at once (k_chol_update2) — per pair: column solve of kb, update of column kb + 1 alone (+ its diagonal block), column
+// solve of kb + 1, K = 128 update of everything to the right (+ the next diagonal block).  One "panel" over the whole matrix: no
+// k_syrk, no lookahead.  Measured (profiles/r04_fit_notes.txt): N = 2048 1303-1309 us against 1322-1340 for single steps (half the
+// trailing-matrix traffic buys 2-3 %: the update is bound by the latency of a tile in its slot, not by the HBM), N = 1024 +1 %
+// (the chain), N = 1536 754 against 735, N = 3072 3270 against 3300, N = 4096 6770-6940 us against 6150-6270 for panels of 256 with
+// k_syrk: used for 1536 < Np <= 3072 only.
+static int launch_potrf_pairs(gpb_ctx* ctx) {
+    const int64_t Np = ctx->Np, nb = Np / 64;
+    const unsigned P = (unsigned)ctx->P;
+    hipLaunchKernelGGL(k_chol_diag, dim3(P), dim3(CHOL_THREADS), 0, ctx->stream, ctx->K, ctx->Linv, Np, (int64_t)0, ctx->info);
+    for (int64_t kb = 0; kb + 1 < nb; kb += 2) {
+        hipLaunchKernelGGL(k_chol_trsm, dim3((unsigned)(nb - kb - 1) * P), dim3(CHOL_THREADS), 0, ctx->stream, ctx->K, ctx->Linv,
+                           Np, kb, P);
+        // column kb + 1 alone: its nb - kb - 1 tiles, the first of which is the diagonal block (k_chol_update with je = kb + 2)
+        hipLaunchKernelGGL(k_chol_update, dim3((unsigned)(nb - kb - 1) * P), dim3(CHOL_THREADS), 0, ctx->stream, ctx->K,
+                           ctx->Linv, Np, kb, kb + 2, ctx->info, P);
+        if (kb + 2 >= nb) break;                       // column kb + 1 was the last
+        hipLaunchKernelGGL(k_chol_trsm, dim3((unsigned)(nb - kb - 2) * P), dim3(CHOL_THREADS), 0, ctx->stream, ctx->K, ctx->Linv,
+                           Np, kb + 1, P);
+        int64_t ntile = 0;
+        for (int64_t j = kb + 2; j < nb; ++j) ntile += nb - j;
+        hipLaunchKernelGGL(k_chol_update2, dim3((unsigned)ntile * P), dim3(CHOL_THREADS), 0, ctx->stream, ctx->K, ctx->Linv, Np,
+                           kb, ctx->info, P);
+    }
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_potrf_fused(gpb_ctx* ctx) {
+    if (ctx->chol_outer == 0 && (ctx->chol_pair == 2 || (ctx->chol_pair == 1 && ctx->Np > 1536 && ctx->Np <= 3072)))
+        return launch_potrf_pairs(ctx);
     const int64_t Np = ctx->Np, nb = Np / 64;
     // outer panel width (multiple of 64).  0 = by size (tools/gpu_fit_timing.py, 10 GPs): up to N = 2048 ONE panel — every
     // step updates the whole trailing matrix with K = 64 and no panel-end SYRK is left (0.74 -> 0.70 ms at 1024, 2.41 ->

@@ -272,7 +272,9 @@ GPB_API int gpb_dist_finalize(gpb_ctx* ctx);
  *   sharded step loop (0 off: default, 1 from 8 ranks on, 2 always); 40 the emulators of a chain share one launch per kernel kind;
  *   42 force the predict tile (0: by rule; 128, 64, 32 = 64 rows x 32 walkers, 65 = 64 x 128: every shape gives the same bits);
  *   43 route the block log-likelihood through the generic LDS / HBM Cholesky kernel (what M > 64 takes) whatever M;
- *   44 the number of 128x128 predict tiles per 256 CUs from which the rule takes them (0: default 960).
+ *   44 the number of 128x128 predict tiles per 256 CUs from which the rule takes them (0: default 960);
+ *   47 Cholesky by column pairs (every second trailing update takes two block columns at once, K = 128): 1 where it is the faster
+ *   schedule (default: 1536 < N <= 3072), 2 always, 0 never; results agree to rounding (another order of the same sums).
  *   Keys and values that select a measured-and-rejected kernel variant or a measurement hook (2, 21, 24, 26, 32, 37, 38, 39, 41
  *   and 5 = 0) exist in the debug build only (libgpbayes_debug.so: include/gpbayes_debug.h) and return GPB_E_ARG here.
  * gpb_debug_has_variants: 1 when the loaded library is that debug build (-DGPB_DEBUG_VARIANTS), 0 for the product library.
