@@ -137,6 +137,17 @@ def test_cholesky_schedules_agree(N, library):
         if outer == 256 and look == 0:
             assert np.array_equal(L, L256)
     eng.tune("chol_algo", 1); eng.tune("chol_outer", 0); eng.tune("chol_lookahead", 1)
+    # column pairs (every second trailing update by two block columns at once: another grouping of the same sums) on and off
+    pair = {}
+    for mode in (2, 0, 2):
+        eng.tune("chol_pair", mode)
+        eng.factor()
+        L, Xi = eng.get("L"), eng.get("Linv")
+        assert np.max(np.abs(L - ref_L)) < 1e-12 * np.max(np.abs(ref_L)) and np.max(np.abs(Xi - ref_X)) < 1e-11 * np.max(np.abs(ref_X))
+        if mode in pair:
+            assert np.array_equal(L, pair[mode][0]) and np.array_equal(Xi, pair[mode][1])         # run to run
+        pair[mode] = (L, Xi)
+    eng.tune("chol_pair", 1)
     K = O.kernel_train(X, th[0], O.KIND_RBF, 0.1)
     Lo = np.linalg.cholesky(K)
     assert np.max(np.abs(ref_L[0] - Lo)) < 1e-11 * np.max(np.abs(Lo))
