@@ -14,15 +14,16 @@ using namespace gpb;
 
 namespace {
 
+// (through the buffer cache of gpb_pool.hip: contexts come and go with every training)
 template <typename T>
 int dev_alloc(gpb_ctx* ctx, T** p, int64_t count) {
-    if (*p) { GPB_HIP(hipFree(*p)); *p = nullptr; }
-    GPB_HIP(hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * (size_t)(count > 0 ? count : 1)));
+    if (*p) { pool_free(*p); *p = nullptr; }
+    GPB_HIP(pool_malloc(reinterpret_cast<void**>(p), sizeof(T) * (size_t)(count > 0 ? count : 1)));
     return 0;
 }
 template <typename T>
 void dev_free(T** p) {
-    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (*p) { pool_free(*p); *p = nullptr; }
 }
 
 int pick_dpad(int64_t d) {

@@ -223,6 +223,10 @@ struct gpb_ctx {
     } while (0)
 
 namespace gpb {
+// cache of freed device buffers (gpb_pool.hip): every pointer from pool_malloc must go back through pool_free
+hipError_t pool_malloc(void** p, size_t bytes);
+void pool_free(void* p);
+void pool_trim();
 // fit side (gpb_fit.hip)
 int launch_scale_design(gpb_ctx* ctx);
 int choose_forms(gpb_ctx* ctx);                        // gpb_api.hip: per-GP distance form from h_theta and the design's extents

@@ -1000,18 +1000,18 @@ int ensure_wcap(gpb_ctx* ctx, int64_t W) {
     GPB_HIP(hipStreamSynchronize(ctx->stream));
     double** bufs[] = {&ctx->Xs, &ctx->estd, &ctx->KsT, &ctx->mpart, &ctx->spart, &ctx->mean_pc, &ctx->var_pc};
     for (auto b : bufs) {
-        if (*b) { GPB_HIP(hipFree(*b)); *b = nullptr; }
+        if (*b) { pool_free(*b); *b = nullptr; }
     }
     ctx->Wcap = 0;
     const int64_t P = ctx->P, Np = ctx->Np;
     const int64_t nchunk = (Np + KX_CHUNK - 1) / KX_CHUNK, nI64 = Np / 64;
-    GPB_HIP(hipMalloc(&ctx->Xs, sizeof(double) * need * ctx->d));
-    GPB_HIP(hipMalloc(&ctx->estd, sizeof(double) * need));
-    GPB_HIP(hipMalloc(&ctx->KsT, sizeof(double) * P * Np * need));
-    GPB_HIP(hipMalloc(&ctx->mpart, sizeof(double) * nchunk * P * need));
-    GPB_HIP(hipMalloc(&ctx->spart, sizeof(double) * nI64 * P * need));
-    GPB_HIP(hipMalloc(&ctx->mean_pc, sizeof(double) * P * need));
-    GPB_HIP(hipMalloc(&ctx->var_pc, sizeof(double) * P * need));
+    GPB_HIP(pool_malloc(reinterpret_cast<void**>(&ctx->Xs), sizeof(double) * need * ctx->d));
+    GPB_HIP(pool_malloc(reinterpret_cast<void**>(&ctx->estd), sizeof(double) * need));
+    GPB_HIP(pool_malloc(reinterpret_cast<void**>(&ctx->KsT), sizeof(double) * P * Np * need));
+    GPB_HIP(pool_malloc(reinterpret_cast<void**>(&ctx->mpart), sizeof(double) * nchunk * P * need));
+    GPB_HIP(pool_malloc(reinterpret_cast<void**>(&ctx->spart), sizeof(double) * nI64 * P * need));
+    GPB_HIP(pool_malloc(reinterpret_cast<void**>(&ctx->mean_pc), sizeof(double) * P * need));
+    GPB_HIP(pool_malloc(reinterpret_cast<void**>(&ctx->var_pc), sizeof(double) * P * need));
     if (ctx->cmp_idx) { GPB_HIP(hipFree(ctx->cmp_idx)); ctx->cmp_idx = nullptr; }
     if (ctx->cmp_X) { GPB_HIP(hipFree(ctx->cmp_X)); ctx->cmp_X = nullptr; }
     ctx->cmp_X_cap = 0;

@@ -3,10 +3,35 @@ Host-side preprocessing of the training observables (one N x M SVD; SURVEY §8 a
 this on the host): standardisation, whitened PCA, and the PC -> observable transform arrays.
 numpy/scipy only — scikit-learn is not needed at run time.
 """
+import contextlib
 import math
 
 import numpy as np
 from scipy import linalg
+
+_blas_ctl = None
+
+
+@contextlib.contextmanager
+def single_thread_blas():
+    """The host linear algebra of a training — one N x M SVD, two small products — on ONE BLAS thread.  Two reasons: (i) a threaded
+    LAPACK rounds differently for every thread count, so two processes that train on the same data (the ranks of a sharded run:
+    torch.distributed.run gives its ranks OMP_NUM_THREADS=1, a notebook has all cores) would disagree in the last bits of the GP
+    targets, and with them in every log-probability — on one thread every process computes the same bits; (ii) it is faster at
+    these sizes (1000 x 60: 1.2 ms on one thread against 3.4 on 64, tools/micro/svd_threads.py).  threadpoolctl when it is
+    installed (it ships with scikit-learn, which the reference needs anyway); otherwise the caller's threading stays."""
+    global _blas_ctl
+    if _blas_ctl is None:
+        try:
+            from threadpoolctl import ThreadpoolController
+            _blas_ctl = ThreadpoolController()
+        except Exception:                  # not installed: nothing to pin
+            _blas_ctl = False
+    if _blas_ctl is False:
+        yield
+        return
+    with _blas_ctl.limit(limits=1, user_api="blas"):
+        yield
 
 
 class Standardizer:
@@ -43,7 +68,8 @@ class WhitenedPCA:
         S = np.asarray(S, dtype=np.float64)
         n = S.shape[0]
         self.mean_ = S.mean(axis=0)
-        U, s, Vt = linalg.svd(S - self.mean_, full_matrices=False)
+        with single_thread_blas():
+            U, s, Vt = linalg.svd(S - self.mean_, full_matrices=False)
         # deterministic signs: largest-magnitude entry of every component is positive
         idx = np.argmax(np.abs(Vt), axis=1)
         sg = np.sign(Vt[np.arange(Vt.shape[0]), idx])
@@ -80,7 +106,8 @@ def observable_transform(components, explained_variance, scale, var, npc):
     T = components * np.sqrt(explained_variance)[:, None] * scale
     A = np.ascontiguousarray(T[:npc])
     B = T[npc:]
-    cov_trunc = B.T @ B
+    with single_thread_blas():
+        cov_trunc = B.T @ B
     cov_trunc[np.diag_indices(nobs)] += 1e-4 * var
     return T, A, cov_trunc
 

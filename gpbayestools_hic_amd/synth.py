@@ -38,7 +38,9 @@ def observables(X, M, seed=SEED + 1, noise=0.01):
     W1 = rng.standard_normal((d, M))
     W2 = rng.standard_normal((d, M))
     eps = rng.standard_normal((X.shape[0], M))
-    return 2.0 + np.sin(X @ W1) + 0.5 * np.cos(X @ W2) + noise * eps
+    from .preprocess import single_thread_blas
+    with single_thread_blas():             # the same bits whatever the process's BLAS threading (ranks of a sharded bench)
+        return 2.0 + np.sin(X @ W1) + 0.5 * np.cos(X @ W2) + noise * eps
 
 
 def truth_point(d, seed=SEED + 2):

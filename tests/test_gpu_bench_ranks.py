@@ -31,13 +31,14 @@ def _run(cmd, env):
 
 @pytest.mark.parametrize("R", [2, 4])
 def test_bench_two_ranks_on_one_gpu_equal_the_single_gpu_run(R):
-    # torch.distributed.run gives every rank OMP_NUM_THREADS=1, and the host side of trainEmulator (scaler + PCA: an N x M SVD
-    # in numpy, as in the reference) rounds differently with threaded BLAS, the GP targets with it.  The ranks agree among
-    # themselves whatever their threading (rank 0's fitted state is broadcast: WalkerSharding.replicate, and every run starts
-    # with a digest check); the comparison with a SEPARATE single-GPU process needs that process to round the same way
-    # as rank 0, so it gets the ranks' thread count
+    # torch.distributed.run gives every rank OMP_NUM_THREADS=1, the single-GPU process keeps all cores: no pin on either side.
+    # The host linear algebra of a training (the scaler / PCA SVD, two small products; the synthetic observables) runs on ONE
+    # BLAS thread whatever the process's threading (preprocess.single_thread_blas), so separate processes fit the same bits; on
+    # top of that rank 0's fitted state is broadcast (WalkerSharding.replicate) and every sharded run starts with a digest check
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    one = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS, dict(env, OMP_NUM_THREADS="1"))
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        env.pop(k, None)
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS, env)
     env2 = dict(env, GPB_DIST_BACKEND="gloo")
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(R), "--master-addr",
                 "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", str(R)] + ARGS, env2)
