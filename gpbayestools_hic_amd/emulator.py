@@ -315,7 +315,7 @@ class Emulator:
         sh = self.fit_sharding
         copies = 1 + int(self.nrestarts)
         Np = -(-self._X_train.shape[0] // 64) * 64
-        if copies * self._ngp * 3 * 8 * Np * Np > (96 << 30):     # the batch of all starts would not fit comfortably: start by start
+        if copies * self._ngp * 3 * 8 * Np * Np > _BATCH_BYTES_MAX:     # the batch of all starts would not fit comfortably: start by start
             copies = 1
         if sh is None or sh.world == 1:
             if copies == 1:
@@ -330,6 +330,18 @@ class Emulator:
             sub.set_data(self._X_train, self._Z_train[idx], _KERNELS[kernel_type][0], self.alpha)
             return sub
         return search_hyperparameters(sub_engine, self._ngp, theta0, bounds, self.nrestarts, sh, close=True)
+
+    def _optimise_with_points(self, kernel_type, theta0_bounds, draws):
+        """the search of this emulator alone from given restart points (train_emulators' fallback for batches that do not fit)"""
+        theta0, bounds = theta0_bounds
+        eng = self._new_engine()
+        best_theta = np.tile(theta0, (self._ngp, 1))
+        best_val = np.full(self._ngp, np.inf)
+        for start in [best_theta.copy()] + [draws[:, r, :] for r in range(draws.shape[1] if draws.ndim == 3 else 0)]:
+            th, val = _batched_lbfgsb(eng, start, bounds)
+            better = val < best_val
+            best_theta[better], best_val[better] = th[better], val[better]
+        return best_theta, -best_val
 
     def _build_transform(self):
         if self.perform_no_PCA_:
@@ -494,6 +506,9 @@ class Emulator:
         return self._holdout(nTestPoints, on_training=True, thetas=thetas)
 
 
+_BATCH_BYTES_MAX = 96 << 30          # three N x N matrices per virtual GP of a search batch: beyond this the emulators train one by one
+
+
 def train_emulators(emulators, eventMasks=None, kernel_type="RBF"):
     """Train the emulators of a chain TOGETHER: what `for emu in emulators: emu.trainEmulator(mask, kernel_type)` does
     (the reference fits dataset after dataset and GP after GP: examples/EmulatorTraining.ipynb:124-138,
@@ -529,8 +544,15 @@ def train_emulators(emulators, eventMasks=None, kernel_type="RBF"):
             if results[i] is None:
                 raise NotImplementedError("train_emulators: a sharded fit with restarts trains through trainEmulator")
             continue
-        Xs, Zs, start, bnd, owner = [], [], [], [], []
         smax = 1 + max(int(emulators[i].nrestarts) for i in members)
+        nvirt = sum(emulators[i]._ngp * (1 + int(emulators[i].nrestarts)) for i in members)
+        if len(members) > 1 and nvirt * 3 * 8 * (64 * key[2]) ** 2 > _BATCH_BYTES_MAX:
+            # the batch's three N x N matrices per virtual GP would not fit comfortably: these emulators train one by one
+            for i in members:
+                emu = emulators[i]
+                results[i] = emu._optimise_with_points(kernel_type, t0b[i], draws[i])
+            continue
+        Xs, Zs, start, bnd, owner = [], [], [], [], []
         for s_ in range(smax):                       # virtual GPs start-major: the first block is every GP's theta0 start
             for i in members:
                 emu = emulators[i]

@@ -18,6 +18,8 @@
  *     (call gpb_sync or use stream order).
  *   - one context per (process, device, emulator); not thread-safe per context.
  *   - there is NO CPU fallback: if no gfx950 device is present gpb_ctx_create fails.
+ *   - device buffers a context releases are kept for the next context of about that size (up to GPB_POOL_MB megabytes per
+ *     process, default 8192, 0 = off): on this runtime hipFree + hipMalloc of a large buffer is a driver round trip of 60-100 ms.
  */
 #ifndef GPBAYES_H
 #define GPBAYES_H

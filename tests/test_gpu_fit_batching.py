@@ -139,3 +139,22 @@ def test_train_emulators_together_equals_one_after_the_other(tmp_path, kernel_ty
         mb, cb = b.predict(Xq, return_cov=True)
         assert np.array_equal(ma, mb) and np.array_equal(ca, cb)
         assert np.array_equal(a.gp_scores_, b.gp_scores_)
+
+
+def test_a_batch_that_would_not_fit_trains_the_emulators_one_by_one(tmp_path, monkeypatch):
+    """train_emulators' fallback (the batch's matrices beyond the memory bound): each emulator's own search from the same restart
+    points — identical results again"""
+    from gpbayestools_hic_amd import emulator as E
+    spec = [(100, 5, 3, 1), (128, 7, 2, 0)]
+    def make(sub):
+        (tmp_path / sub).mkdir()
+        return [_emulator(str(tmp_path / sub), str(i), N, 4, M, npc, seed=80 + 3 * i, nrestarts=nr) for i, (N, M, npc, nr) in enumerate(spec)]
+    a = make("a")
+    np.random.seed(5)
+    E.train_emulators(a)
+    monkeypatch.setattr(E, "_BATCH_BYTES_MAX", 0)
+    b = make("b")
+    np.random.seed(5)
+    E.train_emulators(b)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.thetas_, y.thetas_) and np.array_equal(np.asarray(x.lml_), np.asarray(y.lml_))
