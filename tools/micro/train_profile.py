@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Where does the time of train_emulators go?  Nine emulators (N = 1000, 20 parameters, 63 GPs): wall time, the time inside the device
+log-marginal-likelihood calls (GPEngine.lml / lml_subset, timed by wrapping them), and a cProfile of one call.  The measurement that
+found the two host stalls of profiles/r04_train_batching.txt."""
 import os, sys, time, tempfile
 import numpy as np
 sys.path.insert(0, "/root/repo")
