@@ -371,3 +371,38 @@ def test_rows_with_nan_or_infinite_parameters_are_outside_the_box(tmp_path):
         eng.tune("compact", compact)
         assert np.array_equal(chain.log_posterior(bad), lp)
     eng.tune("compact", 1)
+
+
+def test_contexts_come_and_go_through_the_buffer_cache():
+    """csrc/gpb_pool.hip keeps the device buffers a context releases for the next context of about that size (hipFree + hipMalloc of a
+    large buffer is a driver round trip on this runtime): contexts of many shapes created, used, re-set and destroyed in any order —
+    also while another context is alive on buffers of the same sizes — give the numbers a fresh context gives"""
+    from gpbayestools_hic_amd import GPEngine, synth
+    rng = np.random.default_rng(4)
+    shapes = [(64, 3, 2), (200, 5, 3), (130, 4, 1), (200, 5, 3), (64, 3, 2), (333, 6, 2), (200, 5, 3)]
+    ref = {}
+    keep = []
+    for rep in range(3):
+        for n, (N, d, P) in enumerate(shapes):
+            X = synth.lhs(N, d, seed=N + d); Z = np.random.default_rng(N).standard_normal((P, N))
+            th = synth.fixed_theta(d, P)
+            Xs = np.random.default_rng(d).random((37 + 64 * (n % 3), d))
+            eng = GPEngine(0)
+            eng.set_data(X, Z, "Matern15" if n % 2 else "RBF", 0.1); eng.set_theta(th); eng.factor()
+            got = eng.predict(Xs) + (eng.lml(th)[0],)
+            key = (n,)
+            if key in ref:
+                for a, b in zip(got, ref[key]):
+                    assert np.array_equal(a, b), (rep, n)
+            else:
+                ref[key] = got
+            if rng.random() < 0.4:
+                keep.append(eng)                           # stays alive, on buffers that may have come from the cache
+            else:
+                eng.close()
+            if keep and rng.random() < 0.5:
+                old = keep.pop(int(rng.integers(len(keep))))
+                old.set_data(synth.lhs(96, 2), np.zeros((1, 96)) + 1.0)       # re-set to another shape, then gone
+                old.close()
+    for e in keep:
+        e.close()
