@@ -31,6 +31,35 @@ __device__ __forceinline__ double exp_nonpos(double x) {
     q = fma(q, r, 1.0);
     return ldexp(q, (int)n);
 }
+// The same for N independent arguments, step by step side by side: a wave that evaluates one exp at a time walks a chain of ~19
+// dependent fp64 operations at their full latency (k_kcross at three waves per SIMD kept the vector pipes 66 % busy, and a cheaper
+// exp changed nothing: latency, not issue); N chains interleaved in the source give the scheduler N operations in flight.
+// Element for element the operations of exp_nonpos: same bits.
+template <int N>
+__device__ __forceinline__ void exp_nonpos_n(const double (&xin)[N], double (&out)[N]) {
+    double x[N], n[N], r[N], q[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) x[u] = fmax(xin[u], -746.0);
+#pragma unroll
+    for (int u = 0; u < N; ++u) n[u] = __builtin_rint(x[u] * EXP_C[0]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) r[u] = fma(n[u], EXP_C[1], x[u]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) r[u] = fma(n[u], EXP_C[2], r[u]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) q[u] = EXP_C[3];
+#pragma unroll
+    for (int k = 4; k <= 14; ++k)
+#pragma unroll
+        for (int u = 0; u < N; ++u) q[u] = fma(q[u], r[u], EXP_C[k]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) q[u] = fma(q[u], r[u], 1.0);
+#pragma unroll
+    for (int u = 0; u < N; ++u) q[u] = fma(q[u], r[u], 1.0);
+#pragma unroll
+    for (int u = 0; u < N; ++u) out[u] = ldexp(q[u], (int)n[u]);
+}
+
 // sqrt(x) for x >= 0 by v_rsq_f64 and two coupled Newton steps (Goldschmidt), 1 ulp, without the library form's scaling
 // and special-case selects (17 instructions); x is clamped to 1e-300 first (coincident points: sqrt = 1e-150, K = 1).
 __device__ __forceinline__ double sqrt_pos(double x) {
@@ -57,5 +86,25 @@ __device__ __forceinline__ double shape_fn_fast(double r2) {
     }
 }
 
+// ... for N arguments side by side (see exp_nonpos_n): what k_kcross evaluates for the walkers a lane holds
+template <int KIND, int N>
+__device__ __forceinline__ void shape_fn_fast_n(const double (&r2)[N], double (&out)[N]) {
+    double x[N], e[N];
+    if (KIND == GPB_KERNEL_RBF) {
+#pragma unroll
+        for (int u = 0; u < N; ++u) x[u] = -0.5 * r2[u];
+        exp_nonpos_n<N>(x, out);
+    } else {
+        double t[N];
+#pragma unroll
+        for (int u = 0; u < N; ++u) t[u] = sqrt_pos(r2[u]) * (KIND == GPB_KERNEL_MATERN15 ? 1.7320508075688772 : 2.23606797749979);
+#pragma unroll
+        for (int u = 0; u < N; ++u) x[u] = -t[u];
+        exp_nonpos_n<N>(x, e);
+#pragma unroll
+        for (int u = 0; u < N; ++u)
+            out[u] = (KIND == GPB_KERNEL_MATERN15 ? (1.0 + t[u]) : (1.0 + t[u] + (t[u] * t[u]) * EXP_C[15])) * e[u];
+    }
+}
 
 }  // namespace gpb

@@ -12,6 +12,7 @@
 // walker's result is bit-identical however the ensemble is split across GPUs.
 #include "gpb_internal.h"
 #include "gemm_tile.h"
+#include "fast_math.h"
 #include <math.h>
 
 namespace gpb {
@@ -185,9 +186,13 @@ __device__ __forceinline__ void kcross_body(KxLds<DPAD, WPL>& L, const double* _
                         }
                     }
                 }
+                // the lane's WPL kernel values side by side (fast_math.h: the shape functions of k_kmat_mfma — K(X,X) and K* by the
+                // same arithmetic — with the WPL chains interleaved: one exp at a time ran at its operations' latency)
+                double sh[WPL];
+                shape_fn_fast_n<KIND, WPL>(r2, sh);
 #pragma unroll
                 for (int u = 0; u < WPL; ++u) {
-                    kv[u] = c * shape_fn_p<KIND>(r2[u]);
+                    kv[u] = c * sh[u];
                     msum[u] = fma(sal[pt], kv[u], msum[u]);
                 }
             }
