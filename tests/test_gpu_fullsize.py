@@ -162,3 +162,31 @@ def test_cholesky_schedules_agree(N, library):
     _, ref_info = lapack.dpotrf(Kbad, lower=1)
     assert ref_info > 0 and info[0] == ref_info
     eng.close()
+
+
+@pytest.mark.parametrize("N", [1601, 1700, 3072, 129, 190])
+def test_cholesky_by_column_pairs_at_odd_and_even_block_counts(N):
+    """the pair schedule (k_chol_update2: every second trailing update by two block columns at once) where the rule takes it
+    (1536 < Np <= 3072: 26, 27 and 48 block columns) and forced at three and three-with-a-ragged-end block columns: the factor
+    against LAPACK's, the inverse against it, LAPACK's info on an indefinite matrix"""
+    from gpbayestools_hic_amd import GPEngine
+    from oracle import gp_oracle as O
+    from scipy.linalg import lapack
+    P, d = 2, 6
+    eng = GPEngine(0)
+    if N < 1536:
+        eng.tune("chol_pair", 2)
+    X, Z, th = _setup(eng, N, d, P, "Matern15", seed=N)
+    L, Xi = eng.get("L"), eng.get("Linv")
+    for p in range(P):
+        K = O.kernel_train(X, th[p], O.KIND_MATERN15, 0.1)
+        Lo = np.linalg.cholesky(K)
+        assert np.max(np.abs(L[p] - Lo)) < 1e-11 * np.max(np.abs(Lo))
+        v = np.random.default_rng(p).standard_normal((N, 2))
+        assert np.max(np.abs(Xi[p] @ (Lo @ v) - v)) < 1e-9
+    eng.set_data(X, Z, "Matern15", alpha=-1.2)
+    eng.set_theta(th)
+    info = eng.factor(raise_on_fail=False)
+    _, ref_info = lapack.dpotrf(O.kernel_train(X, th[1], O.KIND_MATERN15, -1.2), lower=1)
+    assert ref_info > 0 and info[1] == ref_info
+    eng.close()
