@@ -241,8 +241,10 @@ def extras(chain4, emu4, info4):
     for _ in range(2):
         chain5.log_prob_device(Xd5, lp5, outside=-1e300)
     torch.cuda.synchronize()
-    eng5c.profile(True)
     t5 = timed(lambda: chain5.log_prob_device(Xd5, lp5, outside=-1e300), 5)
+    eng5c.profile(True)                                   # (the HIP events of five more batches: the roofline block's launches)
+    for _ in range(5):
+        chain5.log_prob_device(Xd5, lp5, outside=-1e300)
     n_l, ms_l, u_l = eng5c.profile_read()
     eng5c.profile(False)
     ths = []
