@@ -370,6 +370,10 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=None)
     args = ap.parse_args()
 
+    if os.environ.get("GPB_BENCH_WATCHDOG"):            # a stalled rank says where: every thread's stack after N seconds (then
+        import faulthandler, signal                     # exit), and on the launcher's SIGTERM to the ranks that were waiting for it
+        faulthandler.dump_traceback_later(float(os.environ["GPB_BENCH_WATCHDOG"]), exit=True)
+        faulthandler.register(signal.SIGTERM, chain=True)
     import torch
     import torch.distributed as dist
     from gpbayestools_hic_amd import synth

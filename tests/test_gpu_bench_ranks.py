@@ -21,15 +21,25 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run(cmd, env):
-    r = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
-    assert r.returncode == 0, r.stderr.decode()[-3000:]
+def _run(cmd, env, tag):
+    # a rank that stalls dumps its stacks after 100 s and exits (bench.py: GPB_BENCH_WATCHDOG), the launcher then ends the others
+    env = dict(env, GPB_BENCH_WATCHDOG="100")
+    r = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    if r.returncode != 0:
+        out = os.path.join(REPO, "gpurun_out")
+        if os.path.isdir(out):
+            with open(os.path.join(out, "bench_ranks_%s.err" % tag), "wb") as f:
+                f.write(r.stderr)
+    assert r.returncode == 0, r.stderr.decode()[-6000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout.decode()[-2000:]              # ONE JSON line, from rank 0
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("R", [2, 4])
+# R = 3: a ragged split (2048 proposal rows in shares of 683 / 683 / 682).  Not 4: pytest + the launcher + the ranks all hold the
+# GPU open, the box allows six such processes, and at exactly six the ranks' host<->device copies stalled on some boxes (two
+# ranks inside a blocking 32 KB copy, the other two waiting for them in the all-gather: profiles/r04_ranks_stall.txt).
+@pytest.mark.parametrize("R", [2, 3])
 def test_bench_two_ranks_on_one_gpu_equal_the_single_gpu_run(R):
     # torch.distributed.run gives every rank OMP_NUM_THREADS=1, the single-GPU process keeps all cores: no pin on either side.
     # The host linear algebra of a training (the scaler / PCA SVD, two small products; the synthetic observables) runs on ONE
@@ -38,10 +48,10 @@ def test_bench_two_ranks_on_one_gpu_equal_the_single_gpu_run(R):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         env.pop(k, None)
-    one = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS, env)
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS, env, "one")
     env2 = dict(env, GPB_DIST_BACKEND="gloo")
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(R), "--master-addr",
-                "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", str(R)] + ARGS, env2)
+                "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", str(R)] + ARGS, env2, "R%d" % R)
     assert one["n_gpus"] == 1 and two["n_gpus"] == R
     assert one["config"]["step_loop"] == "gpb_chain_emcee_run"
     assert two["config"]["step_loop"] == "host-driven"               # no in-stream RCCL collective under gloo
