@@ -10,15 +10,21 @@ namespace gpb {
 
 // exp(x) for x <= 0 without the library's special-case selects, its coefficients in SGPRs (scalar loads from constant
 // memory: as immediates the compiler re-materialised them in VGPRs with two v_mov_b32 each — 12 per evaluation, a sixth of
-// the kernel's vector instructions).  n = rint(x log2 e), r = x - n ln 2 (two-term), e^r by the Taylor polynomial of degree
-// 13 (|r| <= ln 2 / 2: truncation 4e-18), 2^n by v_ldexp_f64 (underflows to 0 for n < -1074).  x is clamped at -746 first
+// the kernel's vector instructions).  n = rint(x log2 e), r = x - n ln 2 (two-term), e^r by a polynomial of degree 11
+// (|r| <= ln 2 / 2: 1.6e-17; round 3 used the Taylor polynomial of degree 13 — two more multiply-adds per pair of a kernel that
+// runs at the package's power limit), 2^n by v_ldexp_f64 (underflows to 0 for n < -1074).  x is clamped at -746 first
 // (exp(-746) rounds to 0): without the clamp n = rint(x log2 e) stops being exact beyond |x| ~ 2^53, r stops being small, the
 // polynomial overflows and x = -inf gives NaN (fma(-inf, -ln 2, -inf)) where the library exp of k_kcross gives 0 — extreme
 // theta then left NaN in K(X,X) and 0 in K*.
 // 1-2 ulp; numpy's exp, which sklearn calls, is within 1 ulp: 4e-16 relative between the two (the G1 / G2 bars: 1e-13, 1e-11).
 static __constant__ double EXP_C[16] = {1.4426950408889634, -6.93147180369123816490e-01, -1.90821492927058770002e-10,
-                                 1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0,
-                                 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0 / 3.0};
+                                 // e^r = 1 + r + r^2 (c2 + c3 r + ... + c11 r^9), |r| <= ln 2 / 2: interpolation of (e^r - 1 - r) / r^2 at
+                                 // ten Chebyshev nodes (tools/exp_poly.py; near-minimax: 1.6e-17 relative in exact arithmetic with these
+                                 // doubles, the Taylor polynomial needs degree 13 for that) — c11 first
+                                 2.51004512318139235428e-08, 2.76202012214868374137e-07, 2.75572683411822321766e-06,
+                                 2.48015210588699591568e-05, 1.98412698631052176416e-04, 1.38888889173661989052e-03,
+                                 8.33333333333006499866e-03, 4.16666666666238236227e-02, 1.66666666666666685170e-01,
+                                 5.00000000000000111022e-01, 0.0, 0.0, 1.0 / 3.0};
 __device__ __forceinline__ double exp_nonpos(double x) {
     x = fmax(x, -746.0);
     const double n = __builtin_rint(x * EXP_C[0]);
@@ -26,12 +32,12 @@ __device__ __forceinline__ double exp_nonpos(double x) {
     r = fma(n, EXP_C[2], r);
     double q = EXP_C[3];
 #pragma unroll
-    for (int k = 4; k <= 14; ++k) q = fma(q, r, EXP_C[k]);      // 1/13! ... 1/2!
+    for (int k = 4; k <= 12; ++k) q = fma(q, r, EXP_C[k]);      // c10 ... c2
     q = fma(q, r, 1.0);
     q = fma(q, r, 1.0);
     return ldexp(q, (int)n);
 }
-// The same for N independent arguments, step by step side by side: a wave that evaluates one exp at a time walks a chain of ~19
+// The same for N independent arguments, step by step side by side: a wave that evaluates one exp at a time walks a chain of ~17
 // dependent fp64 operations at their full latency (k_kcross at three waves per SIMD kept the vector pipes 66 % busy, and a cheaper
 // exp changed nothing: latency, not issue); N chains interleaved in the source give the scheduler N operations in flight.
 // Element for element the operations of exp_nonpos: same bits.
@@ -49,7 +55,7 @@ __device__ __forceinline__ void exp_nonpos_n(const double (&xin)[N], double (&ou
 #pragma unroll
     for (int u = 0; u < N; ++u) q[u] = EXP_C[3];
 #pragma unroll
-    for (int k = 4; k <= 14; ++k)
+    for (int k = 4; k <= 12; ++k)
 #pragma unroll
         for (int u = 0; u < N; ++u) q[u] = fma(q[u], r[u], EXP_C[k]);
 #pragma unroll

@@ -130,7 +130,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     gpb_dist_finalize(ctx);
     free(ctx->h_theta);
     dev_free(&ctx->lr_R); dev_free(&ctx->lr_v0);
-    dev_free(&ctx->xmean); dev_free(&ctx->muS); dev_free(&ctx->Xc); dev_free(&ctx->dnorm); dev_free(&ctx->gpform); dev_free(&ctx->gpN); dev_free(&ctx->gpmap);
+    dev_free(&ctx->xmean); dev_free(&ctx->muS); dev_free(&ctx->Xc); dev_free(&ctx->dnorm); dev_free(&ctx->gpform); dev_free(&ctx->kmtiles); dev_free(&ctx->gpN); dev_free(&ctx->gpmap);
     dev_free(&ctx->X); dev_free(&ctx->Xsc); dev_free(&ctx->ls); dev_free(&ctx->amp); dev_free(&ctx->noise);
     dev_free(&ctx->Z); dev_free(&ctx->K); dev_free(&ctx->Linv); dev_free(&ctx->LinvT); dev_free(&ctx->T); dev_free(&ctx->yv);
     dev_free(&ctx->alpha); dev_free(&ctx->apart); dev_free(&ctx->info); dev_free(&ctx->lmlbuf);
@@ -221,6 +221,8 @@ static int gp_set_impl(gpb_ctx* ctx, int64_t P, int64_t d, const int64_t* N_p, c
     if ((rc = dev_alloc(ctx, &ctx->gpN, P))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->gpmap, P))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->gpform, P))) return rc;
+    const int64_t nb64 = ctx->Np / 64;
+    if ((rc = dev_alloc(ctx, &ctx->kmtiles, nb64 * (nb64 + 1)))) return rc;
     free(ctx->h_theta);
     ctx->h_theta = (double*)calloc((size_t)(P * (d + 2)), sizeof(double));
     std::vector<double> xp((size_t)(PX * Np * dpad), 0.0), zp((size_t)(P * Np), 0.0), xm((size_t)(PX * dpad), 0.0);
@@ -251,6 +253,14 @@ static int gp_set_impl(gpb_ctx* ctx, int64_t P, int64_t d, const int64_t* N_p, c
     ctx->h_map.clear();
     ctx->n_diff = 0;
     GPB_HIP(hipMemset(ctx->gpform, 0, sizeof(int) * P));
+    {   // the tiles of the lower block triangle, row by row (k_kmat_mfma's 1-D grid: the index arithmetic — a double sqrt and
+        // its integer fix-ups per workgroup — was 5-9 % of that kernel's time, tools/micro/kmat_lab.hip)
+        std::vector<int> tl;
+        tl.reserve((size_t)(nb64 * (nb64 + 1)));
+        for (int bi = 0; bi < (int)nb64; ++bi)
+            for (int bj = 0; bj <= bi; ++bj) { tl.push_back(bi); tl.push_back(bj); }
+        GPB_HIP(hipMemcpy(ctx->kmtiles, tl.data(), sizeof(int) * tl.size(), hipMemcpyHostToDevice));
+    }
     GPB_HIP(hipMemcpy(ctx->gpN, ctx->h_N.data(), sizeof(int) * P, hipMemcpyHostToDevice));
     GPB_HIP(hipMemcpy(ctx->xmean, xm.data(), sizeof(double) * xm.size(), hipMemcpyHostToDevice));
     GPB_HIP(hipMemcpy(ctx->X, xp.data(), sizeof(double) * xp.size(), hipMemcpyHostToDevice));

@@ -146,11 +146,20 @@ __global__ __launch_bounds__(256) void k_kmat(const double* __restrict__ Xsc, co
 //   * the diagonal / padding logic only in the tiles that have a diagonal or padding (a uniform branch): the interior
 //     tiles are straight-line code whose 16 exponentials share their constants.
 // Bound: max(HBM write 4 Np^2 bytes per GP, fp64 VALU ~ Np^2 / 2 x (dpad + ~30) operations per GP).
+// c-free value of one pair from the MFMA's a.b and the staged row terms.  RBF: the rows carry -|a|^2 / 2, so that
+// -r^2 / 2 = a.b - (|a|^2 + |b|^2) / 2 is two additions — the bits of -0.5 * max(|a|^2 + |b|^2 - 2 a.b, 0), scaling by 2 being exact
+// — one multiplication per pair less in a kernel that runs at the package's power limit.  Matern: r^2 itself is needed.
+template <int KIND>
+__device__ __forceinline__ double kmat_pair(double ab, double si, double sj) {
+    if (KIND == GPB_KERNEL_RBF) return exp_nonpos(fmin(ab + (si + sj), 0.0));
+    return shape_fn_fast<KIND>(fmax(fma(-2.0, ab, si + sj), 0.0));
+}
+
 template <int KIND, int DPAD>
 __global__ __launch_bounds__(256) void k_kmat_mfma(const double* __restrict__ Xc, const double* __restrict__ dnorm,
                                                    const double* __restrict__ amp, const double* __restrict__ noise,
                                                    double alpha_reg, double* __restrict__ K, const GpSel sel, int64_t Np,
-                                                   const int* __restrict__ form) {
+                                                   const int* __restrict__ form, const int2* __restrict__ tiles) {
     if (form && form[blockIdx.y] != 0) return;         // a difference-form GP: k_kmat's
     const int64_t N = sel.Nq(sel.q(blockIdx.y));
     // the tile's two operand blocks (64 design rows x DPAD each, contiguous in Xc) are staged in LDS by coalesced 16-byte
@@ -159,12 +168,10 @@ __global__ __launch_bounds__(256) void k_kmat_mfma(const double* __restrict__ Xc
     constexpr int LDX = DPAD + 1;
     __shared__ double sXi[64 * LDX], sXj[64 * LDX], sdi[64], sdj[64];
     const int p = blockIdx.y;
-    // tile t of the lower block triangle, row by row: t = bi (bi + 1) / 2 + bj, bj <= bi
-    const int64_t t = blockIdx.x;
-    int64_t bi = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while (bi * (bi + 1) / 2 > t) --bi;
-    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-    const int64_t bj = t - bi * (bi + 1) / 2;
+    // tile t of the lower block triangle, row by row: t = bi (bi + 1) / 2 + bj, bj <= bi — from the context's table (one scalar
+    // load; solving for bi with a double sqrt and integer fix-ups in every workgroup cost 9 % of the kernel at N = 4096)
+    const int2 tl = tiles[blockIdx.x];
+    const int64_t bi = tl.x, bj = tl.y;
     const int64_t i0 = bi * 64, j0 = bj * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = (wave >> 1) * 32, n0 = (wave & 1) * 32, lr = lane & 15, lk = lane >> 4;
@@ -180,8 +187,9 @@ __global__ __launch_bounds__(256) void k_kmat_mfma(const double* __restrict__ Xc
             sXi[r * LDX + k] = vi.x; sXi[r * LDX + k + 1] = vi.y;
             sXj[r * LDX + k] = vj.x; sXj[r * LDX + k + 1] = vj.y;
         }
-        if (tid < 64) sdi[tid] = dn[i0 + tid];
-        else if (tid < 128) sdj[tid - 64] = dn[j0 + tid - 64];
+        constexpr double RS = KIND == GPB_KERNEL_RBF ? -0.5 : 1.0;      // see kmat_pair
+        if (tid < 64) sdi[tid] = RS * dn[i0 + tid];
+        else if (tid < 128) sdj[tid - 64] = RS * dn[j0 + tid - 64];
     }
     __syncthreads();
     constexpr int KG = DPAD / 4;
@@ -214,10 +222,9 @@ __global__ __launch_bounds__(256) void k_kmat_mfma(const double* __restrict__ Xc
             for (int b = 0; b < 2; ++b) {
                 const double dj = sdj[n0 + 16 * b + lr];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double r2 = fmax(fma(-2.0, acc[a][b][r], sdi[m0 + 16 * a + lk + 4 * r] + dj), 0.0);
-                    Kp[(i0 + m0 + 16 * a + lk + 4 * r) * Np + j0 + n0 + 16 * b + lr] = c * shape_fn_fast<KIND>(r2);
-                }
+                for (int r = 0; r < 4; ++r)
+                    Kp[(i0 + m0 + 16 * a + lk + 4 * r) * Np + j0 + n0 + 16 * b + lr] =
+                        c * kmat_pair<KIND>(acc[a][b][r], sdi[m0 + 16 * a + lk + 4 * r], dj);
                 __builtin_amdgcn_sched_barrier(0);      // four evaluations in flight, not sixteen: registers for occupancy
             }
         return;
@@ -231,11 +238,10 @@ __global__ __launch_bounds__(256) void k_kmat_mfma(const double* __restrict__ Xc
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t i = i0 + m0 + 16 * a + lk + 4 * r, j = j0 + n0 + 16 * b + lr;
-                const double r2 = fmax(fma(-2.0, acc[a][b][r], sdi[m0 + 16 * a + lk + 4 * r] + dj), 0.0);
                 double v;
                 if (i >= N || j >= N) v = (i == j) ? 1.0 : 0.0;
                 else if (i == j) v = dg;
-                else v = c * shape_fn_fast<KIND>(r2);
+                else v = c * kmat_pair<KIND>(acc[a][b][r], sdi[m0 + 16 * a + lk + 4 * r], dj);
                 Kp[i * Np + j] = v;
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -248,7 +254,8 @@ static void launch_kmat_mfma(gpb_ctx* ctx) {
     dim3 grid((unsigned)(nb * (nb + 1) / 2), (unsigned)ctx->P);
 #define GPB_KM(DP)                                                                                                  \
     hipLaunchKernelGGL((k_kmat_mfma<KIND, DP>), grid, dim3(256), 0, ctx->stream, ctx->Xc, ctx->dnorm, ctx->amp,     \
-                       ctx->noise, ctx->alpha_reg, ctx->K, ctx->sel(), ctx->Np, ctx->n_diff > 0 ? ctx->gpform : nullptr)
+                       ctx->noise, ctx->alpha_reg, ctx->K, ctx->sel(), ctx->Np, ctx->n_diff > 0 ? ctx->gpform : nullptr,     \
+                       reinterpret_cast<const int2*>(ctx->kmtiles))
     switch (ctx->dpad) {
         case 8: GPB_KM(8); break;
         case 16: GPB_KM(16); break;

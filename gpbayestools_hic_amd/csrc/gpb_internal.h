@@ -69,6 +69,7 @@ struct gpb_ctx {
     std::vector<double> h_ext;     // host [d] column extents (max - min) of the design; multi: [Pstore][d]
     std::vector<int> h_form;       // host [P]
     int* gpform = nullptr;         // device [P]
+    int* kmtiles = nullptr;        // device [Np/64 (Np/64 + 1) / 2][2]: (row block, column block) of tile t of the lower block triangle (k_kmat_mfma)
     int n_diff = 0;                // GPs in the difference form
     double gram_limit = 1024.0;    // S above this: difference form (r^2 within ~1e-13 absolute, K within ~2e-13, below it)
     double* ls = nullptr;          // [P][dpad]    length scales (1 in pad columns)
