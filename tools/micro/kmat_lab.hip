@@ -619,6 +619,102 @@ __global__ __launch_bounds__(320, WPE) void k_v7(const double* __restrict__ Xc, 
     }
 }
 
+// ---- V8: a 128 x 128 macro tile per workgroup: both operand blocks (128 rows each) staged once, the four 64 x 64 sub-tiles one
+// after the other (three on the diagonal) — half the operand loads per pair of V5
+template <int KIND, int DPAD, int WPE>
+__global__ __launch_bounds__(256, WPE) void k_v8(const double* __restrict__ Xc, const double* __restrict__ dnorm,
+                                                 const double* __restrict__ amp, double* __restrict__ K, int64_t N, int64_t Np,
+                                                 const int2* __restrict__ tiles) {
+    constexpr int LDX = DPAD + 1;
+    __shared__ double sXi[128 * LDX], sXj[128 * LDX], sdi[128], sdj[128];
+    const int p = blockIdx.y;
+    const int2 tl = tiles[blockIdx.x];
+    const int64_t Bi = tl.x, Bj = tl.y;                 // 128-row blocks, Bj <= Bi
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = (wave >> 1) * 32, n0 = (wave & 1) * 32, lr = lane & 15, lk = lane >> 4;
+    const double* Xp = Xc + (int64_t)p * Np * DPAD;
+    const double* dn = dnorm + (int64_t)p * Np;
+    {
+        const d2* gi = reinterpret_cast<const d2*>(Xp + Bi * 128 * DPAD);
+        const d2* gj = reinterpret_cast<const d2*>(Xp + Bj * 128 * DPAD);
+#pragma unroll
+        for (int e = tid; e < 128 * DPAD / 2; e += 256) {
+            const int r = (2 * e) / DPAD, k = 2 * e - r * DPAD;
+            const d2 vi = gi[e], vj = gj[e];
+            sXi[r * LDX + k] = vi.x; sXi[r * LDX + k + 1] = vi.y;
+            sXj[r * LDX + k] = vj.x; sXj[r * LDX + k + 1] = vj.y;
+        }
+        if (tid < 128) sdi[tid] = dn[Bi * 128 + tid];
+        else sdj[tid - 128] = dn[Bj * 128 + tid - 128];
+    }
+    __syncthreads();
+    constexpr int KG = DPAD / 4;
+    const double c = amp[p];
+    double* Kp = K + (int64_t)p * Np * Np;
+#pragma unroll 1
+    for (int sub = 0; sub < 4; ++sub) {
+        const int si = sub >> 1, sj = sub & 1;
+        const int64_t bi = 2 * Bi + si, bj = 2 * Bj + sj;
+        if (bj > bi) continue;                          // above the diagonal: nothing reads it
+        const int64_t i0 = bi * 64, j0 = bj * 64;
+        const double* xi = sXi + si * 64 * LDX;
+        const double* xj = sXj + sj * 64 * LDX;
+        d4 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            double fa[2], fb[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                fa[a] = xi[(m0 + 16 * a + lr) * LDX + 4 * g + lk];
+                fb[a] = xj[(n0 + 16 * a + lr) * LDX + 4 * g + lk];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+        const double* di = sdi + si * 64;
+        const double* dj_ = sdj + sj * 64;
+        const bool special = bi == bj || i0 + 64 > N;
+        if (!special) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const double dj = dj_[n0 + 16 * b + lr];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double r2 = fmax(fma(-2.0, acc[a][b][r], di[m0 + 16 * a + lk + 4 * r] + dj), 0.0);
+                        Kp[(i0 + m0 + 16 * a + lk + 4 * r) * Np + j0 + n0 + 16 * b + lr] = c * shape_fn_fast<KIND>(r2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const double dj = dj_[n0 + 16 * b + lr];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t i = i0 + m0 + 16 * a + lk + 4 * r, j = j0 + n0 + 16 * b + lr;
+                        const double r2 = fmax(fma(-2.0, acc[a][b][r], di[m0 + 16 * a + lk + 4 * r] + dj), 0.0);
+                        double v;
+                        if (i >= N || j >= N) v = (i == j) ? 1.0 : 0.0;
+                        else if (i == j) v = c + 0.1;
+                        else v = c * shape_fn_fast<KIND>(r2);
+                        Kp[i * Np + j] = v;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+    }
+}
+
 // ---- store-only with the stores spread in time, as a kernel that computes between them does: after every group of four store
 // instructions a wave sleeps ~SLEEP x 64 cycles.  PAT 0: MFMA layout over 64 x 64; PAT 3: 32 x 128 tile, 1 KB row pieces;
 // PAT 4: 16 x 256 tile, 2 KB row pieces (each wave: 4 rows)
@@ -775,6 +871,24 @@ static void run(int64_t N, int P, int reps) {
             for (int64_t i = 0; i < Np; ++i) for (int64_t j = 0; j <= i; ++j) bad += h0[i * Np + j] != h1[i * Np + j];
             printf("      V7 lower-triangle elements that are not V0's: %zu (meaningful when V0 ran in this process)\n", bad);
         }
+    }
+    if (nb % 2 == 0) {
+        const int nb2 = nb / 2;
+        std::vector<int2> tl;
+        for (int bi = 0; bi < nb2; ++bi) for (int bj = 0; bj <= bi; ++bj) tl.push_back(int2{bi, bj});
+        int2* dtab2; hipMalloc(&dtab2, tl.size() * sizeof(int2));
+        hipMemcpy(dtab2, tl.data(), tl.size() * sizeof(int2), hipMemcpyHostToDevice);
+        const dim3 g8((unsigned)tl.size(), (unsigned)P);
+        hipMemset(K1, 0, (size_t)P * Np * Np * 8);
+        REPORT("V8 128x128 macro tile", [&] { hipLaunchKernelGGL((k_v8<KIND, DP, 3>), g8, dim3(256), 0, 0, X, dn, amp, K1, N, Np, dtab2); }, reps);
+        if (!g_only) {
+            hipMemcpy(h1.data(), K1 + (size_t)(P - 1) * Np * Np, h1.size() * 8, hipMemcpyDeviceToHost);
+            hipMemcpy(h0.data(), K0 + (size_t)(P - 1) * Np * Np, h0.size() * 8, hipMemcpyDeviceToHost);
+            size_t bad = 0;
+            for (int64_t i = 0; i < Np; ++i) for (int64_t j = 0; j <= i; ++j) if ((i / 64) >= (j / 64)) bad += h0[i * Np + j] != h1[i * Np + j];
+            printf("      V8 lower-triangle elements that are not V0's: %zu\n", bad);
+        }
+        hipFree(dtab2);
     }
     REPORT("V5m3 no loads, no shape (MFMA + stores)", [&] { hipLaunchKernelGGL((k_v5<KIND, DP, 3, 5>), g0, dim3(256), 0, 0, X, dn, amp, K1, N, Np, dtab); }, reps);
     REPORT("V5m4 no MFMA, no shape (loads + stores)", [&] { hipLaunchKernelGGL((k_v5<KIND, DP, 4, 5>), g0, dim3(256), 0, 0, X, dn, amp, K1, N, Np, dtab); }, reps);
