@@ -370,9 +370,13 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=None)
     args = ap.parse_args()
 
-    if os.environ.get("GPB_BENCH_WATCHDOG"):            # a stalled rank says where: every thread's stack after N seconds (then
-        import faulthandler, signal                     # exit), and on the launcher's SIGTERM to the ranks that were waiting for it
-        faulthandler.dump_traceback_later(float(os.environ["GPB_BENCH_WATCHDOG"]), exit=True)
+    # A stalled rank says where: every thread's stack after N seconds (then exit, so that the launcher ends the others), and on
+    # the launcher's SIGTERM to the ranks that were waiting for it.  GPB_BENCH_WATCHDOG=N sets N, 0 switches it off; a multi-rank
+    # run has it on by default (20 minutes: many times what any --gpus N line takes) — a failed line with stacks, never a hang.
+    wd = os.environ.get("GPB_BENCH_WATCHDOG", "1200" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "0")
+    if float(wd) > 0:
+        import faulthandler, signal
+        faulthandler.dump_traceback_later(float(wd), exit=True)
         faulthandler.register(signal.SIGTERM, chain=True)
     import torch
     import torch.distributed as dist
