@@ -38,6 +38,8 @@ def build_native(force=False, verbose=False, debug_variants=False):
         # include/gpbayes_debug.h — nothing of the C++ inside
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-c",
                os.path.join(CSRC, src), "-o", obj] + (["-DGPB_DEBUG_VARIANTS"] if debug_variants else [])
+        if debug_variants:
+            cmd += os.environ.get("GPB_DEBUG_EXTRA_DEFINES", "").split()      # A/B builds of the debug library only
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -15,6 +15,13 @@
 #include "fast_math.h"
 #include <math.h>
 
+// the K*^T store of k_kcross: with the streaming hint (global_store ... nt).  K*^T is written once and read back by k_predict; its
+// lines need not push the design rows and alpha out of the L2 while the kernel runs.  A/B against plain stores in one process and
+// bench against bench (profiles/r04_nt_store_ab.txt): k_kcross a few us faster, k_predict unchanged (1.3152 -> 1.3136 ms),
+// the step 0.4 % shorter at cfg 4 and 0.5 % at cfg 3; same bits.  (The same hint on K(X,X) makes the K build 2-11 % faster and
+// the Cholesky that reads K next slower by more: not taken there.)
+#define GPB_KSTAR_STORE(p, v) __builtin_nontemporal_store((v), (p))
+
 namespace gpb {
 
 template <int KIND>
@@ -197,7 +204,7 @@ __device__ __forceinline__ void kcross_body(KxLds<DPAD, WPL>& L, const double* _
                 }
             }
 #pragma unroll
-            for (int u = 0; u < WPL; ++u) Kp[n * Wld + w0 + lane + 64 * u] = kv[u];
+            for (int u = 0; u < WPL; ++u) GPB_KSTAR_STORE(&Kp[n * Wld + w0 + lane + 64 * u], kv[u]);
         }
         // red: written here, read by wave 0 below; the next write is behind the two barriers at the top of the loop
 #pragma unroll

@@ -199,6 +199,102 @@ __global__ __launch_bounds__(256, WPE) void k_v5(const double* __restrict__ Xc, 
         }
 }
 
+// ---- V9: V5 with non-temporal stores (MODE 0), non-temporal operand loads (MODE 5) or both (MODE 6)
+template <int KIND, int DPAD, int MODE, int WPE>
+__global__ __launch_bounds__(256, WPE) void k_v9(const double* __restrict__ Xc, const double* __restrict__ dnorm,
+                                            const double* __restrict__ amp, double* __restrict__ K, int64_t N, int64_t Np,
+                                            const int2* __restrict__ tiles) {
+    constexpr int LDX = DPAD + 1;
+    __shared__ double sXi[64 * LDX], sXj[64 * LDX], sdi[64], sdj[64];
+    const int p = blockIdx.y;
+    const int2 tl = tiles[blockIdx.x];
+    const int64_t bi = tl.x, bj = tl.y;
+    const int64_t i0 = bi * 64, j0 = bj * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = (wave >> 1) * 32, n0 = (wave & 1) * 32, lr = lane & 15, lk = lane >> 4;
+    const double* Xp = Xc + (int64_t)p * Np * DPAD;
+    const double* dn = dnorm + (int64_t)p * Np;
+    {
+        const d2* gi = reinterpret_cast<const d2*>(Xp + i0 * DPAD);
+        const d2* gj = reinterpret_cast<const d2*>(Xp + j0 * DPAD);
+#pragma unroll
+        for (int e = tid; e < 64 * DPAD / 2; e += 256) {
+            const int r = (2 * e) / DPAD, k = 2 * e - r * DPAD;
+            d2 vi, vj;
+            if (MODE == 3) { vi = d2{1e-3 * e, 1.0}; vj = d2{0.5, 2e-3 * e}; }      // MODE 3: no global loads
+            else if (MODE >= 5) {
+                vi.x = __builtin_nontemporal_load(&gi[e].x); vi.y = __builtin_nontemporal_load(&gi[e].y);
+                vj.x = __builtin_nontemporal_load(&gj[e].x); vj.y = __builtin_nontemporal_load(&gj[e].y);
+            } else { vi = gi[e]; vj = gj[e]; }
+            sXi[r * LDX + k] = vi.x; sXi[r * LDX + k + 1] = vi.y;
+            sXj[r * LDX + k] = vj.x; sXj[r * LDX + k + 1] = vj.y;
+        }
+        if (MODE == 3) { if (tid < 64) sdi[tid] = tid; else if (tid < 128) sdj[tid - 64] = tid; }
+        else if (tid < 64) sdi[tid] = dn[i0 + tid];
+        else if (tid < 128) sdj[tid - 64] = dn[j0 + tid - 64];
+    }
+    __syncthreads();
+    constexpr int KG = DPAD / 4;
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+        double fa[2], fb[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            fa[a] = sXi[(m0 + 16 * a + lr) * LDX + 4 * g + lk];
+            fb[a] = sXj[(n0 + 16 * a + lr) * LDX + 4 * g + lk];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (MODE == 4) { if (g == 0) acc[a][b] = d4{fa[a], fb[b], fa[a] + fb[b], fa[a] - fb[b]}; }      // MODE 4: no MFMA
+                else acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            }
+    }
+    const double c = amp[p];
+    double* Kp = K + (int64_t)p * Np * Np;
+    const bool special = bi == bj || i0 + 64 > N;
+    if (!special) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const double dj = sdj[n0 + 16 * b + lr];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double r2 = fmax(fma(-2.0, acc[a][b][r], sdi[m0 + 16 * a + lk + 4 * r] + dj), 0.0);
+                    const double v = (MODE >= 2) ? r2 : c * shape_fn_fast<KIND>(r2);
+                    if (MODE != 5) __builtin_nontemporal_store(v, &Kp[(i0 + m0 + 16 * a + lk + 4 * r) * Np + j0 + n0 + 16 * b + lr]);
+                    else Kp[(i0 + m0 + 16 * a + lk + 4 * r) * Np + j0 + n0 + 16 * b + lr] = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const double dj = sdj[n0 + 16 * b + lr];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t i = i0 + m0 + 16 * a + lk + 4 * r, j = j0 + n0 + 16 * b + lr;
+                const double r2 = fmax(fma(-2.0, acc[a][b][r], sdi[m0 + 16 * a + lk + 4 * r] + dj), 0.0);
+                double v;
+                if (i >= N || j >= N) v = (i == j) ? 1.0 : 0.0;
+                else if (i == j) v = c + 0.1;
+                else v = (MODE >= 2) ? r2 : c * shape_fn_fast<KIND>(r2);
+                if (MODE != 1 || v == 12345.678) Kp[i * Np + j] = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
 // ---- strips ---------------------------------------------------------------------------------------------------------
 // chunk c of the lower block triangle: row block bi, column blocks [TJ q, min(TJ q + TJ, bi + 1)); chunks numbered row by row
 template <int KIND, int DPAD, int GROUP>
@@ -890,6 +986,9 @@ static void run(int64_t N, int P, int reps) {
         }
         hipFree(dtab2);
     }
+    REPORT("V9 non-temporal stores", [&] { hipLaunchKernelGGL((k_v9<KIND, DP, 0, 5>), g0, dim3(256), 0, 0, X, dn, amp, K1, N, Np, dtab); }, reps);
+    REPORT("V9m5 non-temporal loads", [&] { hipLaunchKernelGGL((k_v9<KIND, DP, 5, 5>), g0, dim3(256), 0, 0, X, dn, amp, K1, N, Np, dtab); }, reps);
+    REPORT("V9m6 non-temporal loads and stores", [&] { hipLaunchKernelGGL((k_v9<KIND, DP, 6, 5>), g0, dim3(256), 0, 0, X, dn, amp, K1, N, Np, dtab); }, reps);
     REPORT("V5m3 no loads, no shape (MFMA + stores)", [&] { hipLaunchKernelGGL((k_v5<KIND, DP, 3, 5>), g0, dim3(256), 0, 0, X, dn, amp, K1, N, Np, dtab); }, reps);
     REPORT("V5m4 no MFMA, no shape (loads + stores)", [&] { hipLaunchKernelGGL((k_v5<KIND, DP, 4, 5>), g0, dim3(256), 0, 0, X, dn, amp, K1, N, Np, dtab); }, reps);
     REPORT("V5 no shape fn (MFMA + stores)", [&] { hipLaunchKernelGGL((k_v5<KIND, DP, 2, 5>), g0, dim3(256), 0, 0, X, dn, amp, K1, N, Np, dtab); }, reps);
