@@ -26,6 +26,14 @@
 #include <math.h>
 #include <vector>
 
+// the trailing matrix's tile of k_chol_update / k_chol_update2 is read once and written once per step: the write carries the
+// streaming hint (global_store ... nt), so that it does not push the step's operand blocks — shared by a whole row / column of
+// tiles — out of the L2.  A/B in one process (tools/micro/fit_ab.py, profiles/r04_nt_store_ab.txt): Cholesky 0.7-1.1 % shorter at
+// N = 1024 .. 2048, unchanged at 3072 / 4096; the hint on the READ of the tile as well: -3 % at N = 1024 and 3072 but +1.6 % at 1536;
+// on the read alone: +1.5 .. +3 % at N <= 1536 — not taken.
+#define GPB_C_LOAD(p) (*(p))
+#define GPB_C_STORE(p, v) __builtin_nontemporal_store((v), (p))
+
 namespace gpb {
 
 namespace {
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(CHOL_THREADS, 4) void k_chol_update(double* __restr
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) c[tt][r] = Cp[(int64_t)(m0 + 16 * tt + lk + 4 * r) * Np + n0 + lr];
+        for (int r = 0; r < 4; ++r) c[tt][r] = GPB_C_LOAD(&Cp[(int64_t)(m0 + 16 * tt + lk + 4 * r) * Np + n0 + lr]);
     __syncthreads();
     d4 acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
     mma_nt_64(s.a, i != j ? s.x : s.a, acc, wave, lane);
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(CHOL_THREADS, 4) void k_chol_update(double* __restr
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Cp[(int64_t)(m0 + 16 * tt + lk + 4 * r) * Np + n0 + lr] = c[tt][r] - acc[tt][r];
+            for (int r = 0; r < 4; ++r) GPB_C_STORE(&Cp[(int64_t)(m0 + 16 * tt + lk + 4 * r) * Np + n0 + lr], c[tt][r] - acc[tt][r]);
         return;
     }
     __syncthreads();                                   // every wave is done reading the operand tile in s.a
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(CHOL_THREADS, 4) void k_chol_update2(double* __rest
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) c[tt][r] = Cp[(int64_t)(m0 + 16 * tt + lk + 4 * r) * Np + n0 + lr];
+        for (int r = 0; r < 4; ++r) c[tt][r] = GPB_C_LOAD(&Cp[(int64_t)(m0 + 16 * tt + lk + 4 * r) * Np + n0 + lr]);
     __syncthreads();
     d4 acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
     mma_nt_64(s.a, diag ? s.a : s.x, acc, wave, lane);
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(CHOL_THREADS, 4) void k_chol_update2(double* __rest
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Cp[(int64_t)(m0 + 16 * tt + lk + 4 * r) * Np + n0 + lr] = c[tt][r] - acc[tt][r];
+            for (int r = 0; r < 4; ++r) GPB_C_STORE(&Cp[(int64_t)(m0 + 16 * tt + lk + 4 * r) * Np + n0 + lr], c[tt][r] - acc[tt][r]);
         return;
     }
     __syncthreads();                                   // every wave is done reading the operand tile in s.a
