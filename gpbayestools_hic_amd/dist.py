@@ -210,13 +210,24 @@ class WalkerSharding:
         W = X.shape[0]
         r0, r1, chunk = self.rows(W)
         if self.world > 1 and X.is_cuda and self.dist.get_backend(self.group) == "gloo":
-            # rehearsal only (several ranks sharing one GPU, gloo has no CUDA all-gather): stage through the host
-            local = torch.zeros(chunk, dtype=out.dtype, device=X.device)
+            # rehearsal only (several ranks sharing one GPU, gloo has no CUDA all-gather): stage through PINNED host buffers with
+            # stream-ordered copies and one stream synchronisation — the blocking pageable copies this branch used before
+            # (local.cpu(), out.copy_(host tensor)) are where two of four ranks once stalled for good while six processes held
+            # the GPU (profiles/r04_ranks_stall.txt)
+            key = ("gloo", chunk, X.device, out.dtype)
+            if key not in self._buf:
+                self._buf[key] = (torch.zeros(chunk, dtype=out.dtype, device=X.device),
+                                  torch.empty(chunk, dtype=out.dtype).pin_memory(),
+                                  torch.empty(chunk * self.world, dtype=out.dtype).pin_memory())
+            local, mine_h, gathered = self._buf[key]
+            if r1 < r0 + chunk:
+                local.zero_()
             if r1 > r0:
                 fn(X[r0:r1], local[:r1 - r0])
-            gathered = torch.empty(chunk * self.world, dtype=out.dtype)
-            self.dist.all_gather_into_tensor(gathered, local.cpu(), group=self.group)
-            out.copy_(gathered[:W])
+            mine_h.copy_(local, non_blocking=True)
+            torch.cuda.current_stream(X.device).synchronize()      # (also: the previous call's copy out of `gathered` is done)
+            self.dist.all_gather_into_tensor(gathered, mine_h, group=self.group)
+            out.copy_(gathered[:W], non_blocking=True)
             return out
         if (self.world > 1 or self.direct is not None) and W == chunk * self.world and out.is_contiguous():
             # even split: every rank writes its slice of `out` and the all-gather runs in place
