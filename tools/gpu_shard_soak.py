@@ -4,7 +4,8 @@ library's loopback communicator (everything of the multi-GPU loop but the wire) 
 random R 2..8, ensemble sizes with nw / 2 a multiple of R (the resident loop's condition; other sizes take the host-driven loop), random emulator shapes, walkers at the edge of the box (compacted batches,
 ragged shares, ranks without a live row), both balance modes.  A test tool (debug library).  usage: gpu_shard_soak.py [cases=30] [seed=0]"""
 import json, os, sys, tempfile, time
-os.environ.setdefault("GPB_DEBUG_LIB", "1")
+if __name__ == "__main__":                           # (imported by tests/test_gpu_soak.py under its debug_lib fixture instead)
+    os.environ.setdefault("GPB_DEBUG_LIB", "1")
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
