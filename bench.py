@@ -107,6 +107,59 @@ def extras(chain4, emu4, info4):
                                         "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS, "frac": tf / FP64_MFMA_PEAK_TFLOPS,
                                         "what": "k_predict on 2048-row batches with every row inside the prior box "
                                                 "(algorithmic flops N^2 per (GP, row))"}
+    # The SUSTAINED rate of the headline's loop (a production chain is thousands of steps, src/mcmc.py:372-412; the headline's
+    # timed region is 20 steps behind a 100-step pre-heat: a burst).  >= 5.5 s of continuous stretch-move steps through
+    # gpb_chain_emcee_run — propose, 2048-row log-posterior batch, accept, twice per step — in blocks of 40 steps; after each
+    # block the ensemble goes back to the same burnt-in ball (two device copies), so that over the whole run every proposal
+    # row lies inside the prior box and every block does the same work.  Per block: wall time and the HIP-event time of its
+    # k_predict launches; the whole-loop rate counts everything between the first block's start and the last block's end.
+    from gpbayestools_hic_amd.sampler import StretchSampler
+    nw4, blk = 2 * info4["W"], 40
+    ball4 = float(min(1e-3, max(1e-13, 10.0 ** (-3.0 - 0.16 * (blk + 3)))))
+    X04 = synth.walkers_ball(nw4, info4["xstar"], ball4, lo=info4["lo"], hi=info4["hi"])
+    ss = StretchSampler(chain4, nw4, seed=2468)
+    assert ss._resident_engine() is not None
+    ss.run(X04, 0, status=10 ** 9, store=False)
+    snap = ss._snapshot()
+    ss.run(None, blk, status=10 ** 9, store=False)
+    ss._restore(snap)
+    torch.cuda.synchronize()
+    blocks = []
+    eng4.profile(True)
+    t_start = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        ss.run(None, blk, status=10 ** 9, store=False)          # (ends in one synchronisation: the NaN counter's read-out)
+        ss._restore(snap)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_l, ms_l, u_l = eng4.profile_read()
+        blocks.append((t1 - t0, ms_l / max(n_l, 1), u_l / max(n_l, 1), n_l))
+        if t1 - t_start >= 5.5 or len(blocks) >= 400:
+            break
+    t_all = time.perf_counter() - t_start
+    eng4.profile(False)
+    del ss
+    fr = lambda b: b[2] * float(info4["N"]) ** 2 / (b[1] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS
+    us = [b[1] * 1e3 for b in blocks]
+    rows_in = sum(b[2] * b[3] for b in blocks) / (sum(b[3] for b in blocks) * info4["P"] * (nw4 // 2))
+    tail = blocks[-max(len(blocks) // 4, 1):]
+    out["sustained_cfg4"] = {
+        "seconds": t_all, "steps": blk * len(blocks), "blocks": len(blocks), "steps_per_block": blk, "walkers": nw4,
+        "walker_evals_per_s": nw4 * blk * len(blocks) / t_all,
+        "ms_per_step": t_all / (blk * len(blocks)) * 1e3,
+        "ms_per_step_first_block": blocks[0][0] / blk * 1e3, "ms_per_step_last_quarter": sum(b[0] for b in tail) / (blk * len(tail)) * 1e3,
+        "rows_inside_box_fraction": rows_in,
+        "k_predict_us_per_launch": {"first_block": us[0], "last_block": us[-1], "min": min(us), "max": max(us),
+                                    "median": sorted(us)[len(us) // 2],
+                                    "by_block": [round(u, 1) for u in us[::max(len(us) // 24, 1)]]},
+        "k_predict_frac_of_peak": {"first_block": fr(blocks[0]), "last_block": fr(blocks[-1]),
+                                   "last_quarter": sum(fr(b) for b in tail) / len(tail)},
+        "what": "continuous stretch-move steps of the headline configuration through gpb_chain_emcee_run for >= 5.5 s, in blocks "
+                "of 40 steps from the same burnt-in ball (every proposal row inside the prior box and evaluated); whole-loop "
+                "rate = walkers x steps / wall time over all blocks incl. the two device copies that reset the ensemble; "
+                "k_predict: HIP-event time per launch, by block (algorithmic flops N^2 per (GP, row))"}
+
     _, emu2, info2 = build_chain(2)
     eng2 = emu2._engine_ready()
     Xs = torch.as_tensor(synth.walkers(10000, info2["d"]), device="cuda")
@@ -145,6 +198,20 @@ def extras(chain4, emu4, info4):
                   c5["kernel"], 0.1)
     eng5.set_theta(synth.fixed_theta(c5["d"], c5["P"]))
     out["fit_fixed_theta_cfg5"] = fit_entry(eng5, c5["N"], c5["P"], c5["kernel"])
+
+    # the regime train_emulators itself factors in: the 63 GPs of nine emulators (each over its own 1000-point design, all padded
+    # to Np = 1024) side by side on ONE gpb_gp_set_multi context — 63 matrices per launch of the Cholesky chain
+    # (src/emulator.py:309-315 for each of the nine data sets, examples/EmulatorTraining.ipynb:124-138); flops counted at N = 1000
+    nb_gp, nb_N, nb_d = 63, 1000, 20
+    engb = GPEngine(torch.cuda.current_device())
+    rngb = np.random.default_rng(7)
+    engb.set_data_multi([synth.lhs(nb_N, nb_d, seed=synth.SEED + 300 + i % 9) for i in range(nb_gp)],
+                        [rngb.standard_normal(nb_N) for _ in range(nb_gp)], "RBF", 0.1)
+    engb.set_theta(synth.fixed_theta(nb_d, nb_gp))
+    out["fit_fixed_theta_batch63"] = fit_entry(engb, nb_N, nb_gp, "RBF")
+    out["fit_fixed_theta_batch63"]["what"] += ("; 63 GPs over nine different 1000-point designs on one gpb_gp_set_multi context "
+                                                "(the batch train_emulators factors per lock-step round), Np = 1024")
+    engb.close()
 
     def k_build_entry(eng, Nn, dd, Pp, kernel):
         """K(X,X) + (noise + alpha) I of all GPs (k_kmat_mfma): the lower block triangle is all the factorisation reads.
@@ -356,6 +423,110 @@ def extras(chain4, emu4, info4):
     return out
 
 
+class Watchdog:
+    """A stalled rank says where, and a failed line is printed instead of a hang.  `arm(seconds, phase)` (re)starts the clock; when
+    it runs out the process writes to stderr (a) every Python thread's stack, (b) for every OS thread of the process its name,
+    scheduler state, the kernel function it sleeps in and the system call it is inside (/proc/self/task/*/{comm,stat,wchan,
+    syscall}: what a stack of Python frames cannot say when the wait is inside libamdhip64 or librccl), then exits with 124 so
+    that the launcher ends the other ranks.  The watcher is a Python thread (torch's copies and collectives, ctypes calls and
+    time.sleep all release the GIL); behind it faulthandler's own C thread fires 15 s later in case the GIL was never released.
+    No HIP call is made from either."""
+
+    def __init__(self, tag):
+        import threading
+        self.tag, self.deadline, self.phase = tag, None, "start"
+        self._cv = threading.Condition()
+        self._t = threading.Thread(target=self._watch, daemon=True, name="bench-watchdog")
+        self._t.start()
+
+    def arm(self, seconds, phase):
+        import faulthandler
+        with self._cv:
+            self.phase = phase
+            self.deadline = None if seconds <= 0 else time.monotonic() + seconds
+            self._cv.notify()
+        faulthandler.cancel_dump_traceback_later()
+        if seconds > 0:
+            faulthandler.dump_traceback_later(seconds + 15.0, exit=True)
+
+    def _watch(self):
+        with self._cv:
+            while True:
+                if self.deadline is None:
+                    self._cv.wait()
+                    continue
+                left = self.deadline - time.monotonic()
+                if left > 0:
+                    self._cv.wait(left)
+                    continue
+                break
+        self.dump()
+        os._exit(124)
+
+    def dump(self, out=None):
+        import faulthandler
+        out = out or sys.stderr
+        out.write("\n==== bench.py watchdog: %s made no progress in phase '%s' ====\n" % (self.tag, self.phase))
+        out.flush()
+        faulthandler.dump_traceback(file=out, all_threads=True)
+        out.write("---- OS threads of pid %d: tid comm state wchan syscall ----\n" % os.getpid())
+        try:
+            tids = sorted(os.listdir("/proc/self/task"), key=int)
+        except OSError:
+            tids = []
+        for tid in tids:
+            vals = []
+            for name in ("comm", "stat", "wchan", "syscall"):
+                try:
+                    with open("/proc/self/task/%s/%s" % (tid, name)) as f:
+                        v = f.read().strip()
+                    if name == "stat":              # "pid (comm) S ...": the state letter follows the closing bracket
+                        v = v[v.rindex(")") + 2:][:1]
+                except OSError as e:
+                    v = "<%s>" % e.strerror
+                vals.append(v or "-")
+            out.write("%s %s %s %s [%s]\n" % (tid, vals[0], vals[1], vals[2], vals[3]))
+        out.flush()
+
+
+def spawn_ranks(n, argv):
+    """`python3 bench.py --gpus N` typed bare (no torchrun around it, WORLD_SIZE unset): start the N ranks as ONE child process
+    tree — python -m torch.distributed.run on this very file with the same arguments, rendezvous on 127.0.0.1 — relay rank 0's
+    single JSON line to stdout (everything else the ranks print goes to stderr), and return the child's exit code.  This parent
+    never imports torch and never opens the GPU: nothing is exec'ed over a process that has, and the box's count of processes
+    holding the card is the N ranks alone."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), GPB_BENCH_SPAWNED="1")
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE)
+    lines = 0
+    for raw in p.stdout:
+        ln = raw.decode(errors="replace")
+        is_line = False
+        if ln.startswith("{"):
+            try:
+                is_line = "metric" in json.loads(ln)
+            except ValueError:
+                pass
+        if is_line:
+            lines += 1
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if rc == 0 and lines != 1:
+        print(f"bench.py: the {n} ranks ended with status 0 but printed {lines} result lines (expected 1)", file=sys.stderr)
+        rc = 3
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -369,14 +540,27 @@ def main():
     ap.add_argument("--no-uniform", action="store_true", help="skip the second timed run from the uniform start")
     ap.add_argument("--cpu-rows", type=int, default=None)
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
-    # A stalled rank says where: every thread's stack after N seconds (then exit, so that the launcher ends the others), and on
-    # the launcher's SIGTERM to the ranks that were waiting for it.  GPB_BENCH_WATCHDOG=N sets N, 0 switches it off; a multi-rank
-    # run has it on by default (20 minutes: many times what any --gpus N line takes) — a failed line with stacks, never a hang.
-    wd = os.environ.get("GPB_BENCH_WATCHDOG", "1200" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "0")
-    if float(wd) > 0:
+    # The launch contract.  Under a launcher (torchrun sets WORLD_SIZE) this process is one rank and WORLD_SIZE must be --gpus.
+    # Bare with --gpus N > 1 it becomes the launcher's parent (spawn_ranks) BEFORE torch is imported or the GPU touched.
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if int(env_world or "1") != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks: refusing to time a job "
+              f"whose size is not the one asked for", file=sys.stderr)
+        sys.exit(2)
+
+    # GPB_BENCH_WATCHDOG=N: seconds a phase (start-up incl. the first `import torch`, set-up, each timed run) may take; 0 = off.
+    # A multi-rank run has it on by default, at 240 s: three phases stay inside the driver's 600 s limit, so a stalled N-rank
+    # line ends as a FAILED line with every rank's stacks, never as a hang.
+    wd_s = float(os.environ.get("GPB_BENCH_WATCHDOG", "240" if args.gpus > 1 else "0"))
+    dog = Watchdog("rank %s of %d" % (os.environ.get("RANK", "0"), args.gpus))
+    dog.arm(wd_s, "start-up (import torch, rendezvous)")
+    if wd_s > 0:
         import faulthandler, signal
-        faulthandler.dump_traceback_later(float(wd), exit=True)
         faulthandler.register(signal.SIGTERM, chain=True)
     import torch
     import torch.distributed as dist
@@ -386,9 +570,9 @@ def main():
     from gpbayestools_hic_amd.workload import build_chain, flops_per_walker
 
     rank, world, local = init_from_env()
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    assert world == args.gpus
     torch.cuda.set_device(local)
+    dog.arm(min(wd_s, 120.0), "set-up (training, replication, self-checks)")
     chain, emu, info = build_chain(args.config, device=local)
     N, d, M, P = info["N"], info["d"], info["M"], info["P"]
     nwalkers = args.walkers or 2 * info["W"]
@@ -477,6 +661,7 @@ def main():
             return smp, float(mx[0].item()), launches, kms, units, float(sm[1].item())
         return smp, dt, launches, kms, units, units
 
+    dog.arm(min(wd_s, 90.0), "timed run (pre-heat, warm-up, timed steps; burnt-in start)")
     _, dt, launches, kms, units, units_all = timed_run(X0, None)
     acc = float(sampler.acceptance_fraction.mean())
     inside_frac = (units_all / (launches * P * (nwalkers // 2))) if launches else None      # all ranks' rows
@@ -489,6 +674,11 @@ def main():
         print(f"bench.py: only {inside_frac:.3f} of the timed region's proposal rows lay inside the prior box "
               f"(--steps {args.steps} --warmup {args.warmup}: more than ~60 steps in all); `value` counts evaluated "
               f"walkers only", file=sys.stderr)
+    devices_used = [local]
+    if world > 1:       # which GPU each rank ran on, as the communicator's ranks report it
+        dv = [None] * world
+        dist.all_gather_object(dv, int(local))
+        devices_used = dv
     consistent = None
     if world > 1:       # replicated RNG + gathered log-probabilities: every rank must hold the same ensemble
         chk = torch.stack([sampler.pos.sum(), sampler.lp.sum()])
@@ -510,6 +700,7 @@ def main():
     # leave the 20-dimensional box and are not evaluated
     uni = None
     if not args.no_uniform:
+        dog.arm(min(wd_s, 90.0), "timed run from the uniform start")
         su, dtu, lu, kmsu, unitsu, units_all_u = timed_run(X0_uniform, 4242)
         uni = {"value": nwalkers * args.steps / dtu, "unit": "walker-evals/s (proposals outside the box counted, not evaluated)",
                "value_evaluated": units_all_u / P / dtu, "ms_per_step": dtu / args.steps * 1e3,
@@ -521,6 +712,7 @@ def main():
                "what": "the same step loop started from walkers uniform in the prior box (SURVEY 8d's walkers)"}
         del su
 
+    dog.arm(0.0 if world == 1 else min(wd_s, 60.0), "result line")      # (extras and the CPU baseline: N = 1 only, minutes)
     if rank == 0:
         value = nwalkers * args.steps / dt if not degraded else units_all / P / dt
         alg_flops_per_launch = units / max(launches, 1) * float(N) * float(N)     # N^2 per (GP, walker): the trsm term
@@ -538,6 +730,11 @@ def main():
                                    + ("; the ensemble reached the box inside the timed region: value = evaluated walkers only"
                                       if degraded else ""), "walkers": nwalkers,
                        "parallelism": f"walker-shard x{world}" if world > 1 else "single GPU", "step_loop": loop,
+                       "ranks": dist.get_world_size() if world > 1 else 1,
+                       "devices_used": devices_used,
+                       "launched_by": "bench.py itself (bare --gpus N: child torch.distributed.run)"
+                                      if os.environ.get("GPB_BENCH_SPAWNED") == "1" else
+                                      ("an outer launcher (WORLD_SIZE set)" if world > 1 else "single process"),
                        "untimed_preheat": f"{args.preheat} steps of the same loop on a scratch ensemble before the W warm-up steps (clocks, RCCL channels)",
                        "allgather": None if world == 1 else (
                            "gpb_dist_allgather (ncclAllGather on the kernel stream)" if sharding.direct is not None

@@ -35,6 +35,7 @@ BOUNDARY = {
     "gpb_ctx_destroy": (C.c_int, [VP]),
     "gpb_ctx_set_stream": (C.c_int, [VP, VP]),
     "gpb_sync": (C.c_int, [VP]),
+    "gpb_pool_trim": (C.c_int, []),
     "gpb_last_error": (C.c_char_p, [VP]),
     "gpb_stream": (VP, [VP]),
     "gpb_gp_set": (C.c_int, [VP, c_i64, c_i64, c_i64, VP, VP, C.c_int, C.c_double]),

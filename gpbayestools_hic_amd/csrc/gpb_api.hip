@@ -17,7 +17,10 @@ namespace {
 // (through the buffer cache of gpb_pool.hip: contexts come and go with every training)
 template <typename T>
 int dev_alloc(gpb_ctx* ctx, T** p, int64_t count) {
-    if (*p) { pool_free(*p); *p = nullptr; }
+    if (*p) {        // a buffer that is replaced goes back to the cache: nothing may still be using it (callers have synchronised
+        if (ctx->side_stream) GPB_HIP(hipStreamSynchronize(ctx->side_stream));      // ctx->stream; the look-ahead stream here)
+        pool_free(*p); *p = nullptr;
+    }
     GPB_HIP(pool_malloc(reinterpret_cast<void**>(p), sizeof(T) * (size_t)(count > 0 ? count : 1)));
     return 0;
 }
@@ -36,7 +39,7 @@ int ensure_out(gpb_ctx* ctx, int64_t count) {
     if (count <= ctx->out_cap) return 0;
     GPB_HIP(hipStreamSynchronize(ctx->stream));
     dev_free(&ctx->out_stage);
-    GPB_HIP(hipMalloc(&ctx->out_stage, sizeof(double) * (size_t)count));
+    GPB_HIP(pool_malloc_t(&ctx->out_stage, sizeof(double) * (size_t)count));
     ctx->out_cap = count;
     return 0;
 }
@@ -100,13 +103,13 @@ extern "C" int gpb_ctx_create(int device, void* stream, gpb_ctx** out) {
         }
         ctx->own_stream = true;
     }
-    if (hipMalloc(&ctx->notpd, sizeof(int)) != hipSuccess ||
+    if (pool_malloc_t(&ctx->notpd, sizeof(int)) != hipSuccess ||
         hipMemsetAsync(ctx->notpd, 0, sizeof(int), ctx->stream) != hipSuccess ||
-        hipMalloc(&ctx->rows_live, sizeof(unsigned long long)) != hipSuccess ||
+        pool_malloc_t(&ctx->rows_live, sizeof(unsigned long long)) != hipSuccess ||
         hipMemsetAsync(ctx->rows_live, 0, sizeof(unsigned long long), ctx->stream) != hipSuccess ||
-        hipMalloc(&ctx->n_nan, sizeof(long long)) != hipSuccess ||
+        pool_malloc_t(&ctx->n_nan, sizeof(long long)) != hipSuccess ||
         hipMemsetAsync(ctx->n_nan, 0, sizeof(long long), ctx->stream) != hipSuccess ||
-        hipMalloc(&ctx->tile_counter, 129 * sizeof(unsigned)) != hipSuccess ||
+        pool_malloc_t(&ctx->tile_counter, 129 * sizeof(unsigned)) != hipSuccess ||
         hipMemsetAsync(ctx->tile_counter, 0, 129 * sizeof(unsigned), ctx->stream) != hipSuccess) {
         delete ctx;
         return GPB_E_ALLOC;
@@ -127,6 +130,9 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     if (!ctx) return GPB_E_ARG;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    // every stream that touched the buffers is idle BEFORE the first of them re-enters circulation through the buffer cache
+    // (the look-ahead stream of the factorisation reads and writes K and L^-1: gpb_chol.hip)
+    if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
     gpb_dist_finalize(ctx);
     free(ctx->h_theta);
     dev_free(&ctx->lr_R); dev_free(&ctx->lr_v0);
@@ -143,7 +149,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     dev_free(&ctx->n_nan); dev_free(&ctx->mc_ws); dev_free(&ctx->bal_ws); dev_free(&ctx->rows_live); dev_free(&ctx->cmp_idx); dev_free(&ctx->cmp_X);
     if (ctx->live_hint) (void)hipHostFree(ctx->live_hint);
     for (hipEvent_t e : ctx->chol_events) (void)hipEventDestroy(e);
-    if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -155,6 +161,11 @@ extern "C" int gpb_ctx_set_stream(gpb_ctx* ctx, void* stream) {
     GPB_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
     ctx->stream = reinterpret_cast<hipStream_t>(stream);      // NULL = the legacy default stream
+    return 0;
+}
+
+extern "C" int gpb_pool_trim(void) {
+    pool_trim();
     return 0;
 }
 
@@ -1065,11 +1076,11 @@ extern "C" int gpb_ctx_option(gpb_ctx* ctx, int key, int value) {
             if (value < 0 || value > 2) return GPB_E_ARG;      // 1: release + ticket per tile only; 2: and the last tile's tail
             GPB_HIP(hipSetDevice(ctx->device));
             GPB_HIP(hipStreamSynchronize(ctx->stream));
-            if (ctx->tile_trace) { (void)hipFree(ctx->tile_trace); ctx->tile_trace = nullptr; }
+            if (ctx->tile_trace) { pool_free(ctx->tile_trace); ctx->tile_trace = nullptr; }
             if (value >= 1) {
                 if (ctx->N == 0) GPB_FAIL(GPB_E_STATE, "gpb_ctx_option 46 before gpb_gp_set");
                 const size_t n = 16 + 65536;
-                GPB_HIP(hipMalloc(&ctx->tile_trace, n * sizeof(unsigned)));
+                GPB_HIP(pool_malloc_t(&ctx->tile_trace, n * sizeof(unsigned)));
                 GPB_HIP(hipMemset(ctx->tile_trace, 0, n * sizeof(unsigned)));
                 const unsigned head[5] = {0u, 0xffffffffu, (unsigned)(ctx->P * (ctx->Np / 64)), 0u, (unsigned)value};
                 GPB_HIP(hipMemcpy(ctx->tile_trace, head, sizeof(head), hipMemcpyHostToDevice));
@@ -1150,7 +1161,7 @@ extern "C" int gpb_debug_tile_trace(gpb_ctx* ctx, int64_t capacity) {
     dev_free(&ctx->tile_trace);
     if (capacity == 0) return 0;
     const size_t n = 8 + 8 * (size_t)capacity;
-    GPB_HIP(hipMalloc(&ctx->tile_trace, n * sizeof(unsigned)));
+    GPB_HIP(pool_malloc_t(&ctx->tile_trace, n * sizeof(unsigned)));
     GPB_HIP(hipMemset(ctx->tile_trace, 0, n * sizeof(unsigned)));
     const unsigned cap = (unsigned)capacity;
     GPB_HIP(hipMemcpy(ctx->tile_trace + 1, &cap, sizeof(unsigned), hipMemcpyHostToDevice));

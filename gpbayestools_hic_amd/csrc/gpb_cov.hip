@@ -89,14 +89,14 @@ int launch_predict_cov(gpb_ctx* ctx, const double* Xs_dev, int64_t W, double* co
     const int64_t need_v = P * Np * Wld, need_c = P * Wc * Wc;
     if (need_v > ctx->vbuf_cap) {
         GPB_HIP(hipStreamSynchronize(ctx->stream));
-        if (ctx->vbuf) GPB_HIP(hipFree(ctx->vbuf));
-        GPB_HIP(hipMalloc(&ctx->vbuf, need_v * sizeof(double)));
+        if (ctx->vbuf) pool_free(ctx->vbuf);
+        GPB_HIP(pool_malloc_t(&ctx->vbuf, need_v * sizeof(double)));
         ctx->vbuf_cap = need_v;
     }
     if (need_c > ctx->covbuf_cap) {
         GPB_HIP(hipStreamSynchronize(ctx->stream));
-        if (ctx->covbuf) GPB_HIP(hipFree(ctx->covbuf));
-        GPB_HIP(hipMalloc(&ctx->covbuf, need_c * sizeof(double)));
+        if (ctx->covbuf) pool_free(ctx->covbuf);
+        GPB_HIP(pool_malloc_t(&ctx->covbuf, need_c * sizeof(double)));
         ctx->covbuf_cap = need_c;
     }
     int rc = launch_predict(ctx, Xs_dev, W, false);          // K*^T and the mean

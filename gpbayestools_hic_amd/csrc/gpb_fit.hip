@@ -863,8 +863,8 @@ int launch_lml_grad(gpb_ctx* ctx, double* grad_dev) {
     const int ntiles = (int)(nt64 * (nt64 + 1) / 2);
     const int64_t need = (int64_t)ctx->P * ntiles * (ctx->d + 2);
     if (need > ctx->gpart_cap) {
-        if (ctx->gpart) GPB_HIP(hipFree(ctx->gpart));
-        GPB_HIP(hipMalloc(&ctx->gpart, need * sizeof(double)));
+        if (ctx->gpart) pool_free(ctx->gpart);
+        GPB_HIP(pool_malloc_t(&ctx->gpart, need * sizeof(double)));
         ctx->gpart_cap = need;
     }
     if (ctx->kind == GPB_KERNEL_RBF) launch_grad_kind<GPB_KERNEL_RBF>(ctx, ntiles, grad_dev);

@@ -228,6 +228,8 @@ namespace gpb {
 hipError_t pool_malloc(void** p, size_t bytes);
 void pool_free(void* p);
 void pool_trim();
+template <typename T>
+inline hipError_t pool_malloc_t(T** p, size_t bytes) { return pool_malloc(reinterpret_cast<void**>(p), bytes); }
 // fit side (gpb_fit.hip)
 int launch_scale_design(gpb_ctx* ctx);
 int choose_forms(gpb_ctx* ctx);                        // gpb_api.hip: per-GP distance form from h_theta and the design's extents

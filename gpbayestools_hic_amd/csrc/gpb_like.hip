@@ -804,8 +804,8 @@ int launch_loglike(gpb_ctx* ctx, int64_t W, double* ll_dev, bool accumulate, boo
         const int64_t need = W * (M + 1) * (M + 1);
         if (need > ctx->mvn_ws_cap) {
             GPB_HIP(hipStreamSynchronize(ctx->stream));
-            if (ctx->mvn_ws) GPB_HIP(hipFree(ctx->mvn_ws));
-            GPB_HIP(hipMalloc(&ctx->mvn_ws, need * sizeof(double)));
+            if (ctx->mvn_ws) pool_free(ctx->mvn_ws);
+            GPB_HIP(pool_malloc_t(&ctx->mvn_ws, need * sizeof(double)));
             ctx->mvn_ws_cap = need;
         }
         gws = ctx->mvn_ws;
@@ -838,8 +838,8 @@ int launch_mvn(gpb_ctx* ctx, const double* dY_dev, const double* cov_dev, int64_
         const int64_t need = W * (M + 1) * (M + 1);
         if (need > ctx->mvn_ws_cap) {
             GPB_HIP(hipStreamSynchronize(ctx->stream));
-            if (ctx->mvn_ws) GPB_HIP(hipFree(ctx->mvn_ws));
-            GPB_HIP(hipMalloc(&ctx->mvn_ws, need * sizeof(double)));
+            if (ctx->mvn_ws) pool_free(ctx->mvn_ws);
+            GPB_HIP(pool_malloc_t(&ctx->mvn_ws, need * sizeof(double)));
             ctx->mvn_ws_cap = need;
         }
         gws = ctx->mvn_ws;
@@ -989,9 +989,9 @@ int launch_compact(gpb_ctx* ctx, const double* X_dev, int64_t W, int64_t dx, con
 int ensure_cmp_rows(gpb_ctx* ctx, int64_t dx) {
     if (ctx->cmp_X_cap < ctx->Wcap * dx) {
         GPB_HIP(hipStreamSynchronize(ctx->stream));
-        if (ctx->cmp_X) GPB_HIP(hipFree(ctx->cmp_X));
+        if (ctx->cmp_X) pool_free(ctx->cmp_X);
         ctx->cmp_X = nullptr;
-        GPB_HIP(hipMalloc(&ctx->cmp_X, sizeof(double) * (size_t)(ctx->Wcap * dx)));
+        GPB_HIP(pool_malloc_t(&ctx->cmp_X, sizeof(double) * (size_t)(ctx->Wcap * dx)));
         GPB_HIP(hipMemsetAsync(ctx->cmp_X, 0, sizeof(double) * (size_t)(ctx->Wcap * dx), ctx->stream));   // rows past the count are read (not used) by the upper-bound launches
         ctx->cmp_X_cap = ctx->Wcap * dx;
     }
@@ -1688,10 +1688,10 @@ int emcee_plan(gpb_ctx* const* ctxs, int E, int64_t nwalkers, EmceePlan& pl) {
     // writes the other) and a second log-probability vector [nwalkers]
     if (ctx->mc_cap < 2 * nh * (d + 3)) {
         GPB_HIP(hipStreamSynchronize(ctx->stream));
-        if (ctx->mc_ws) GPB_HIP(hipFree(ctx->mc_ws));
+        if (ctx->mc_ws) pool_free(ctx->mc_ws);
         ctx->mc_ws = nullptr;
         ctx->mc_cap = 0;
-        GPB_HIP(hipMalloc(&ctx->mc_ws, sizeof(double) * (size_t)(2 * nh * (d + 3))));
+        GPB_HIP(pool_malloc_t(&ctx->mc_ws, sizeof(double) * (size_t)(2 * nh * (d + 3))));
         ctx->mc_cap = 2 * nh * (d + 3);
     }
     pl.fused = pl.plain && loglike_fuses_finalize(ctx, chunk);
@@ -1715,10 +1715,10 @@ int emcee_plan(gpb_ctx* const* ctxs, int E, int64_t nwalkers, EmceePlan& pl) {
         const int64_t need = 4 * nh + 2 * (4 + chunk) + 16;
         if (ctx->bal_cap < need) {
             GPB_HIP(hipStreamSynchronize(ctx->stream));
-            if (ctx->bal_ws) GPB_HIP(hipFree(ctx->bal_ws));
+            if (ctx->bal_ws) pool_free(ctx->bal_ws);
             ctx->bal_ws = nullptr;
             ctx->bal_cap = 0;
-            GPB_HIP(hipMalloc(&ctx->bal_ws, sizeof(int) * (size_t)need));
+            GPB_HIP(pool_malloc_t(&ctx->bal_ws, sizeof(int) * (size_t)need));
             ctx->bal_cap = need;
         }
     }

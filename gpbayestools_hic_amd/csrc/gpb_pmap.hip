@@ -92,12 +92,12 @@ extern "C" int gpb_param_map_set(gpb_ctx* ctx, int64_t d_in, int64_t d_out, cons
     }
     GPB_HIP(hipSetDevice(ctx->device));
     GPB_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->pmap_int) { GPB_HIP(hipFree(ctx->pmap_int)); ctx->pmap_int = nullptr; }
-    if (ctx->pmap_tab) { GPB_HIP(hipFree(ctx->pmap_tab)); ctx->pmap_tab = nullptr; }
+    if (ctx->pmap_int) { pool_free(ctx->pmap_int); ctx->pmap_int = nullptr; }
+    if (ctx->pmap_tab) { pool_free(ctx->pmap_tab); ctx->pmap_tab = nullptr; }
     const size_t ni = (size_t)d_out + 6 * (size_t)n_groups;
     const size_t nt = (size_t)n_groups * (4 + maxpc) * PMAP_GRID;
-    GPB_HIP(hipMalloc(&ctx->pmap_int, ni * sizeof(int)));
-    GPB_HIP(hipMalloc(&ctx->pmap_tab, nt * sizeof(double)));
+    GPB_HIP(pool_malloc_t(&ctx->pmap_int, ni * sizeof(int)));
+    GPB_HIP(pool_malloc_t(&ctx->pmap_tab, nt * sizeof(double)));
     GPB_HIP(hipMemcpy(ctx->pmap_int, col_src, (size_t)d_out * sizeof(int), hipMemcpyHostToDevice));
     GPB_HIP(hipMemcpy(ctx->pmap_int + d_out, group_desc, 6 * (size_t)n_groups * sizeof(int), hipMemcpyHostToDevice));
     GPB_HIP(hipMemcpy(ctx->pmap_tab, tables, nt * sizeof(double), hipMemcpyHostToDevice));

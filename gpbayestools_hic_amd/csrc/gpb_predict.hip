@@ -1024,11 +1024,11 @@ int ensure_wcap(gpb_ctx* ctx, int64_t W) {
     GPB_HIP(pool_malloc(reinterpret_cast<void**>(&ctx->spart), sizeof(double) * nI64 * P * need));
     GPB_HIP(pool_malloc(reinterpret_cast<void**>(&ctx->mean_pc), sizeof(double) * P * need));
     GPB_HIP(pool_malloc(reinterpret_cast<void**>(&ctx->var_pc), sizeof(double) * P * need));
-    if (ctx->cmp_idx) { GPB_HIP(hipFree(ctx->cmp_idx)); ctx->cmp_idx = nullptr; }
-    if (ctx->cmp_X) { GPB_HIP(hipFree(ctx->cmp_X)); ctx->cmp_X = nullptr; }
+    if (ctx->cmp_idx) { pool_free(ctx->cmp_idx); ctx->cmp_idx = nullptr; }
+    if (ctx->cmp_X) { pool_free(ctx->cmp_X); ctx->cmp_X = nullptr; }
     ctx->cmp_X_cap = 0;
     // [0] = number of rows inside the box, [4..] = their indices; then the compaction's scratch: ranks, workgroup counts
-    GPB_HIP(hipMalloc(&ctx->cmp_idx, sizeof(int) * (size_t)(4 + 2 * need + need / 256 + 8)));
+    GPB_HIP(pool_malloc_t(&ctx->cmp_idx, sizeof(int) * (size_t)(4 + 2 * need + need / 256 + 8)));
     ctx->Wcap = need;
     return 0;
 }
@@ -1315,7 +1315,7 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev) {
         if (ctx->predict_dma && T == 64 && nwv == 4) {
             // LDS-DMA tiles (tune key 41; measured, 0-5 % slower: profiles/r03_small_batch_notes.txt): need the k-major copy of
             // L^-1, made here after a new factorisation
-            if (!ctx->LinvT) GPB_HIP(hipMalloc(&ctx->LinvT, sizeof(double) * (size_t)(ctx->P * ctx->Np * ctx->Np)));
+            if (!ctx->LinvT) GPB_HIP(pool_malloc_t(&ctx->LinvT, sizeof(double) * (size_t)(ctx->P * ctx->Np * ctx->Np)));
             if (!ctx->linvT_valid) {
                 hipLaunchKernelGGL(k_transpose_linv, dim3((unsigned)(ctx->Np / 64), (unsigned)(ctx->Np / 64), (unsigned)ctx->P),
                                    dim3(256), 0, ctx->stream, ctx->Linv, ctx->LinvT, ctx->Np);

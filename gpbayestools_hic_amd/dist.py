@@ -27,8 +27,17 @@ def init_from_env(backend=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:     # GPB_DIST_BACKEND=gloo rehearses the N>1 path with several ranks on ONE GPU
             backend = os.environ.get("GPB_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if torch.cuda.is_available():
-            local = local % max(torch.cuda.device_count(), 1)
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if backend == "nccl":
+            # one process per GPU: RCCL refuses two ranks on one device, and a rank folded onto another rank's GPU would time a
+            # different job from the one asked for.  Refuse on every rank, before the rendezvous, with the numbers.
+            nlocal = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+            if nlocal > ndev or local >= ndev:
+                raise RuntimeError("init_from_env: %d ranks on this node but %d visible GPU(s) (LOCAL_RANK %d): the nccl backend "
+                                   "needs one GPU per rank.  Start at most %d ranks, or rehearse the multi-rank control flow on "
+                                   "one GPU with GPB_DIST_BACKEND=gloo" % (nlocal, ndev, local, ndev))
+        elif ndev:
+            local = local % ndev                # gloo rehearsal only: the ranks share the visible GPU(s)
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world,
@@ -100,7 +109,8 @@ class WalkerSharding:
     def replicate(self, chain, src=0):
         """Rank `src` broadcasts the host state of the chain's emulators (what their pickles hold: scaler, PCA, design,
         targets, theta*, transforms) and the chain's experiment block and prior box; the other ranks install it and
-        rebuild their device state from it (set_data, set_theta, factor: milliseconds).  Collective."""
+        rebuild their device state from it before returning (set_data, set_theta, factor: milliseconds).  Each rank keeps its
+        own device and its own fit-side sharding (Emulator.fit_sharding).  Collective."""
         box = [None]
         if self.rank == src:
             box[0] = ([e.__getstate__() for e in chain.emuList], chain.expdata, chain.expdata_cov, chain.min, chain.max)
@@ -113,10 +123,14 @@ class WalkerSharding:
                 eng = getattr(emu, "_engine", None)
                 if eng is not None:
                     eng.close()
-                st = dict(st, device=emu.device)           # (each rank keeps its own GPU)
-                emu.__setstate__(st)
+                st = dict(st, device=emu.device, fit_sharding=getattr(emu, "fit_sharding", None))
+                emu.__setstate__(st)                       # (each rank keeps its own GPU and its own fit-side sharding)
             chain.prior_volume_ = float(__import__("numpy").prod(chain.max - chain.min))
             chain._like_sig = None
+            chain.__dict__.pop("_digest_cache", None)
+            for emu in chain.emuList:                      # the device state, now: set_data, set_theta, factor, transform
+                if getattr(emu, "_trained", False) and hasattr(emu, "_engine_ready"):
+                    emu._engine_ready()
         return chain
 
     def agree_state(self, digest):
@@ -135,26 +149,39 @@ class WalkerSharding:
                                "one rank and call WalkerSharding.replicate(chain) before sampling.")
         return True
 
-    def rows_agree_begin(self, X_dev):
-        """start the check that every rank was handed the same batch: a position-weighted 64-bit checksum of the rows' bits,
-        ONE max-all-reduce of (c, -c) enqueued behind it (asynchronous with nccl); rows_agree_end reads the outcome"""
+    def rows_agree_begin(self, X_dev, digest=None):
+        """start the check that every rank was handed the same batch — and, with `digest` (Chain.state_digest: 32 bytes), holds
+        the same model: a position-weighted 64-bit checksum of the rows' bits and the digest's four words, ONE max-all-reduce of
+        (v, -v) over all of them enqueued behind it (asynchronous with nccl); rows_agree_end reads the outcome"""
+        import numpy as np
         import torch
         v = X_dev.contiguous().view(torch.int64).reshape(-1)
         key = (v.numel(), v.device)
         if getattr(self, "_cs_key", None) != key:
             self._cs_w = torch.arange(v.numel(), dtype=torch.int64, device=v.device) * 2 + 1
             self._cs_key = key
-        c = (v * self._cs_w).sum() + v.numel()
-        t = torch.stack([c, -c]).to(self._coll_device())
+        c = ((v * self._cs_w).sum() + v.numel()).reshape(1)
+        if digest is not None:
+            dk = (bytes(digest), self._coll_device())
+            if getattr(self, "_dg_key", None) != dk:         # the digest's words on the collective's device: uploaded once
+                w = np.frombuffer(dk[0][:32].ljust(32, b"\0"), dtype=np.int64) >> 1       # (>> 1: -w never overflows)
+                self._dg_w, self._dg_key = torch.as_tensor(w.copy(), device=dk[1]), dk
+            c = torch.cat([c.to(self._coll_device()), self._dg_w])
+        t = torch.cat([c, -c]).to(self._coll_device())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return t
 
     def rows_agree_end(self, t):
-        """raises — on every rank — unless max(c) == min(c) over the ranks (synchronises on the two words)"""
-        hi, neg_lo = (int(x) for x in t.cpu())
-        if hi != -neg_lo:
+        """raises — on every rank — unless max(v) == min(v) over the ranks for every word (synchronises on the words)"""
+        w = [int(x) for x in t.cpu()]
+        n = len(w) // 2
+        if w[0] != -w[n]:
             raise RuntimeError("the ranks of a sharded log-probability call were handed different rows: the sampler above it "
                                "must run replicated (same seed, same inputs on every rank)")
+        if any(w[i] != -w[n + i] for i in range(1, n)):
+            raise RuntimeError("the ranks' replicas of the GP state differ (hyper-parameters, targets, transforms or the "
+                               "experiment block): a sharded call would mix log-probabilities of different models.  Train on "
+                               "one rank and call WalkerSharding.replicate(chain) before evaluating.")
 
     def _drop_direct(self):
         if self.direct is not None:

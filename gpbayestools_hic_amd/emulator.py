@@ -401,6 +401,9 @@ class Emulator:
                        bool(self.parameterTrafoPCA_))).encode())
         arrs = [self._X_train, self._Z_train, self.thetas_, self.scaler.mean_]
         arrs += [self.scaler.scale_] if self.perform_no_PCA_ else [self._A, self._cov_trunc]
+        if self.parameterTrafoPCA_:          # the parameter-space map in front of the GPs (src/emulator.py:492-551)
+            for g in self._ppca.groups:
+                arrs += [g.scaler.mean_, g.scaler.scale_, g.pca.mean_, g.pca.components_]
         for a in arrs:
             a = np.ascontiguousarray(a, dtype=np.float64)
             h.update(repr(a.shape).encode()); h.update(a.tobytes())

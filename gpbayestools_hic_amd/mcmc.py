@@ -75,7 +75,7 @@ class Chain:
         st.pop("_box_key", None)
         st["_like_sig"] = None
         st["sharding"] = None
-        st.pop("_agreed_sig", None)
+        st.pop("_digest_cache", None)
         return st
 
     def __setstate__(self, st):
@@ -87,11 +87,12 @@ class Chain:
         (dist.WalkerSharding; one process per GPU): rank r takes rows [r chunk, (r + 1) chunk) of the batch, one
         all-gather of the shares completes the vector on every rank.  This is the multi-GPU form of the call pocoMC makes —
         log_likelihood(X[n_active, ndim], finite=True) once per batch, src/mcmc.py:798-805 — with the sampler itself
-        replicated: EVERY rank must make the same calls with the same rows (checked: a batch whose rows differ between the
-        ranks raises on all of them), and all ranks must hold the same emulators (WalkerSharding.replicate; checked once per
-        set of device contexts).  A row's value does not depend on the split.  `None` switches it off."""
+        replicated: EVERY rank must make the same calls with the same rows, and all ranks must hold the same emulators
+        (WalkerSharding.replicate).  Both are checked on EVERY call by the one all-reduce that rides in front of the batch (the
+        rows' checksum and the four words of the state digest: a batch whose rows — or a replica whose model — differ between
+        the ranks raises on all of them), so the sequence of collectives a rank issues never depends on what only that rank
+        knows.  A row's value does not depend on the split.  `None` switches it off."""
         self.sharding = sharding
-        self._agreed_sig = None
         return self
 
     # ------------------------------------------------------------------ inputs
@@ -104,6 +105,17 @@ class Chain:
         errs = np.nan_to_num(np.abs(np.array([data[k]["obs"][1] for k in data.keys()])))
         cov = np.diag(errs.flatten() ** 2)
         return vals, cov
+
+    def state_digest_cached(self):
+        """state_digest(), recomputed only when an emulator was re-trained / re-loaded or the experiment replaced (new arrays):
+        the key is rank-local, and only ever decides which VALUE this rank contributes to a check — never whether it takes part"""
+        key = (id(self.expdata), id(self.expdata_cov), self.min.tobytes(), self.max.tobytes(),
+               tuple((id(e), id(getattr(e, "thetas_", None)), id(getattr(e, "_X_train", None)), id(getattr(e, "_Z_train", None)))
+                     for e in self.emuList))
+        c = getattr(self, "_digest_cache", None)
+        if c is None or c[0] != key:
+            c = self._digest_cache = (key, self.state_digest())
+        return c[1]
 
     def state_digest(self):
         """sha256 over the emulators' state digests, the experiment block and the prior box: what the ranks of a walker-
@@ -261,17 +273,16 @@ class Chain:
             per_row = max(8 * e._ngp * e._X_train.shape[0] for e in self.emuList)
             slab = int(min(max((8 << 30) // per_row, 1024), 1 << 17)) // 128 * 128
             sh = self.sharding if (self.sharding is not None and getattr(self.sharding, "world", 1) > 1) else None
-            if sh is not None:                   # all ranks hold the same model: once per set of device contexts
-                sig = tuple(id(getattr(e, "_engine", None)) for e in self.emuList)
-                if sig != getattr(self, "_agreed_sig", None):
-                    sh.agree_state(self.state_digest())
-                    self._agreed_sig = sig
+            # sharded: all ranks must hold the same model and be handed the same rows.  ONE all-reduce of the rows' checksum
+            # and the state digest's words rides in front of every batch and is read after it — every rank issues it on every
+            # call, whatever it knows locally (a rank whose engines were rebuilt by replicate(), a rank that has evaluated
+            # before): the collective sequences of the ranks cannot drift apart
+            digest = self.state_digest_cached() if sh is not None else None
 
             def evaluate(Xd):
                 if sh is None:
                     return self.log_prob_device(Xd, outside=outside)
-                # ... and were handed the same rows: a checksum's all-reduce rides in front of the batch, read after it
-                pending = sh.rows_agree_begin(Xd)
+                pending = sh.rows_agree_begin(Xd, digest)
                 out = torch.empty(Xd.shape[0], dtype=torch.float64, device=Xd.device)
                 sh.logprob(lambda Xr, o: self.log_prob_device(Xr, out=o, outside=outside), Xd, out)
                 sh.rows_agree_end(pending)

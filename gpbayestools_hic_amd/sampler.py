@@ -147,12 +147,11 @@ class StretchSampler:
         if sh is not None and getattr(sh, "world", 1) > 1 and hasattr(sh, "agree_state") and hasattr(self.chain_obj, "state_digest") \
                 and not self._logprob_override:
             # sharded: rank r's rows are evaluated with rank r's GP state.  Every rank proves, before anything is accepted on
-            # the strength of another rank's numbers, that all replicas are the same (raises on every rank otherwise)
-            # (once per sampler and set of device contexts: a re-trained emulator has a new engine and is checked again)
-            sig = tuple(id(getattr(e, "_engine", None)) for e in getattr(self.chain_obj, "emuList", []))
-            if sig != getattr(self, "_agreed_sig", None):
-                sh.agree_state(self.chain_obj.state_digest())
-                self._agreed_sig = sig
+            # the strength of another rank's numbers, that all replicas are the same (raises on every rank otherwise) — at the
+            # top of EVERY run(), unconditionally: whether a rank enters a collective must never hang on what only it knows
+            # (which of its engines were rebuilt, whether it has sampled before)
+            ch = self.chain_obj
+            sh.agree_state(ch.state_digest_cached() if hasattr(ch, "state_digest_cached") else ch.state_digest())
         res = self._resident_engine()
         if res is not None and self.sharding is not None:
             # sharded C loop: whatever can fail on ONE rank (state checks, workspace allocation) is done now, and the

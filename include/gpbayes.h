@@ -77,6 +77,11 @@ GPB_API int  gpb_ctx_destroy(gpb_ctx* ctx);
  * torch.cuda.current_stream() is unless the caller changed it). */
 GPB_API int  gpb_ctx_set_stream(gpb_ctx* ctx, void* stream);
 GPB_API int  gpb_sync(gpb_ctx* ctx);
+/* Hand every cached device buffer back to the driver (the cache of the header comment: GPB_POOL_MB megabytes per process, default
+ * 8192, 0 = off).  The cache is invisible to other allocators of the process (torch's caching allocator, the caller's own
+ * hipMalloc): call this before a large allocation elsewhere.  The library does it itself when one of its own allocations fails.
+ * No reference counterpart (memory management of the native side). */
+GPB_API int  gpb_pool_trim(void);
 GPB_API const char* gpb_last_error(gpb_ctx* ctx);
 GPB_API void* gpb_stream(gpb_ctx* ctx);
 

@@ -315,8 +315,17 @@ def _replica_worker(rank, world, port, q):
             res["rows"].append("no error")
         except RuntimeError as e:
             res["rows"].append(str(e))
+    # ... and with the state digest riding on the same all-reduce (Chain._log_prob: every sharded call, on every rank alike)
+    res["rows_digest"] = []
+    for dg in (b"d" * 32, bytes([rank == 1]) * 32, chain.state_digest()):
+        try:
+            sh.rows_agree_end(sh.rows_agree_begin(Xsame, dg))
+            res["rows_digest"].append("no error")
+        except RuntimeError as e:
+            res["rows_digest"].append(str(e))
     sh.replicate(chain)
     res["after"] = sh.agree_state(chain.state_digest())
+    sh.rows_agree_end(sh.rows_agree_begin(Xsame, chain.state_digest()))
     res["z"] = chain.emuList[0].z.copy()
     res["dev"] = [e.device for e in chain.emuList]
     res["exp"] = float(chain.expdata[0, 0])
@@ -342,6 +351,8 @@ def test_replicas_are_rank_zeros_and_a_difference_raises_on_every_rank():
         assert "replicas of the GP state differ" in got[r]["differ"], (r, got[r]["differ"])
         assert got[r]["after"] is True
         assert len(got[r]["rows"]) == 2 and all("different rows" in m for m in got[r]["rows"]), got[r]["rows"]
+        rd = got[r]["rows_digest"]
+        assert rd[0] == "no error" and all("replicas of the GP state differ" in m for m in rd[1:]), rd
         assert np.array_equal(got[r]["z"], got[0]["z"]) and got[r]["exp"] == 0.5          # rank 0's state everywhere ...
         assert got[r]["dev"] == [r, r]                                                    # ... on each rank's own device
         assert got[r]["like_sig"] == ("stale" if r == 0 else None)                        # likelihood blocks are re-installed

@@ -433,3 +433,27 @@ def test_product_and_debug_libraries_give_the_same_bits(eng, deng):
         assert eng.lib is not deng.lib and deng.has_variants and not eng.has_variants
     for a, b in zip(*out):
         assert np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------- the cache of freed device buffers
+def test_pool_trim_hands_cached_buffers_back_and_contexts_still_work():
+    """contexts come and go with every training and their large buffers are cached (csrc/gpb_pool.hip, GPB_POOL_MB); gpb_pool_trim
+    gives the cache back to the driver, the next context allocates afresh and factors to the same bits"""
+    import torch
+    from gpbayestools_hic_amd import GPEngine, synth
+    X = synth.lhs(700, 6)
+    Z = np.random.default_rng(3).standard_normal((3, 700))
+    th = synth.fixed_theta(6, 3)
+
+    def alpha():
+        e = GPEngine(0)
+        e.set_data(X, Z, "RBF", 0.1); e.set_theta(th); e.factor()
+        a = e.get("alpha")
+        e.close()
+        return a
+    a0 = alpha()                                   # its K / L^-1 / T (3 x 704^2 doubles each, 11.9 MB) are cached now
+    free_cached = torch.cuda.mem_get_info()[0]
+    assert GPEngine(0).lib.gpb_pool_trim() == 0
+    free_trimmed = torch.cuda.mem_get_info()[0]
+    assert free_trimmed >= free_cached + 3 * 11 * (1 << 20)          # the three matrices went back to the driver
+    assert np.array_equal(alpha(), a0) and np.array_equal(alpha(), a0)       # fresh allocation, then a cached one

@@ -98,3 +98,62 @@ def test_ranks_refuse_differing_replicas_and_agree_after_replicate(tmp_path):
         for a, b in zip(got[r][4], want):
             assert np.array_equal(a, b), r                          # sharded batches = the single process's, bit for bit
         assert "different rows" in got[r][5], got[r][5]             # and both ranks refuse a batch that differs between them
+
+
+def _flow_worker(rank, world, port, workdir, q):
+    """the flow INTEGRATION.md documents for the pocoMC call shape: train, WalkerSharding.replicate(chain), chain.shard_over(sh),
+    then log_likelihood batches — with NO sampler run in between, so that after replicate rank 0 still holds its engines while
+    rank 1's were rebuilt: what one rank knows locally must not decide which collectives it enters"""
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import numpy as np
+    import torch.distributed as dist
+    from gpbayestools_hic_amd import synth
+    from gpbayestools_hic_amd.dist import GPSharding, WalkerSharding, init_from_env
+    init_from_env(backend="gloo")
+    d = os.path.join(workdir, f"r{rank}"); os.makedirs(d, exist_ok=True)
+    chain, emu, info = _build(d, perturb=(rank == 1))
+    emu.fit_sharding = mine = GPSharding()
+    sh = WalkerSharding()
+    Xb = synth.walkers(129, info["d"], seed=8)
+    chain.shard_over(sh)
+    try:                                                            # differing replicas: every rank refuses the batch
+        chain.log_likelihood(Xb, finite=True)
+        refused = "ran"
+    except RuntimeError as e:
+        refused = str(e)
+    sh.replicate(chain)
+    rebuilt = emu._engine is not None                               # replicate rebuilds the device state before it returns
+    kept = emu.fit_sharding is mine                                 # ... and leaves each rank its own fit-side sharding
+    ll = [chain.log_likelihood(Xb, finite=True), chain.log_likelihood(Xb[:50], finite=True), chain.log_posterior(Xb)]
+    emu._engine.close(); emu._engine = None                         # one rank's engines dropped (a pickle round trip): still
+    if rank == 0:                                                   # the same collectives on both ranks
+        emu._engine_ready()
+    ll.append(chain.log_likelihood(Xb, finite=True))
+    dist.barrier()
+    q.put((rank, refused, rebuilt, kept, ll))
+    dist.destroy_process_group()
+
+
+def test_replicate_then_shard_over_then_batches_without_a_sampler_run(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_flow_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs: p.start()
+    got = {r[0]: r[1:] for r in (q.get(timeout=600) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    one = tmp_path / "single"; one.mkdir()
+    chain, emu, info = _build(str(one), perturb=False)
+    from gpbayestools_hic_amd import synth
+    Xb = synth.walkers(129, info["d"], seed=8)
+    want = [chain.log_likelihood(Xb, finite=True), chain.log_likelihood(Xb[:50], finite=True), chain.log_posterior(Xb),
+            chain.log_likelihood(Xb, finite=True)]
+    for r in range(world):
+        refused, rebuilt, kept, ll = got[r]
+        assert "replicas of the GP state differ" in refused, refused
+        assert rebuilt and kept
+        for a, b in zip(ll, want):
+            assert np.array_equal(a, b), r
