@@ -11,6 +11,7 @@ Objects pickle/dill cleanly: device handles are dropped in __getstate__ and the 
 is rebuilt on the device from (X, Z, theta) at first use after loading (src/mcmc.py:145-150).
 """
 import logging
+import os
 import pickle
 import threading
 
@@ -306,7 +307,7 @@ class Emulator:
         return _SearchEngine(self.device, [self._X_train] * len(idx), [self._Z_train[i] for i in idx],
                              _KERNELS[self.kernel_type_][0], self.alpha, copies)
 
-    def _optimise(self, eng, kernel_type):
+    def _optimise(self, eng, kernel_type, draws=None):
         """argmax LML per GP with scipy L-BFGS-B (sk:_gpr.py:296-337,654-670).  The P searches — and, with
         nrestarts > 0, the 1 + nrestarts starts of each — are independent; they run in lock-step threads so that every
         objective call is ONE batched device evaluation of the log-marginal likelihoods and gradients of all searches
@@ -319,9 +320,9 @@ class Emulator:
             copies = 1
         if sh is None or sh.world == 1:
             if copies == 1:
-                return search_hyperparameters(lambda idx: eng, self._ngp, theta0, bounds, self.nrestarts)
+                return search_hyperparameters(lambda idx: eng, self._ngp, theta0, bounds, self.nrestarts, draws=draws)
             return search_hyperparameters(lambda idx: self._search_engine(idx, copies), self._ngp, theta0, bounds,
-                                          self.nrestarts, close=True)
+                                          self.nrestarts, close=True, draws=draws)
 
         def sub_engine(idx):            # this rank's GPs only: same design, a subset of the target rows
             if copies > 1:
@@ -329,7 +330,7 @@ class Emulator:
             sub = GPEngine(self.device)
             sub.set_data(self._X_train, self._Z_train[idx], _KERNELS[kernel_type][0], self.alpha)
             return sub
-        return search_hyperparameters(sub_engine, self._ngp, theta0, bounds, self.nrestarts, sh, close=True)
+        return search_hyperparameters(sub_engine, self._ngp, theta0, bounds, self.nrestarts, sh, close=True, draws=draws)
 
     def _optimise_with_points(self, kernel_type, theta0_bounds, draws):
         """the search of this emulator alone from given restart points (train_emulators' fallback for batches that do not fit)"""
@@ -540,17 +541,16 @@ def train_emulators(emulators, eventMasks=None, kernel_type="RBF"):
     results = [None] * len(emulators)
     for key, members in groups.items():
         if key[0] == "alone":
+            # a sharded emulator: its GPs are dealt to the ranks of ITS group (collective: every rank of that group is here), the
+            # 1 + nrestarts starts of this rank's GPs in one lock-step batch, from the points drawn above — Emulator._optimise
             i = members[0]
-            emu = emulators[i]
-            results[i] = search_hyperparameters(lambda idx, emu=emu: emu._search_engine(idx, 1), emu._ngp, t0b[i][0], t0b[i][1],
-                                                0, emu.fit_sharding, close=True) if emu.nrestarts == 0 else None
-            if results[i] is None:
-                raise NotImplementedError("train_emulators: a sharded fit with restarts trains through trainEmulator")
+            results[i] = emulators[i]._optimise(None, kernel_type, draws=draws[i])
             continue
         smax = 1 + max(int(emulators[i].nrestarts) for i in members)
         nvirt = sum(emulators[i]._ngp * (1 + int(emulators[i].nrestarts)) for i in members)
-        if len(members) > 1 and nvirt * 3 * 8 * (64 * key[2]) ** 2 > _BATCH_BYTES_MAX:
-            # the batch's three N x N matrices per virtual GP would not fit comfortably: these emulators train one by one
+        if nvirt * 3 * 8 * (64 * key[2]) ** 2 > _BATCH_BYTES_MAX:
+            # the batch's three N x N matrices per virtual GP would not fit comfortably (several emulators, or one with many
+            # restarts): these emulators train one by one, start by start
             for i in members:
                 emu = emulators[i]
                 results[i] = emu._optimise_with_points(kernel_type, t0b[i], draws[i])
@@ -584,7 +584,7 @@ def train_emulators(emulators, eventMasks=None, kernel_type="RBF"):
     return emulators
 
 
-def search_hyperparameters(make_engine, P, theta0, bounds, nrestarts=0, sharding=None, close=False, rng=None):
+def search_hyperparameters(make_engine, P, theta0, bounds, nrestarts=0, sharding=None, close=False, rng=None, draws=None):
     """theta*[P, d+2] and LML*[P]: L-BFGS-B from `theta0` plus `nrestarts` log-uniform starts per GP
     (sk:_gpr.py:296-337); `rng`: None (numpy's global RandomState, as sklearn), an int seed or a RandomState.  `make_engine(idx)` returns an object whose `.lml(theta[len(idx), d+2],
     eval_gradient=True)` serves the GPs `idx`.  With `sharding` (dist.GPSharding, SURVEY §8e "fit-side") the
@@ -599,9 +599,13 @@ def search_hyperparameters(make_engine, P, theta0, bounds, nrestarts=0, sharding
     # restart points as sklearn draws them: GPR(random_state=None) takes numpy's GLOBAL RandomState (np.random.seed
     # makes a fit reproducible) and draws, GP after GP, one log-uniform theta per restart (sk:_gpr.py:259,318-325).
     # Every rank draws all P x nrestarts points and keeps its own, so a sharded fit equals the unsharded one.
-    rs = _check_random_state(rng)
+    # `draws` [P, nrestarts, d+2]: the points already drawn (train_emulators draws for all its emulators up front, in order).
     nrestarts = int(nrestarts)
-    draws = np.array([[rs.uniform(bounds[:, 0], bounds[:, 1]) for _ in range(nrestarts)] for _ in range(P)])
+    if draws is None:
+        rs = _check_random_state(rng)
+        draws = np.array([[rs.uniform(bounds[:, 0], bounds[:, 1]) for _ in range(nrestarts)] for _ in range(P)])
+    elif nrestarts and np.shape(draws)[:2] != (P, nrestarts):
+        raise ValueError("search_hyperparameters: draws must be [P, nrestarts, d + 2]")
     best_theta = np.tile(theta0, (idx.size, 1))
     best_val = np.full(idx.size, np.inf)
     if idx.size:
@@ -654,26 +658,161 @@ class _SearchEngine:
 
 
 def _batched_lbfgsb(eng, start, bounds):
-    """Run P independent scipy L-BFGS-B minimisations of -LML_p(theta_p) in lock-step threads;
-    each round of objective calls is served by one batched device evaluation — of the searches still running when the
-    engine can evaluate a subset (`lml_active`), else of all P (`lml`; a finished search's theta stays where it ended)."""
+    """P independent L-BFGS-B minimisations of -LML_p(theta_p) in LOCK-STEP: every round of objective calls is served by one
+    batched device evaluation — of the searches still running when the engine can evaluate a subset (`lml_active`), else of all
+    P (`lml`; a finished search's theta stays where it ended).  Each search is scipy's own (sk:_gpr.py:654-670 calls
+    scipy.optimize.minimize(method="L-BFGS-B", jac=True, bounds=...)): driven either by ONE thread that steps scipy's
+    reverse-communication routine for all searches in turn (_lockstep_setulb: no thread switches, no GIL hand-overs — 63 scipy
+    threads cost more per round than the device evaluation they wait for), or, where this scipy does not offer that routine in the
+    form known here, by one scipy.optimize.minimize thread per search (_lockstep_threads).  Same theta*, bit for bit."""
+    if _setulb_usable():
+        return _lockstep_setulb(eng, start, bounds)
+    return _lockstep_threads(eng, start, bounds)
+
+
+def _evaluate_round(eng, cur, ids):
+    """-LML and its gradient of the searches `ids` at cur[ids] (one batched device evaluation); rows of other searches NaN"""
+    P = cur.shape[0]
+    subset = getattr(eng, "lml_active", None)
+    if subset is not None and len(ids) < P:
+        v = np.full(P, np.nan); g = np.full((P, cur.shape[1]), np.nan)
+        v[ids], g[ids] = subset(np.asarray(ids), cur[ids])
+    else:
+        v, g = eng.lml(cur, eval_gradient=True)
+    return -v, -g
+
+
+_SETULB_SIGNATURE = "setulb(m,x,l,u,nbd,f,g,factr,pgtol,wa,iwa,task,lsave,isave,dsave,maxls,ln_task)"
+_setulb_ok = None
+
+
+class _SetulbSearch:
+    """One L-BFGS-B search as scipy.optimize._lbfgsb_py._minimize_lbfgsb runs it (scipy 1.15: m = 10, factr = 2.22e-9 / eps,
+    pgtol = 1e-5, maxfun = maxiter = 15000, maxls = 20, x0 clipped into the bounds, the objective memoised on the latest x as
+    scipy's ScalarFunction does), cut open at the objective call: advance() runs the routine until it wants f and g at a new x
+    (returns True; feed(f, g) hands them over) or has finished (returns False; .x, .f are the result)."""
+
+    def __init__(self, setulb, x0, bounds):
+        n = x0.shape[0]
+        m = 10
+        self.setulb, self.m, self.maxls = setulb, m, 20
+        self.factr, self.pgtol, self.maxfun, self.maxiter = 2.2204460492503131e-09 / np.finfo(float).eps, 1e-5, 15000, 15000
+        self.low, self.up = np.array(bounds[:, 0], dtype=np.float64), np.array(bounds[:, 1], dtype=np.float64)
+        self.nbd = np.full(n, 2, dtype=np.int32)                     # every hyper-parameter has both bounds (finite)
+        self.x = np.array(np.clip(np.asarray(x0, dtype=np.float64).ravel(), self.low, self.up), dtype=np.float64)
+        self.f = np.array(0.0, dtype=np.int32)                       # (scipy's own start values, types included)
+        self.g = np.zeros((n,), dtype=np.int32)
+        self.wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m, np.float64)
+        self.iwa = np.zeros(3 * n, dtype=np.int32)
+        self.task, self.ln_task = np.zeros(2, dtype=np.int32), np.zeros(2, dtype=np.int32)
+        self.lsave, self.isave, self.dsave = np.zeros(4, dtype=np.int32), np.zeros(44, dtype=np.int32), np.zeros(29, dtype=np.float64)
+        self.n_iterations, self.nfev = 0, 0
+        self._memo_x = None                                          # ScalarFunction evaluates at x0 when it is built:
+        self.want = self.x.copy()                                    # the first request, before the routine is entered
+
+    def feed(self, f, g):
+        self._memo_x, self._memo = self.want, (f, np.atleast_1d(g))
+        self.nfev += 1
+
+    def advance(self):
+        while True:
+            self.g = self.g.astype(np.float64)
+            self.setulb(self.m, self.x, self.low, self.up, self.nbd, self.f, self.g, self.factr, self.pgtol, self.wa, self.iwa,
+                        self.task, self.lsave, self.isave, self.dsave, self.maxls, self.ln_task)
+            if self.task[0] == 3:                                    # f and g at the current x
+                if not np.array_equal(self.x, self._memo_x):
+                    self.want = self.x.copy()
+                    return True
+                self.f, self.g = self._memo
+            elif self.task[0] == 1:                                  # new iteration
+                self.n_iterations += 1
+                if self.n_iterations >= self.maxiter:
+                    self.task[0], self.task[1] = 5, 504
+                elif self.nfev > self.maxfun:
+                    self.task[0], self.task[1] = 5, 502
+            else:
+                return False
+
+    def resume(self):
+        """after feed(): the routine asked for f and g at `want` = the current x"""
+        self.f, self.g = self._memo
+        return self.advance()
+
+
+def _setulb_usable():
+    """scipy's L-BFGS-B routine in the reverse-communication form this file knows (scipy 1.15's C port), PROVEN on a bounded test
+    problem to give scipy.optimize.minimize's result bit for bit (x, fun, number of evaluations, every x it asked about);
+    anything else — another signature, a different result — and the searches run as scipy.optimize.minimize threads"""
+    global _setulb_ok
+    if _setulb_ok is None:
+        _setulb_ok = False
+        try:
+            if os.environ.get("GPB_LBFGSB_THREADS") == "1":
+                return False
+            from scipy.optimize import _lbfgsb_py
+            setulb = _lbfgsb_py._lbfgsb.setulb
+            if (setulb.__doc__ or "").strip() != _SETULB_SIGNATURE:
+                return False
+
+            def fg(x):          # a bounded, badly scaled problem that ends ON bounds, after line searches with several trials
+                a = np.arange(1.0, x.shape[0] + 1.0)
+                r = x - 0.3 * a
+                return float(np.sum(a * r ** 2) + np.sum(np.cosh(0.5 * x)) + 5.0 * np.sin(x[0] * x[1])), \
+                    2.0 * a * r + 0.5 * np.sinh(0.5 * x) + 5.0 * np.cos(x[0] * x[1]) * np.concatenate(([x[1], x[0]], np.zeros(x.shape[0] - 2)))
+            bnd = np.array([[-1.0, 0.7], [-2.0, 2.0], [0.95, 3.0], [-4.0, 1.1], [0.0, 9.0]])
+            for x0 in (np.array([0.5, -1.5, 2.5, -3.0, 8.0]), np.array([-5.0, 0.0, 0.0, 0.0, 1.0])):
+                asked = []
+                ref = scipy.optimize.minimize(lambda x: (asked.append(x.copy()), fg(x))[1], x0, method="L-BFGS-B", jac=True, bounds=bnd)
+                s, mine = _SetulbSearch(setulb, x0, bnd), []
+                more = True
+                while more:
+                    mine.append(s.want.copy())
+                    s.feed(*fg(s.want))
+                    more = s.resume() if len(mine) > 1 else s.advance()
+                if not (np.array_equal(s.x, ref.x) and float(s.f) == float(ref.fun) and s.nfev == ref.nfev
+                        and s.n_iterations == ref.nit and len(mine) == len(asked)
+                        and all(np.array_equal(a, b) for a, b in zip(mine, asked))):
+                    return False
+            _setulb_ok = True
+        except Exception:        # noqa: BLE001  (a private scipy interface: any surprise means "use the threads")
+            _setulb_ok = False
+    return _setulb_ok
+
+
+def _lockstep_setulb(eng, start, bounds):
+    from scipy.optimize import _lbfgsb_py
+    setulb = _lbfgsb_py._lbfgsb.setulb
+    P = start.shape[0]
+    cur = np.array(start, dtype=np.float64)
+    searches = [_SetulbSearch(setulb, start[p], bounds[p] if bounds.ndim == 3 else bounds) for p in range(P)]
+    ids = list(range(P))
+    first = True
+    while ids:
+        for p in ids:
+            cur[p] = searches[p].want
+        f, g = _evaluate_round(eng, cur, ids)
+        nxt = []
+        for p in ids:
+            s = searches[p]
+            s.feed(f[p], g[p])
+            if (s.advance() if first else s.resume()):
+                nxt.append(p)
+        ids, first = nxt, False
+    return np.array([s.x for s in searches]), np.array([float(s.f) for s in searches])
+
+
+def _lockstep_threads(eng, start, bounds):
+    """one scipy.optimize.minimize thread per search, meeting at every objective call (see _batched_lbfgsb)"""
     P = start.shape[0]
     cur = start.copy()
     results = [None] * P
     cond = threading.Condition()
     state = {"waiting": 0, "active": P, "round": 0, "val": None, "grad": None, "err": None}
     alive = np.ones(P, dtype=bool)
-    subset = getattr(eng, "lml_active", None)
 
     def evaluate_round():
         try:
-            if subset is not None and not alive.all():
-                ids = np.flatnonzero(alive)
-                v = np.full(P, np.nan); g = np.full((P, cur.shape[1]), np.nan)
-                v[ids], g[ids] = subset(ids, cur[ids])
-            else:
-                v, g = eng.lml(cur, eval_gradient=True)
-            state["val"], state["grad"] = v, g
+            state["val"], state["grad"] = _evaluate_round(eng, cur, np.flatnonzero(alive))
         except Exception as e:  # propagate to every waiting thread
             state["err"] = e
         state["waiting"] = 0
@@ -692,7 +831,7 @@ def _batched_lbfgsb(eng, start, bounds):
                     cond.wait()
             if state["err"] is not None:
                 raise state["err"]
-            return -state["val"][p], -state["grad"][p]
+            return state["val"][p], state["grad"][p]
 
     def worker(p):
         try:

@@ -72,6 +72,70 @@ def test_two_ranks_search_disjoint_gps_and_agree_with_one_rank(tmp_path):
         assert np.array_equal(rmean, mean) and np.array_equal(rcov, cov), rank
 
 
+def _train_two_with_restarts(workdir, sharded):
+    """two emulators trained TOGETHER (train_emulators) with restarts: the first one's GPs dealt to the ranks (its searches,
+    restarts included, in this rank's lock-step batch), the second unsharded on every rank.  np.random.seed fixes the restart
+    points (sklearn draws them from numpy's global RandomState, sk:_gpr.py:259,318-325)."""
+    from gpbayestools_hic_amd import Emulator, synth
+    from gpbayestools_hic_amd.emulator import train_emulators
+    emus = []
+    for i, (npc, nre) in enumerate(((NPC, 2), (3, 1))):
+        X = synth.lhs(N, D, seed=5 + i)
+        tp, pf = os.path.join(workdir, "train%d.pkl" % i), os.path.join(workdir, "par.txt")
+        synth.write_training_pickle(tp, X, synth.observables(X, M, seed=6 + i), 0.01)
+        synth.write_parameter_file(pf, np.zeros(D), np.ones(D))
+        emus.append(Emulator(training_set_path=tp, parameter_file=pf, npc=npc, nrestarts=nre))
+    if sharded:
+        from gpbayestools_hic_amd.dist import GPSharding
+        emus[0].fit_sharding = GPSharding()
+    np.random.seed(1234)
+    train_emulators(emus)
+    Xq = synth.walkers(9, D, seed=9)
+    return [(e.thetas_.copy(), np.asarray(e.lml_).copy(), e.predict(Xq, return_cov=False)) for e in emus]
+
+
+def _restart_worker(rank, world, port, workdir, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from gpbayestools_hic_amd.dist import init_from_env
+    init_from_env(backend="gloo")
+    d = os.path.join(workdir, f"r{rank}"); os.makedirs(d, exist_ok=True)
+    out = _train_two_with_restarts(d, sharded=True)
+    dist.barrier()
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_train_emulators_with_a_sharded_fit_and_restarts(tmp_path):
+    """round 4 raised NotImplementedError here.  The sharded emulator's searches equal the unsharded training's — and the
+    sequential one's (Emulator.trainEmulator emulator after emulator, the same global RandomState) — bit for bit."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_restart_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs: p.start()
+    got = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    one = tmp_path / "single"; one.mkdir()
+    ref = _train_two_with_restarts(str(one), sharded=False)
+    for rank in range(world):
+        for (th, lml, mean), (rth, rlml, rmean) in zip(ref, got[rank]):
+            assert np.array_equal(rth, th) and np.array_equal(rlml, lml) and np.array_equal(rmean, mean), rank
+    # ... and what sequential trainings give from the same seed
+    from gpbayestools_hic_amd import Emulator, synth
+    seq = []
+    np.random.seed(1234)
+    for i, (npc, nre) in enumerate(((NPC, 2), (3, 1))):
+        e = Emulator(training_set_path=str(one / ("train%d.pkl" % i)), parameter_file=str(one / "par.txt"), npc=npc, nrestarts=nre)
+        e.trainEmulatorAutoMask()
+        seq.append(e)
+    for e, (th, lml, _) in zip(seq, ref):
+        assert np.array_equal(e.thetas_, th) and np.array_equal(np.asarray(e.lml_), lml)
+
+
 def test_c_abi_rccl_binding_single_rank():
     """gpb_dist_* (lazy dlopen of librccl, communicator per context, in-stream ncclAllGather) with a one-rank
     communicator: the only size a one-GPU box can form; more ranks run the same calls."""
