@@ -10,6 +10,7 @@ Host Python keeps file parsing, the N x M scaler/PCA SVD and the L-BFGS-B driver
 Objects pickle/dill cleanly: device handles are dropped in __getstate__ and the factorisation
 is rebuilt on the device from (X, Z, theta) at first use after loading (src/mcmc.py:145-150).
 """
+import itertools
 import logging
 import os
 import pickle
@@ -24,6 +25,8 @@ from .preprocess import (Standardizer, WhitenedPCA, observable_transform,
                          parse_model_parameter_file)
 
 log = logging.getLogger(__name__)
+
+_STATE_SERIAL = itertools.count(1)     # one number per fitted state of any emulator of this process (Chain.state_digest_cached)
 
 _KERNELS = {"RBF": ("RBF", (1e-1, 1e2)), "Matern": ("Matern15", (1e-3, 1e5)),
             "Matern25": ("Matern25", (1e-3, 1e5))}
@@ -285,6 +288,7 @@ class Emulator:
     def _finish_training(self, eng, thetas, lml):
         """the final factorisation at theta*, the observable transform and the per-GP scores (src/emulator.py:316-363)"""
         self.thetas_, self.lml_ = thetas, lml
+        self._state_serial = next(_STATE_SERIAL)
         eng.set_theta(self.thetas_)
         eng.factor()
         self._build_transform()
@@ -415,12 +419,14 @@ class Emulator:
         st["_engine"] = None
         st["_like_key"] = None
         st["fit_sharding"] = None
+        st.pop("_state_serial", None)
         st.pop("gps", None)
         return st
 
     def __setstate__(self, st):
         self.__dict__.update(st)
         self.__dict__.setdefault("fit_sharding", None)
+        self._state_serial = next(_STATE_SERIAL)
         if self._trained:
             self.gps = [FittedGP(self, i) for i in range(self._ngp)]
 

@@ -4,6 +4,7 @@ emulator resident in HBM, plus its observable transform and likelihood block.
 Host code only moves arguments; every number is produced by the HIP kernels.
 """
 import ctypes as C
+import itertools
 import os
 
 import numpy as np
@@ -22,6 +23,9 @@ def _is_torch(x):
     return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
 
 
+_SERIAL = itertools.count(1)
+
+
 class GPEngine:
     def __init__(self, device=0, stream="torch", debug=None):
         """stream: "torch" = enqueue on torch's current stream of `device` (one ordered queue
@@ -37,6 +41,7 @@ class GPEngine:
             raise nat.GPBError(f"gpb_ctx_create failed ({rc})")
         self._pid = os.getpid()          # device state does not survive a fork: see _check_pid
         self._h = h
+        self.serial = next(_SERIAL)      # which context is this? (never reused within the process, unlike id() of a freed object)
         self.device = int(device)
         self._follow_torch = stream == "torch"
         self._stream = None

@@ -109,9 +109,13 @@ class Chain:
     def state_digest_cached(self):
         """state_digest(), recomputed only when an emulator was re-trained / re-loaded or the experiment replaced (new arrays):
         the key is rank-local, and only ever decides which VALUE this rank contributes to a check — never whether it takes part"""
-        key = (id(self.expdata), id(self.expdata_cov), self.min.tobytes(), self.max.tobytes(),
-               tuple((id(e), id(getattr(e, "thetas_", None)), id(getattr(e, "_X_train", None)), id(getattr(e, "_Z_train", None)))
-                     for e in self.emuList))
+        # (an emulator's fitted state by its serial number — new with every training and every __setstate__, never reused;
+        # the experiment block by identity AND a content probe: id() alone can come back after an array was dropped)
+        key = (id(self.expdata), id(self.expdata_cov), np.asarray(self.expdata).tobytes(),
+               np.diagonal(np.atleast_2d(self.expdata_cov)).tobytes(), self.min.tobytes(), self.max.tobytes(),
+               tuple((id(e), getattr(e, "_state_serial", None)) for e in self.emuList))
+        if any(k[1] is None for k in key[-1]):           # a foreign emulator: no serial to trust, hash every time
+            return self.state_digest()
         c = getattr(self, "_digest_cache", None)
         if c is None or c[0] != key:
             c = self._digest_cache = (key, self.state_digest())
@@ -177,8 +181,9 @@ class Chain:
         """Hand every emulator its slice of the experimental data.  The fused path needs the
         experimental covariance to be block-diagonal over the emulators (it is diagonal in the
         reference, src/mcmc.py:320-322)."""
+        # (engines by their serial numbers: the id() of a closed engine can come back with the next one created)
         sig = (id(self.expdata), id(self.expdata_cov), tuple(id(e) for e in self.emuList),
-               tuple(id(e._engine) for e in self.emuList))
+               tuple(getattr(e._engine, "serial", None) for e in self.emuList))
         if sig == self._like_sig:
             return
         i0 = 0
@@ -194,7 +199,7 @@ class Chain:
         if np.any(self.expdata_cov[~mask] != 0.0):
             raise ValueError("experimental covariance couples different emulators; "
                              "the fused likelihood needs it block-diagonal")
-        self._like_sig = (sig[0], sig[1], sig[2], tuple(id(e._engine) for e in self.emuList))
+        self._like_sig = (sig[0], sig[1], sig[2], tuple(e._engine.serial for e in self.emuList))
 
     inside_const = EXTRA_STD_CONST               # what the reference adds to every row inside the box
 

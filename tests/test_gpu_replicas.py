@@ -101,6 +101,17 @@ def test_ranks_refuse_differing_replicas_and_agree_after_replicate(tmp_path):
 
 
 def _flow_worker(rank, world, port, workdir, q):
+    import faulthandler
+    import traceback
+    faulthandler.dump_traceback_later(200, exit=True)               # a rank that waits for a peer that died says where
+    try:
+        _flow(rank, world, port, workdir, q)
+    except BaseException:                                           # noqa: BLE001  (the parent fails the test with this text)
+        q.put((rank, "ERROR", traceback.format_exc(), None, None))
+        raise
+
+
+def _flow(rank, world, port, workdir, q):
     """the flow INTEGRATION.md documents for the pocoMC call shape: train, WalkerSharding.replicate(chain), chain.shard_over(sh),
     then log_likelihood batches — with NO sampler run in between, so that after replicate rank 0 still holds its engines while
     rank 1's were rebuilt: what one rank knows locally must not decide which collectives it enters"""
@@ -141,10 +152,18 @@ def test_replicate_then_shard_over_then_batches_without_a_sampler_run(tmp_path):
     q = ctx.Queue()
     procs = [ctx.Process(target=_flow_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
     for p in procs: p.start()
-    got = {r[0]: r[1:] for r in (q.get(timeout=600) for _ in range(world))}
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    got = {}
+    try:
+        for _ in range(world):
+            r = q.get(timeout=300)
+            assert r[1] != "ERROR", "rank %d:\n%s" % (r[0], r[2])
+            got[r[0]] = r[1:]
+    finally:
+        for p in procs:
+            p.join(timeout=5 if len(got) < world else 120)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
     one = tmp_path / "single"; one.mkdir()
     chain, emu, info = _build(str(one), perturb=False)
     from gpbayestools_hic_amd import synth
