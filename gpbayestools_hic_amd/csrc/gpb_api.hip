@@ -149,6 +149,8 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     dev_free(&ctx->n_nan); dev_free(&ctx->mc_ws); dev_free(&ctx->bal_ws); dev_free(&ctx->rows_live); dev_free(&ctx->cmp_idx); dev_free(&ctx->cmp_X);
     if (ctx->live_hint) (void)hipHostFree(ctx->live_hint);
     for (hipEvent_t e : ctx->chol_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ov_ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->prof_open) (void)hipEventDestroy(ctx->prof_open);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1089,6 +1091,7 @@ extern "C" int gpb_ctx_option(gpb_ctx* ctx, int key, int value) {
         }
 #endif
         case 47: if (value < 0 || value > 2) return GPB_E_ARG; ctx->chol_pair = value; break;
+        case 48: if (value < 0 || value > 99) return GPB_E_ARG; ctx->kx_overlap = value; break;
         case 44: if (value < 0) return GPB_E_ARG; ctx->tile_switch = value > 0 ? value : 960; break;
         case 33: if (value < 0) return GPB_E_ARG; ctx->tile_switch_c = value; break;
         case 34: if (value < 0) return GPB_E_ARG; ctx->mid_switch_c = value; break;

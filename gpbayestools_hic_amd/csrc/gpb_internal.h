@@ -167,6 +167,10 @@ struct gpb_ctx {
     int chol_lookahead = 1;        // far part of a panel's trailing update on a side stream, under the next panel's chain
     hipStream_t side_stream = nullptr;
     std::vector<hipEvent_t> chol_events;
+    int kx_overlap = 0;            // option key 48: per cent of a batch's GPs in the FIRST of two groups; the second group's K*^T runs on
+                                   // the side stream under the first group's predict launch (0 = one K*^T and one predict launch: default)
+    hipEvent_t ov_ev[2] = {nullptr, nullptr};
+    hipEvent_t prof_open = nullptr;   // profiling: the start event of a predict launch PAIR (kx_overlap) that is still open
     int kmat_mfma = 1;             // tune key 39: K(X,X) tiles by k_kmat_mfma (dot-product form on the matrix cores, no LDS)
     int chol_algo = 1;             // 1 = two launches per step, next diagonal block fused into the update (gpb_chol.hip); 0 = round 1
     int syrk_tile = 0;              // tile of the end-of-panel trailing updates (0 = by fill, 64, 128)
@@ -248,7 +252,13 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
 // its three phases, for callers that batch the middle one over several contexts (chains of emulators)
 int launch_kcross(gpb_ctx* ctx, const double* Xs_dev, int64_t W, const int* nrows_dev);
 int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, int64_t W, const int* nrows_dev);
-int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev);
+// p0s / p1s (optional): the launch covers GPs [p0s[e], p1s[e]) of context e instead of all of them (the shared-launch kernels with a
+// table of those GPs: same tiles, same bits).  prof_begin / prof_end: a pair of launches timed as one (ctx->prof_open).
+int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, const int* p0s = nullptr, const int* p1s = nullptr,
+               bool prof_begin = true, bool prof_end = true);
+// K*^T and the mean partials of GPs [p0s[e], p1s[e]) of E contexts (same Np, d; Gram form only) in one launch on `stream`
+int launch_kcross_ranges(gpb_ctx* const* ctxs, const double* const* Xs, int E, const int* p0s, const int* p1s, int64_t W,
+                         const int* nrows_dev, hipStream_t stream);
 int launch_finalize(gpb_ctx* ctx, int64_t W, bool need_var);
 constexpr int GPB_MAX_MULTI_GP = 96;      // GPs one batched launch can address (its table is a kernel argument)
 int launch_predict_cov(gpb_ctx* ctx, const double* Xs_dev, int64_t W, double* cov_dev);

@@ -1567,13 +1567,78 @@ int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, doub
             Xg[e] = c->Xs;
         }
     }
-    for (int e = 0; e < E;) {                          // K*^T: one launch per run of emulators of equal padded size and input count
+    // Option key 48 (c0->kx_overlap = per cent of the batch's GPs in the first group; measured, profiles/r05_kcross_overlap.txt):
+    // the GPs of the batch in TWO groups, in emuList order — K*^T of the second group runs on the side stream while the first
+    // group's predict launch has the matrix pipes (k_kcross is fp64 vector work and stores, k_predict leaves both idle).  The
+    // kernels are the shared-launch ones over GP ranges: every tile computes what it computes in the one-launch form.
+    bool overlap = c0->kx_overlap > 0 && c0->chain_batch && E + 1 <= 32;
+    int64_t Gall = 0;
+    for (int e = 0; e < E && overlap; ++e) {
+        const gpb_ctx* c = ctxs[e];
+        overlap = c->n_diff == 0 && c->Np == c0->Np && c->d == c0->d && c->dpad == c0->dpad && !c->multi;
+        Gall += c->P;
+    }
+    overlap = overlap && Gall >= 2 && Gall <= GPB_MAX_MULTI_GP;
+    if (overlap) {
+        if (!c0->side_stream) {
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
+                hipStreamCreateWithPriority(&c0->side_stream, hipStreamNonBlocking, lo) != hipSuccess) {
+                c0->err = "gpb: could not create the side stream"; return GPB_E_HIP;
+            }
+        }
+        for (int i = 0; i < 2; ++i)
+            if (!c0->ov_ev[i] && hipEventCreateWithFlags(&c0->ov_ev[i], hipEventDisableTiming) != hipSuccess) {
+                c0->err = "gpb: could not create an event"; return GPB_E_HIP;
+            }
+        int64_t GA = (Gall * c0->kx_overlap + 50) / 100;
+        GA = GA < 1 ? 1 : (GA > Gall - 1 ? Gall - 1 : GA);
+        gpb_ctx* ca[33]; gpb_ctx* cb[33];
+        const double* xa[33]; const double* xb[33];
+        int a0[33], a1[33], b0[33], b1[33], na = 0, nb = 0;
+        int64_t g = 0;
+        for (int e = 0; e < E; ++e) {                  // GPs [0, GA) of the emuList-order list: group A; the rest: group B
+            const int64_t P = ctxs[e]->P, cut = GA - g < 0 ? 0 : (GA - g > P ? P : GA - g);
+            if (cut > 0) { ca[na] = ctxs[e]; xa[na] = Xg[e]; a0[na] = 0; a1[na] = (int)cut; ++na; }
+            if (cut < P) { cb[nb] = ctxs[e]; xb[nb] = Xg[e]; b0[nb] = (int)cut; b1[nb] = (int)P; ++nb; }
+            g += P;
+        }
+        hipError_t he;
+        // the gathered rows (and the parameter maps' outputs) are enqueued on the chain's stream: the side stream starts behind them
+        if ((he = hipEventRecord(c0->ov_ev[0], c0->stream)) != hipSuccess ||
+            (he = hipStreamWaitEvent(c0->side_stream, c0->ov_ev[0], 0)) != hipSuccess) { c0->err = hipGetErrorString(he); return GPB_E_HIP; }
+        if ((rc = launch_kcross_ranges(cb, xb, nb, b0, b1, W, cmpv, c0->side_stream))) { c0->err = cb[0]->err; return rc; }
+        if ((he = hipEventRecord(c0->ov_ev[1], c0->side_stream)) != hipSuccess) { c0->err = hipGetErrorString(he); return GPB_E_HIP; }
+        if ((rc = launch_kcross_ranges(ca, xa, na, a0, a1, W, cmpv, c0->stream))) { c0->err = ca[0]->err; return rc; }
+        ca[0]->hint_from = c0; cb[0]->hint_from = c0;
+        // timing events and unit counts of both launches go to the chain's first context (ca[0] == ctxs[0]); cb[0] borrows its state
+        if ((rc = launch_vsq(ca, na, W, cmpv, a0, a1, true, false))) { c0->err = ca[0]->err; return rc; }
+        if ((he = hipStreamWaitEvent(c0->stream, c0->ov_ev[1], 0)) != hipSuccess) { c0->err = hipGetErrorString(he); return GPB_E_HIP; }
+        if (cb[0] != c0) {                             // the pair is timed as one interval on c0: hand the open event over and back
+            cb[0]->profile = c0->profile; cb[0]->prof_open = c0->prof_open; cb[0]->prof_gps = c0->prof_gps;
+            c0->prof_open = nullptr;
+        }
+        rc = launch_vsq(cb, nb, W, cmpv, b0, b1, false, true);
+        if (cb[0] != c0) {
+            if (c0->profile) {
+                for (auto& ev : cb[0]->prof_events) c0->prof_events.push_back(ev);
+                cb[0]->prof_events.clear();
+                c0->prof_gps = cb[0]->prof_gps;
+                c0->prof_compacted = c0->prof_compacted || cb[0]->prof_compacted;
+                cb[0]->prof_compacted = false;
+                c0->prof_units += cb[0]->prof_units; cb[0]->prof_units = 0.0;
+            }
+            cb[0]->profile = false;
+        }
+        if (rc) { c0->err = cb[0]->err; return rc; }
+    }
+    for (int e = 0; e < E && !overlap;) {              // K*^T: one launch per run of emulators of equal padded size and input count
         int n = 1;
         while (c0->chain_batch && e + n < E && ctxs[e + n]->Np == ctxs[e]->Np && ctxs[e + n]->d == ctxs[e]->d && n < 32) ++n;
         if ((rc = launch_kcross_group(ctxs + e, Xg + e, n, W, cmpv))) { c0->err = ctxs[e]->err; return rc; }
         e += n;
     }
-    for (int e = 0; e < E;) {
+    for (int e = 0; e < E && !overlap;) {
         int n = 1, gps = (int)ctxs[e]->P;
         while (c0->chain_batch && e + n < E && ctxs[e + n]->Np == ctxs[e]->Np && gps + (int)ctxs[e + n]->P <= GPB_MAX_MULTI_GP) {
             gps += (int)ctxs[e + n]->P;

@@ -245,7 +245,7 @@ constexpr int MAX_KX_CTX = 32;
 struct KxCtx {
     const double *Xs, *Xc, *ls, *amp, *alpha, *dnorm, *muS;
     double *KsT, *mpart;
-    int N, P, kind, g0;
+    int N, P, kind, g0, p0;      // g0: index of the entry's first GP in the launch; p0: that GP's index in its context
 };
 struct KxTable { KxCtx c[MAX_KX_CTX]; int E; };
 
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void k_kcross_multi(const KxTable tab, int64_t
     int e = 0;
     while (e + 1 < tab.E && g >= tab.c[e + 1].g0) ++e;             // uniform: the emulator this GP belongs to
     const KxCtx& c = tab.c[e];
-    const int p = g - c.g0;
+    const int p = g - c.g0 + c.p0;
     if (c.kind == GPB_KERNEL_RBF)
         kcross_body<GPB_KERNEL_RBF, DPAD, true, WPL>(lds, c.Xs, W, d, c.Xc, c.ls, c.amp, c.alpha, c.KsT, c.mpart, c.N, Np, Wld,
                                                      c.P, c.dnorm, c.muS, chunks_per_wg, nrows, p);
@@ -1134,7 +1134,7 @@ int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, in
         c->Wld = Wuse;
         c->last_W = W;
         tab.c[e] = KxCtx{Xs[e], c->Xc, c->ls, c->amp, c->alpha, c->dnorm, c->muS, c->KsT, c->mpart, (int)c->N, (int)c->P,
-                         c->kind, G};
+                         c->kind, G, 0};
         G += (int)c->P;
     }
     tab.E = E;
@@ -1172,19 +1172,78 @@ int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, in
     return 0;
 }
 
+// The same launch for GP RANGES of the contexts, on a stream of the caller's choice (option key 48: a batch's GPs in two groups, the
+// second group's K*^T under the first group's predict launch).  The caller has checked that every context qualifies for the shared
+// launch (Gram form throughout, equal Np / d / dpad).  A GP's workgroups compute what they compute in any other launch: same bits.
+int launch_kcross_ranges(gpb_ctx* const* ctxs, const double* const* Xs, int E, const int* p0s, const int* p1s, int64_t W,
+                         const int* nrows_dev, hipStream_t stream) {
+    gpb_ctx* ctx = ctxs[0];
+    if (E < 1 || E > MAX_KX_CTX) GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_kcross_ranges: table size");
+    const int64_t Wuse = round_up(W, WPAD);
+    KxTable tab;
+    int G = 0;
+    for (int e = 0; e < E; ++e) {
+        gpb_ctx* c = ctxs[e];
+        if (c->multi || !c->factored || W > c->Wcap || c->n_diff != 0 || c->Np != ctx->Np || c->d != ctx->d || c->dpad != ctx->dpad ||
+            p0s[e] < 0 || p1s[e] > c->P || p0s[e] >= p1s[e])
+            GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_kcross_ranges over a context that does not qualify");
+        c->Wld = Wuse;
+        c->last_W = W;
+        tab.c[e] = KxCtx{Xs[e], c->Xc, c->ls, c->amp, c->alpha, c->dnorm, c->muS, c->KsT, c->mpart, (int)c->N, (int)c->P,
+                         c->kind, G, p0s[e]};
+        G += p1s[e] - p0s[e];
+    }
+    tab.E = E;
+    const int nchunk = (int)((ctx->Np + KX_CHUNK - 1) / KX_CHUNK);
+    const int wpl = (ctx->kcross_wpl == 2 && ctx->dpad <= 32 && Wuse >= 256 && Wuse % 128 == 0) ? 2 : 1;
+    int cpw = ctx->kcross_chunks;
+    if (cpw <= 0) {
+        const int64_t Wgeo = nrows_dev ? round_up(Wuse / 2, 64 * wpl) : Wuse;
+        const int64_t wgs1 = (Wgeo / (64 * wpl)) * nchunk * G;
+        cpw = 1;
+        while (cpw < 8 && wgs1 / (2 * cpw) >= 4 * (int64_t)ctx->num_cu) cpw *= 2;
+    }
+    if (Wuse / (64 * wpl) > 65535) GPB_FAIL(GPB_E_ARG, "gpb: more than 65535 walker tiles (4 million rows) in one batch: split it");
+    dim3 grid((unsigned)((nchunk + cpw - 1) / cpw), (unsigned)G, (unsigned)(Wuse / (64 * wpl)));
+#define GPB_KXM(DP)                                                                                              \
+    do {                                                                                                         \
+        if (wpl == 2)                                                                                            \
+            hipLaunchKernelGGL((k_kcross_multi<DP, (DP <= 32 ? 2 : 1)>), grid, dim3(256), 0, stream, tab, W,      \
+                               (int)ctx->d, ctx->Np, Wuse, cpw, nrows_dev);                                       \
+        else                                                                                                     \
+            hipLaunchKernelGGL((k_kcross_multi<DP, 1>), grid, dim3(256), 0, stream, tab, W, (int)ctx->d,         \
+                               ctx->Np, Wuse, cpw, nrows_dev);                                                   \
+    } while (0)
+    switch (ctx->dpad) {
+        case 8: GPB_KXM(8); break;
+        case 16: GPB_KXM(16); break;
+        case 20: GPB_KXM(20); break;
+        case 24: GPB_KXM(24); break;
+        case 32: GPB_KXM(32); break;
+        case 48: GPB_KXM(48); break;
+        default: GPB_KXM(64); break;
+    }
+#undef GPB_KXM
+    GPB_HIP(hipGetLastError());
+    return 0;
+}
+
 // V = L^-1 K*^T with the fused sum of squares for the GPs of E contexts in one launch (E = 1: an emulator's own launch;
 // E > 1: the emulators of a chain whose designs pad to the same Np — see k_predict_multi).  All contexts: same Np, same
 // batch (launch_kcross done), same stream.  Timing events and the unit count go to ctxs[0].
-int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev) {
+int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, const int* p0s, const int* p1s, bool prof_begin,
+               bool prof_end) {
     gpb_ctx* ctx = ctxs[0];
     const int64_t Wuse = round_up(W, WPAD);
     int64_t Gsum = 0;
     for (int e = 0; e < E; ++e) {
         if (ctxs[e]->Np != ctx->Np || ctxs[e]->Wld != Wuse || ctxs[e]->stream != ctx->stream)
             GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_vsq over contexts of different shape");
-        Gsum += ctxs[e]->P;
+        if (p0s && (p0s[e] < 0 || p1s[e] > ctxs[e]->P || p0s[e] >= p1s[e]))
+            GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_vsq: GP range");
+        Gsum += p0s ? p1s[e] - p0s[e] : ctxs[e]->P;
     }
-    const bool multi = E > 1;
+    const bool multi = E > 1 || p0s != nullptr;        // a GP range of one context: the table form of the same tiles
     if (multi && Gsum > MAX_MULTI_GP) GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_vsq: too many GPs for one table");
     const int64_t GP = Gsum;                           // GPs of the launch: what the tile counts are made of
     const int nI64 = (int)(ctx->Np / 64);
@@ -1239,9 +1298,15 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev) {
         if (ctx->force_tile == 65) { T = 64; TN = 128; }        // 64 rows x 128 walkers
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (ctx->profile) {                    // live HIP-event timing of the dominant kernel (bench.py)
-            GPB_HIP(hipEventCreate(&e0));
-            GPB_HIP(hipEventCreate(&e1));
-            GPB_HIP(hipEventRecord(e0, ctx->stream));
+            if (prof_begin) {
+                GPB_HIP(hipEventCreate(&e0));
+                GPB_HIP(hipEventRecord(e0, ctx->stream));
+                if (!prof_end) ctx->prof_open = e0;            // the first launch of a pair: its partner closes the interval
+            } else {
+                e0 = ctx->prof_open;
+                ctx->prof_open = nullptr;
+            }
+            if (prof_end) GPB_HIP(hipEventCreate(&e1));
         }
         const int nI = (T == 128) ? (int)((ctx->Np + 127) / 128) : nI64, nW = (int)(Wuse / TN);
         // which operand is larger decides the XCD affinity: L^-1 (P Np^2/2) or K*^T (P Np W)
@@ -1273,7 +1338,7 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev) {
             PredTable tab;
             int g = 0;
             for (int e = 0; e < E; ++e)
-                for (int pp = 0; pp < (int)ctxs[e]->P; ++pp, ++g)
+                for (int pp = p0s ? p0s[e] : 0; pp < (p0s ? p1s[e] : (int)ctxs[e]->P); ++pp, ++g)
                     tab.gp[g] = PredGP{ctxs[e]->Linv, ctxs[e]->KsT, ctxs[e]->spart, (int)ctxs[e]->P, pp};
             const int order = ctx->resident_order ? ctx->resident_order : 2;
             const int xr = xcd_rows < 2 ? xcd_rows : 0;
@@ -1378,9 +1443,12 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev) {
         }
 #undef GPB_PRED
         if (ctx->profile) {
-            GPB_HIP(hipEventRecord(e1, ctx->stream));
-            ctx->prof_events.push_back({e0, e1});
-            ctx->prof_gps = (double)GP;                                         // GPs per timed launch (a chain: all of them)
+            if (prof_end && e0) {
+                GPB_HIP(hipEventRecord(e1, ctx->stream));
+                ctx->prof_events.push_back({e0, e1});
+            }
+            // GPs per timed interval (a chain: all of them; a pair of launches: both groups')
+            ctx->prof_gps = prof_begin ? (double)GP : ctx->prof_gps + (double)GP;
             if (!nrows_dev) ctx->prof_units += (double)GP * (double)W;          // compacted: counted on the device
             else ctx->prof_compacted = true;
         }
