@@ -135,7 +135,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
     gpb_dist_finalize(ctx);
     free(ctx->h_theta);
-    dev_free(&ctx->lr_R); dev_free(&ctx->lr_v0);
+    dev_free(&ctx->lr_R); dev_free(&ctx->lr_v0); dev_free(&ctx->lr_blocks);
     dev_free(&ctx->xmean); dev_free(&ctx->muS); dev_free(&ctx->Xc); dev_free(&ctx->dnorm); dev_free(&ctx->gpform); dev_free(&ctx->kmtiles); dev_free(&ctx->gpN); dev_free(&ctx->gpmap);
     dev_free(&ctx->X); dev_free(&ctx->Xsc); dev_free(&ctx->ls); dev_free(&ctx->amp); dev_free(&ctx->noise);
     dev_free(&ctx->Z); dev_free(&ctx->K); dev_free(&ctx->Linv); dev_free(&ctx->LinvT); dev_free(&ctx->T); dev_free(&ctx->yv);
@@ -1019,7 +1019,7 @@ extern "C" int gpb_ctx_option(gpb_ctx* ctx, int key, int value) {
     {
         const bool variant = (key == 2 && value != 4) || (key == 5 && value == 0) || (key == 26 && value != 0) || (key == 32 && value != 0) ||
                              (key == 21 && value != 1) || (key == 24 && value != 1) || (key == 37 && value != 1) ||
-                             (key == 38 && value != 0) || (key == 39 && value != 1) || (key == 41 && value != 0);
+                             (key == 38 && value != 0) || (key == 39 && value != 1) || (key == 41 && value != 0) || (key == 48 && value != 0);
         if (variant) GPB_FAIL(GPB_E_ARG, "gpb_ctx_option: this value selects a kernel variant or hook of the debug build only");
     }
 #endif
@@ -1092,6 +1092,7 @@ extern "C" int gpb_ctx_option(gpb_ctx* ctx, int key, int value) {
 #endif
         case 47: if (value < 0 || value > 2) return GPB_E_ARG; ctx->chol_pair = value; break;
         case 48: if (value < 0 || value > 99) return GPB_E_ARG; ctx->kx_overlap = value; break;
+        case 49: if (value < 0 || value > 1) return GPB_E_ARG; ctx->lr_split = value; break;
         case 44: if (value < 0) return GPB_E_ARG; ctx->tile_switch = value > 0 ? value : 960; break;
         case 33: if (value < 0) return GPB_E_ARG; ctx->tile_switch_c = value; break;
         case 34: if (value < 0) return GPB_E_ARG; ctx->mid_switch_c = value; break;

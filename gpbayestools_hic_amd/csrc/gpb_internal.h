@@ -137,6 +137,9 @@ struct gpb_ctx {
     double lr_logdet0 = 0.0;       // log det C0
     bool lr_ok = false;
     int lowrank = 1;               // use it when it applies (tune key 23)
+    int lr_split = 1;              // option key 49: a chain's block likelihoods as one workgroup per (walker tile, emulator) + an ordered sum
+    double* lr_blocks = nullptr;   // [E][Wcap] the emulators' blocks of a chain's batch (chain's first context)
+    int64_t lr_blocks_cap = 0;
     double* A = nullptr;           // [P][M]
     double* mu = nullptr;          // [M]
     double* scale = nullptr;       // [M]

@@ -688,10 +688,13 @@ struct LrCtx {
 };
 struct LrTable { LrCtx c[MAX_LR_CTX]; int E; };
 
+// Round 5: with `blocks` set the grid is (walker tiles, emulators): workgroup (t, e) computes emulator e's block alone and leaves
+// it in blocks[e][w]; k_lowrank_sum then adds a row's blocks in emuList order — the same additions as the walk below, which ran
+// nine latency-bound bodies one after the other in each of only W / 64 workgroups (57 us for nine emulators at 2048 rows).
 template <int PP>
 __global__ __launch_bounds__(lr_threads<PP>()) void k_loglike_lowrank_multi(const LrTable tab, int64_t Wld, int64_t W,
                                                               double* __restrict__ ll, const int* __restrict__ cmp,
-                                                              double inside_const) {
+                                                              double inside_const, double* __restrict__ blocks) {
     __shared__ double sR[PP][PP + 1];
     __shared__ double sv0[PP];
     __shared__ double smg[2][PP][64];
@@ -699,10 +702,11 @@ __global__ __launch_bounds__(lr_threads<PP>()) void k_loglike_lowrank_multi(cons
     const int64_t w = (int64_t)blockIdx.x * 64 + lane;
     const bool live = w < W && w < cmp[0];
     double total = 0.0;
-    for (int e = 0; e < tab.E; ++e) {
+    const int e_begin = blocks ? (int)blockIdx.y : 0, e_end = blocks ? (int)blockIdx.y + 1 : tab.E;
+    for (int e = e_begin; e < e_end; ++e) {
         const LrCtx& c = tab.c[e];
         const int P = c.P;
-        if (e) __syncthreads();                        // wave 0 is done with the previous emulator's tables
+        if (e > e_begin) __syncthreads();              // wave 0 is done with the previous emulator's tables
         for (int i = threadIdx.x; i < PP * PP; i += lr_threads<PP>()) sR[i / PP][i % PP] = c.R[(i / PP) * 16 + (i % PP)];
         if (threadIdx.x < PP) sv0[threadIdx.x] = c.v0[threadIdx.x];
         if (live)                                      // k_finalize's sums, in its order (as k_loglike_lowrank)
@@ -755,9 +759,20 @@ __global__ __launch_bounds__(lr_threads<PP>()) void k_loglike_lowrank_multi(cons
             r = nan("");
             atomicAdd(c.notpd, 1);
         }
+        if (blocks) { blocks[(int64_t)e * Wld + w] = r; return; }      // (grp 0, live: the ordered sum follows in k_lowrank_sum)
         total = e ? (total + r) : r;                   // ll = r0; ll = ll + r1; ... as the separate launches accumulate
     }
-    if (grp == 0 && live) ll[cmp[4 + w]] = total + inside_const;
+    if (grp == 0 && live && !blocks) ll[cmp[4 + w]] = total + inside_const;
+}
+
+// a row's log-likelihood = its emulators' blocks added in emuList order (ll = r0; ll = ll + r1; ...), + the constant
+__global__ __launch_bounds__(256) void k_lowrank_sum(const double* __restrict__ blocks, int E, int64_t Wld, int64_t W,
+                                                     double* __restrict__ ll, const int* __restrict__ cmp, double inside_const) {
+    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= W || w >= cmp[0]) return;
+    double total = blocks[w];
+    for (int e = 1; e < E; ++e) total = total + blocks[(int64_t)e * Wld + w];
+    ll[cmp[4 + w]] = total + inside_const;
 }
 
 __global__ void k_box(const double* __restrict__ X, int64_t W, int d, const double* __restrict__ lo,
@@ -1520,6 +1535,19 @@ int64_t chain_ndim(const gpb_ctx* c) { return c->pmap_d_in > 0 ? c->pmap_d_in : 
 // take any number; k_compact_mark stages 256 rows of it in LDS in tiles, so the bound is only a sanity limit.
 constexpr int64_t MAX_CHAIN_NDIM = 512;
 
+// the per-emulator blocks of a chain's log-likelihood, [E][Wcap] in the chain's first context (k_loglike_lowrank_multi / k_lowrank_sum)
+int ensure_lr_blocks(gpb_ctx* ctx, int E) {
+    if (E < 2 || !ctx->lr_split) return 0;
+    const int64_t need = (int64_t)E * ctx->Wcap;
+    if (ctx->lr_blocks_cap >= need) return 0;
+    GPB_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->lr_blocks) { pool_free(ctx->lr_blocks); ctx->lr_blocks = nullptr; }
+    ctx->lr_blocks_cap = 0;
+    GPB_HIP(pool_malloc_t(&ctx->lr_blocks, sizeof(double) * (size_t)need));
+    ctx->lr_blocks_cap = need;
+    return 0;
+}
+
 // every context usable by the compacted chain path?  (same device, stream and parameter space; likelihood installed;
 // a block likelihood kernel applies)
 int chain_check(gpb_ctx* const* ctxs, int E, const char* who) {
@@ -1548,6 +1576,7 @@ int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, doub
     int rc;
     for (int e = 0; e < E; ++e)
         if ((rc = ensure_wcap(ctxs[e], W))) { if (e) c0->err = ctxs[e]->err; return rc; }
+    if ((rc = ensure_lr_blocks(c0, E))) return rc;
     if ((rc = launch_compact(c0, X_dev, W, chain_ndim(c0), lo_dev, hi_dev, outside, ll_dev, premarked))) return rc;
     if (!cmpv) cmpv = c0->cmp_idx;                     // (count, -, -, -, indices ...) of the rows inside the box
     // Three passes over the emulators (each kernel sees what it would see in its own emulator's sequence: same bits):
@@ -1567,11 +1596,15 @@ int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, doub
             Xg[e] = c->Xs;
         }
     }
-    // Option key 48 (c0->kx_overlap = per cent of the batch's GPs in the first group; measured, profiles/r05_kcross_overlap.txt):
-    // the GPs of the batch in TWO groups, in emuList order — K*^T of the second group runs on the side stream while the first
-    // group's predict launch has the matrix pipes (k_kcross is fp64 vector work and stores, k_predict leaves both idle).  The
-    // kernels are the shared-launch ones over GP ranges: every tile computes what it computes in the one-launch form.
-    bool overlap = c0->kx_overlap > 0 && c0->chain_batch && E + 1 <= 32;
+    bool overlap = false;
+#ifdef GPB_DEBUG_VARIANTS
+    // Option key 48 (debug build; c0->kx_overlap = per cent of the batch's GPs in the first group): the GPs of the batch in TWO
+    // groups, in emuList order — K*^T of the second group runs on the side stream while the first group's predict launch has the
+    // matrix pipes.  The kernels are the shared-launch ones over GP ranges: every tile computes what it computes in the one-launch
+    // form (same bits, tested).  MEASURED AND REJECTED (profiles/r05_kcross_overlap.txt): 2-3 % SLOWER at cfg 4, 0.5-2 % slower on
+    // the nine-emulator chain, 15-23 % slower on a rank's share of eight — on this part an fp64 MFMA and fp64 vector work share
+    // the same units, so the cross kernel under the predict launch takes its cycles, and two predict launches have two tails.
+    overlap = c0->kx_overlap > 0 && c0->chain_batch && E + 1 <= 32;
     int64_t Gall = 0;
     for (int e = 0; e < E && overlap; ++e) {
         const gpb_ctx* c = ctxs[e];
@@ -1632,6 +1665,7 @@ int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, doub
         }
         if (rc) { c0->err = cb[0]->err; return rc; }
     }
+#endif
     for (int e = 0; e < E && !overlap;) {              // K*^T: one launch per run of emulators of equal padded size and input count
         int n = 1;
         while (c0->chain_batch && e + n < E && ctxs[e + n]->Np == ctxs[e]->Np && ctxs[e + n]->d == ctxs[e]->d && n < 32) ++n;
@@ -1662,11 +1696,17 @@ int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, doub
                                  (int)c->P, (int)((c->Np + KX_CHUNK - 1) / KX_CHUNK), (int)(c->Np / 64)};
             }
             tab.E = E;
-            const dim3 grid((unsigned)((W + 63) / 64));
+            // one workgroup per (walker tile, emulator) + the ordered sum, when the blocks' buffer is there (ensure_lr_blocks;
+            // option key 49 = 0: the one-launch walk — the A/B, and the bit-identity test)
+            double* blocks = (c0->lr_split && c0->lr_blocks && c0->lr_blocks_cap >= (int64_t)E * c0->Wld) ? c0->lr_blocks : nullptr;
+            const dim3 grid((unsigned)((W + 63) / 64), blocks ? (unsigned)E : 1u);
 #define GPB_LRM(PPV)                                                                                             \
-    hipLaunchKernelGGL(k_loglike_lowrank_multi<PPV>, grid, dim3(lr_threads<PPV>()), 0, c0->stream, tab, c0->Wld, W, ll_dev, cmpv, inside_const)
+    hipLaunchKernelGGL(k_loglike_lowrank_multi<PPV>, grid, dim3(lr_threads<PPV>()), 0, c0->stream, tab, c0->Wld, W, ll_dev, cmpv, inside_const, blocks)
             if (pmax <= 4) GPB_LRM(4); else if (pmax <= 8) GPB_LRM(8); else if (pmax <= 12) GPB_LRM(12); else GPB_LRM(16);
 #undef GPB_LRM
+            if (blocks)
+                hipLaunchKernelGGL(k_lowrank_sum, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, c0->stream, blocks, E, c0->Wld, W,
+                                   ll_dev, cmpv, inside_const);
             if (hipGetLastError() != hipSuccess) { c0->err = "gpb: k_loglike_lowrank_multi launch failed"; return GPB_E_HIP; }
             return 0;
         }
@@ -1749,6 +1789,7 @@ int emcee_plan(gpb_ctx* const* ctxs, int E, int64_t nwalkers, EmceePlan& pl) {
     const int64_t chunk = pl.chunk;
     for (int e = 0; e < E; ++e)                        // all workspaces now: the loop holds pointers into them
         if ((rc = ensure_wcap(ctxs[e], chunk))) { if (e) ctx->err = ctxs[e]->err; return rc; }
+    if (!pl.plain && (rc = ensure_lr_blocks(ctx, E))) return rc;
     // proposal workspace: two sets of q[nh][d], factor[nh], lpq[nh] (the fused accept + proposal kernel reads one set and
     // writes the other) and a second log-probability vector [nwalkers]
     if (ctx->mc_cap < 2 * nh * (d + 3)) {

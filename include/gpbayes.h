@@ -282,9 +282,9 @@ GPB_API int gpb_dist_finalize(gpb_ctx* ctx);
  *   44 the number of 128x128 predict tiles per 256 CUs from which the rule takes them (0: default 960);
  *   47 Cholesky by column pairs (every second trailing update takes two block columns at once, K = 128): 1 where it is the faster
  *   schedule (default: 1536 < N <= 3072), 2 always, 0 never; results agree to rounding (another order of the same sums);
- *   48 the GPs of a log-posterior batch in two groups — value = per cent of them in the first — with the second group's K*^T on a
- *   side stream under the first group's predict launch (0: one launch of each, default; same bits either way).
- *   Keys and values that select a measured-and-rejected kernel variant or a measurement hook (2, 21, 24, 26, 32, 37, 38, 39, 41
+ *   49 the block log-likelihoods of a chain of emulators as one workgroup per (walker tile, emulator) and an ordered sum (1,
+ *   default) or as one workgroup per walker tile that walks the emulators (0); same bits.
+ *   Keys and values that select a measured-and-rejected kernel variant or a measurement hook (2, 21, 24, 26, 32, 37, 38, 39, 41, 48
  *   and 5 = 0) exist in the debug build only (libgpbayes_debug.so: include/gpbayes_debug.h) and return GPB_E_ARG here.
  * gpb_debug_has_variants: 1 when the loaded library is that debug build (-DGPB_DEBUG_VARIANTS), 0 for the product library.
  * gpb_profile_enable / _read: HIP-event timing of the dominant kernel (k_predict: V = L^-1 K*^T + sum of squares) on the

@@ -242,10 +242,11 @@ def test_chain_with_more_than_64_parameters(tmp_path):
 
 
 @pytest.mark.parametrize("specs", [[(100, 20, 4, "RBF"), (120, 24, 6, "Matern25"), (128, 16, 3, "RBF")], [(200, 30, 10, "RBF")]])
-def test_cross_kernel_of_the_second_gp_group_under_the_first_groups_predict_launch(tmp_path, specs):
-    """option key 48: the batch's GPs in two groups, the second group's K*^T on the side stream while the first group's predict
-    launch runs (two streams, two events per batch).  Every tile computes what it computes in the one-launch form: log-posterior
-    batches and the resident step loop give the same bits for any split — also one that cuts an emulator's GPs in two."""
+def test_cross_kernel_of_the_second_gp_group_under_the_first_groups_predict_launch(tmp_path, specs, debug_lib):
+    """option key 48 (debug build: measured and rejected, profiles/r05_kcross_overlap.txt): the batch's GPs in two groups, the
+    second group's K*^T on the side stream while the first group's predict launch runs (two streams, two events per batch).
+    Every tile computes what it computes in the one-launch form: log-posterior batches and the resident step loop give the same
+    bits for any split — also one that cuts an emulator's GPs in two."""
     from gpbayestools_hic_amd import StretchSampler, synth
     from gpbayestools_hic_amd.workload import build_multi_chain
     chain, emus, info = build_multi_chain(specs, D, workdir=str(tmp_path))
@@ -275,3 +276,30 @@ def test_cross_kernel_of_the_second_gp_group_under_the_first_groups_predict_laun
     assert n == 1 and ms > 0 and units == sum(sp[2] for sp in specs) * 512
     e0.tune("kx_overlap", 0)
     assert np.array_equal(chain.log_posterior(X), ref)
+
+
+def test_chain_block_likelihoods_split_over_workgroups_give_the_walks_bits(tmp_path):
+    """option key 49: the block log-likelihoods of a chain's emulators as one workgroup per (walker tile, emulator) + an ordered sum
+    (default) against one workgroup per walker tile walking the emulators: the same additions in the same order, bit for bit — on
+    batches with rows outside the box, tiny batches, and through the resident step loop"""
+    from gpbayestools_hic_amd import StretchSampler, synth
+    from gpbayestools_hic_amd.workload import build_multi_chain
+    chain, emus, info = build_multi_chain(SPECS, D, workdir=str(tmp_path))
+    e0 = emus[0]._engine_ready()
+    X = synth.walkers(1500, D, seed=21)
+    X[::11, 3] = -0.25
+    X0 = synth.walkers(192, D, seed=4)
+    outs = {}
+    for split in (1, 0, 1):
+        e0.tune("lr_split", split)
+        s = StretchSampler(chain, 192, seed=9)
+        outs.setdefault(split, []).append((chain.log_posterior(X), chain.log_posterior(X[:3]), chain.log_likelihood(X[:65], finite=True),
+                                           s.run(X0, 5, status=10 ** 9), s.lnprobability))
+    for a, b in zip(outs[1][0], outs[0][0]):
+        assert np.array_equal(a, b)
+    for a, b in zip(outs[1][0], outs[1][1]):
+        assert np.array_equal(a, b)
+    assert np.isneginf(outs[1][0][0][::11]).all() and np.isfinite(outs[1][0][0][1::11]).all()
+    ref = _oracle_chain(info)(X[:40])
+    ins = np.isfinite(ref)
+    assert relerr(outs[1][0][0][:40][ins], ref[ins]) < 1e-10
