@@ -553,12 +553,19 @@ def main():
               f"whose size is not the one asked for", file=sys.stderr)
         sys.exit(2)
 
-    # GPB_BENCH_WATCHDOG=N: seconds a phase (start-up incl. the first `import torch`, set-up, each timed run) may take; 0 = off.
-    # A multi-rank run has it on by default, at 240 s: three phases stay inside the driver's 600 s limit, so a stalled N-rank
-    # line ends as a FAILED line with every rank's stacks, never as a hang.
+    # GPB_BENCH_WATCHDOG=N: seconds a phase may take; 0 = off.  A multi-rank run has it on by default, at 240 s — and the whole run
+    # has 570 s (the driver's limit for a bench line is 600 s): start-up gets up to 1.6 N (the first `import torch` on a fresh box
+    # takes 1-2 minutes, longer with eight ranks paging the same files in), set-up N / 2, each timed run 3 N / 8, all cut to what
+    # is left of the total — so a stalled N-rank line ends as a FAILED line with every rank's stacks, never as a hang, and a slow
+    # but healthy start is not shot.
     wd_s = float(os.environ.get("GPB_BENCH_WATCHDOG", "240" if args.gpus > 1 else "0"))
+    t_begin = time.monotonic()
     dog = Watchdog("rank %s of %d" % (os.environ.get("RANK", "0"), args.gpus))
-    dog.arm(wd_s, "start-up (import torch, rendezvous)")
+
+    def phase(frac, name):
+        left = 2.375 * wd_s - (time.monotonic() - t_begin)          # 570 s at the default
+        dog.arm(max(min(frac * wd_s, left), 1.0) if wd_s > 0 else 0.0, name)
+    phase(1.6, "start-up (import torch, rendezvous)")
     if wd_s > 0:
         import faulthandler, signal
         faulthandler.register(signal.SIGTERM, chain=True)
@@ -572,7 +579,7 @@ def main():
     rank, world, local = init_from_env()
     assert world == args.gpus
     torch.cuda.set_device(local)
-    dog.arm(min(wd_s, 120.0), "set-up (training, replication, self-checks)")
+    phase(0.5, "set-up (training, replication, self-checks)")
     chain, emu, info = build_chain(args.config, device=local)
     N, d, M, P = info["N"], info["d"], info["M"], info["P"]
     nwalkers = args.walkers or 2 * info["W"]
@@ -661,7 +668,7 @@ def main():
             return smp, float(mx[0].item()), launches, kms, units, float(sm[1].item())
         return smp, dt, launches, kms, units, units
 
-    dog.arm(min(wd_s, 90.0), "timed run (pre-heat, warm-up, timed steps; burnt-in start)")
+    phase(0.375, "timed run (pre-heat, warm-up, timed steps; burnt-in start)")
     _, dt, launches, kms, units, units_all = timed_run(X0, None)
     acc = float(sampler.acceptance_fraction.mean())
     inside_frac = (units_all / (launches * P * (nwalkers // 2))) if launches else None      # all ranks' rows
@@ -700,7 +707,7 @@ def main():
     # leave the 20-dimensional box and are not evaluated
     uni = None
     if not args.no_uniform:
-        dog.arm(min(wd_s, 90.0), "timed run from the uniform start")
+        phase(0.375, "timed run from the uniform start")
         su, dtu, lu, kmsu, unitsu, units_all_u = timed_run(X0_uniform, 4242)
         uni = {"value": nwalkers * args.steps / dtu, "unit": "walker-evals/s (proposals outside the box counted, not evaluated)",
                "value_evaluated": units_all_u / P / dtu, "ms_per_step": dtu / args.steps * 1e3,
@@ -712,7 +719,10 @@ def main():
                "what": "the same step loop started from walkers uniform in the prior box (SURVEY 8d's walkers)"}
         del su
 
-    dog.arm(0.0 if world == 1 else min(wd_s, 60.0), "result line")      # (extras and the CPU baseline: N = 1 only, minutes)
+    if world == 1:
+        dog.arm(0.0, "result line")                      # (extras and the CPU baseline: N = 1 only, minutes)
+    else:
+        phase(0.25, "result line")
     if rank == 0:
         value = nwalkers * args.steps / dt if not degraded else units_all / P / dt
         alg_flops_per_launch = units / max(launches, 1) * float(N) * float(N)     # N^2 per (GP, walker): the trsm term
