@@ -765,15 +765,15 @@ def main():
                          "launches": launches, "avg_launch_ms": kms / max(launches, 1)},
         }
         # HBM-side traffic of the dominant kernel: PMC counters need rocprofv3, so the per-launch figure comes
-        # from the committed summary of the same command (profiles/r04_pmc_traffic.json), when it matches.
+        # from the committed summary of the same command (profiles/r05_pmc_traffic.json), when it matches.
         try:
-            with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")) as f:
                 pmc = json.load(f)
             wl = pmc["workload"]
             if (wl["config"], wl["N"], wl["P"], wl["W_per_launch"]) == (args.config, N, P, nwalkers // 2) and world == 1 \
                     and wl.get("burnt_in"):
                 out["roofline"]["traffic"] = pmc["k_predict"]["bytes_per_launch_corrected"]
-                out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r04_pmc_traffic.json)"
+                out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r05_pmc_traffic.json)"
                 out["roofline"]["algorithmic_bytes"] = pmc["k_predict"]["algorithmic_bytes_per_launch"]
         except Exception:
             pass

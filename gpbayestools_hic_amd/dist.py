@@ -94,6 +94,15 @@ class WalkerSharding:
             return torch.device("cpu")
         return torch.device("cuda", torch.cuda.current_device())
 
+    def backend(self):
+        return self.dist.get_backend(self.group)
+
+    def broadcast_object(self, obj, src=0):
+        """rank `src`'s picklable object on every rank (collective)"""
+        box = [obj if self.rank == src else None]
+        self.dist.broadcast_object_list(box, src=src, group=self.group)
+        return box[0]
+
     def _all_ok(self, ok):
         import torch
         t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self._coll_device())

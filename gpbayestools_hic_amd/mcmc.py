@@ -341,22 +341,38 @@ class Chain:
         resume from an existing chain pickle, else two-stage burn-in with re-seeding at the
         `nwalkers` best unique log-probabilities, then production; thinned chain appended to
         `{'chain': [nwalkers, nsteps/nthin, ndim]}`.  The stretch move runs on the device
-        (sampler.StretchSampler) instead of emcee."""
+        (sampler.StretchSampler) instead of emcee.  After `shard_over(WalkerSharding())` the walkers are sharded over the
+        GPUs of the group (collective: every rank calls it with the same arguments)."""
         from .sampler import StretchSampler
+        # Several GPUs (chain.shard_over(WalkerSharding()), one process per GPU, every rank makes this call): the sampler runs
+        # replicated and walker-sharded — rank 0's start positions, seed and chain file are everybody's (broadcast: numpy's
+        # global RandomState and a file system need not agree between processes), every half-step's rows are evaluated in shares
+        # with one all-gather (in-stream RCCL when the group's backend is nccl), every rank ends with the same chain, rank 0
+        # writes the pickle.  The samples are those of the single-GPU run with the same seed and start, bit for bit.
+        sh = self.sharding if (self.sharding is not None and getattr(self.sharding, "world", 1) > 1) else None
+        root = sh is None or sh.rank == 0
+        share = (lambda obj: obj) if sh is None else sh.broadcast_object
         chain_data = {}
-        try:
-            with open(self.mcmc_path, "rb") as f:
-                chain_data = pickle.load(f)
-        except FileNotFoundError:
-            pass
-        burn = "chain" not in chain_data
+        if root:
+            try:
+                with open(self.mcmc_path, "rb") as f:
+                    chain_data = pickle.load(f)
+            except FileNotFoundError:
+                pass
+        burn = share("chain" not in chain_data)
         if nburnsteps is None or nwalkers is None:
             log.error("must specify nburnsteps and nwalkers to start chain")
             return
-        sampler = StretchSampler(self, nwalkers, seed=seed)
+        if sh is not None:
+            if seed is None:
+                seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
+            seed = share(int(seed))
+            if sh.direct is None and sh.backend() == "nccl" and self._native():
+                sh.try_direct(self.emuList[0]._engine_ready())        # collective; torch.distributed's all-gather stays otherwise
+        sampler = StretchSampler(self, nwalkers, seed=seed, sharding=sh)
         if burn:
             nburn0 = nburnsteps // 2
-            sampler.run(self.random_pos(nwalkers), nburn0, status=status)
+            sampler.run(share(self.random_pos(nwalkers) if root else None), nburn0, status=status)
             flat_lp = sampler.lnprobability.reshape(-1)
             flat_x = sampler.chain.reshape(-1, self.ndim)
             X0 = flat_x[np.unique(flat_lp, return_index=True)[1][-nwalkers:]]
@@ -364,17 +380,20 @@ class Chain:
             X0 = sampler.run(X0, nburnsteps - nburn0, status=status)
             sampler.reset()
         else:
-            X0 = chain_data["chain"][:, -1, :]
+            X0 = share(chain_data["chain"][:, -1, :] if root else None)
         sampler.run(X0, nsteps, status=status)
         thinned = sampler.chain[:, ::nthin, :]
         if "chain" in chain_data:
             chain_data["chain"] = np.concatenate((chain_data["chain"], thinned), axis=1)
         else:
             chain_data["chain"] = thinned
-        self.chain = chain_data["chain"]
+        self.chain = chain_data["chain"] if root else thinned
         self.acceptance_fraction = sampler.acceptance_fraction
-        with open(self.mcmc_path, "wb") as f:
-            pickle.dump(chain_data, f)
+        if root:
+            with open(self.mcmc_path, "wb") as f:
+                pickle.dump(chain_data, f)
+        if sh is not None:
+            self.chain = share(self.chain if root else None)          # (also: nobody returns before the file is written)
 
     def run_pocoMC(self, n_effective=1000, n_active=250, n_prior=2000, sample="tpcn", n_max_steps=200,
                    random_state=42, n_total=5000, n_evidence=5000, pool=None, prior=None):

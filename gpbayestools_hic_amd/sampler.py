@@ -132,17 +132,6 @@ class StretchSampler:
         lib, h = eng.lib, eng.h
         nw, d = self.nwalkers, self.ndim
         eng._track_stream()
-        if X0 is not None:            # X0=None: continue from the resident state
-            self.pos.copy_(torch.as_tensor(np.ascontiguousarray(X0, dtype=np.float64)))
-            self._eval(self.pos, self.lp)
-            if torch.isnan(self.lp).any().item():
-                raise ValueError("The initial log_prob was NaN")          # emcee's message
-        cd = ld = None
-        if store:
-            cd = torch.empty((nsteps, nw, d), dtype=torch.float64, device=self.device)
-            ld = torch.empty((nsteps, nw), dtype=torch.float64, device=self.device)
-        if status is None:
-            status = max(nsteps // 10, 1)
         sh = self.sharding
         if sh is not None and getattr(sh, "world", 1) > 1 and hasattr(sh, "agree_state") and hasattr(self.chain_obj, "state_digest") \
                 and not self._logprob_override:
@@ -152,6 +141,21 @@ class StretchSampler:
             # (which of its engines were rebuilt, whether it has sampled before)
             ch = self.chain_obj
             sh.agree_state(ch.state_digest_cached() if hasattr(ch, "state_digest_cached") else ch.state_digest())
+        if X0 is not None:            # X0=None: continue from the resident state
+            self.pos.copy_(torch.as_tensor(np.ascontiguousarray(X0, dtype=np.float64)))
+            shd = self.sharding
+            if shd is not None and getattr(shd, "world", 1) > 1 and hasattr(shd, "rows_agree_begin"):
+                # replicated sampler: every rank must start from THE SAME ensemble (checksum all-reduce; raises on every rank)
+                shd.rows_agree_end(shd.rows_agree_begin(self.pos))
+            self._eval(self.pos, self.lp)
+            if torch.isnan(self.lp).any().item():
+                raise ValueError("The initial log_prob was NaN")          # emcee's message
+        cd = ld = None
+        if store:
+            cd = torch.empty((nsteps, nw, d), dtype=torch.float64, device=self.device)
+            ld = torch.empty((nsteps, nw), dtype=torch.float64, device=self.device)
+        if status is None:
+            status = max(nsteps // 10, 1)
         res = self._resident_engine()
         if res is not None and self.sharding is not None:
             # sharded C loop: whatever can fail on ONE rank (state checks, workspace allocation) is done now, and the

@@ -176,3 +176,69 @@ def test_replicate_then_shard_over_then_batches_without_a_sampler_run(tmp_path):
         assert rebuilt and kept
         for a, b in zip(ll, want):
             assert np.array_equal(a, b), r
+
+
+def _mcmc_calls(chain):
+    chain.run_mcmc(nsteps=12, nburnsteps=8, nwalkers=32, nthin=3, seed=7, status=100)       # burn-in, re-seeding, production
+    first = chain.chain.copy()
+    chain.run_mcmc(nsteps=6, nburnsteps=8, nwalkers=32, nthin=3, seed=8, status=100)        # resumes from the chain file
+    return first, chain.chain.copy(), np.asarray(chain.acceptance_fraction).copy()
+
+
+def _mcmc_worker(rank, world, port, workdir, q):
+    import faulthandler
+    import traceback
+    faulthandler.dump_traceback_later(200, exit=True)
+    try:
+        sys.path.insert(0, REPO)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        import torch.distributed as dist
+        from gpbayestools_hic_amd.dist import WalkerSharding, init_from_env
+        init_from_env(backend="gloo")
+        d = os.path.join(workdir, f"r{rank}"); os.makedirs(d, exist_ok=True)
+        chain, emu, info = _build(d, perturb=False)
+        sh = WalkerSharding()
+        sh.replicate(chain)
+        chain.shard_over(sh)
+        np.random.seed(5 if rank == 0 else 99)        # the start positions are rank 0's draws, whatever the others would draw
+        out = _mcmc_calls(chain)
+        wrote = os.path.exists(chain.mcmc_path)
+        dist.barrier()
+        q.put((rank, "ok", out, wrote))
+        dist.destroy_process_group()
+    except BaseException:                             # noqa: BLE001
+        q.put((rank, "ERROR", traceback.format_exc(), None))
+        raise
+
+
+def test_run_mcmc_walker_sharded_over_two_ranks_is_the_single_gpu_chain(tmp_path):
+    """Chain.run_mcmc after shard_over (src/mcmc.py:345-426 on several GPUs): rank 0's start, seed and chain file are everybody's,
+    every half-step is evaluated in shares; both ranks end with the single-process chain — burn-in with re-seeding, production,
+    thinning, resume — bit for bit, and only rank 0 writes the pickle."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mcmc_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs: p.start()
+    got = {}
+    try:
+        for _ in range(world):
+            r = q.get(timeout=300)
+            assert r[1] != "ERROR", "rank %d:\n%s" % (r[0], r[2])
+            got[r[0]] = r[2:]
+    finally:
+        for p in procs:
+            p.join(timeout=5 if len(got) < world else 120)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
+    one = tmp_path / "single"; one.mkdir()
+    chain, emu, info = _build(str(one), perturb=False)
+    np.random.seed(5)
+    ref = _mcmc_calls(chain)
+    assert ref[0].shape == (32, 4, info["d"]) and ref[1].shape == (32, 6, info["d"])
+    for r in range(world):
+        out, wrote = got[r]
+        for a, b in zip(out, ref):
+            assert np.array_equal(a, b), r
+        assert wrote == (r == 0)
