@@ -232,7 +232,9 @@ int ensure_lookahead(gpb_ctx* ctx, size_t nev) {
 // k_syrk, no lookahead.  Measured (profiles/r04_fit_notes.txt): N = 2048 1303-1309 us against 1322-1340 for single steps (half the
 // trailing-matrix traffic buys 2-3 %: the update is bound by the latency of a tile in its slot, not by the HBM), N = 1024 +1 %
 // (the chain), N = 1536 754 against 735, N = 3072 3270 against 3300, N = 4096 6770-6940 us against 6150-6270 for panels of 256 with
-// k_syrk: used for 1536 < Np <= 3072 only.
+// k_syrk.  Round 5: with 63 GPs per launch (the batch train_emulators factors) N = 1024 is bound by the bulk, not the chain, and pairs
+// win 11-14 % (1129-1156 -> 966-1026 us; panels of 256 + k_syrk: 1050; profiles/r05_fit_notes.txt) — used for 1024 <= Np <= 3072,
+// whatever the number of GPs (10 GPs at N = 1024 / 1536 pay 1-3 % for it).
 static int launch_potrf_pairs(gpb_ctx* ctx) {
     const int64_t Np = ctx->Np, nb = Np / 64;
     const unsigned P = (unsigned)ctx->P;
@@ -256,7 +258,9 @@ static int launch_potrf_pairs(gpb_ctx* ctx) {
 }
 
 int launch_potrf_fused(gpb_ctx* ctx) {
-    if (ctx->chol_outer == 0 && (ctx->chol_pair == 2 || (ctx->chol_pair == 1 && ctx->Np > 1536 && ctx->Np <= 3072)))
+    // (the rule reads Np alone — never the number of GPs of the launch: a GP's bits must not depend on its neighbours, which is what
+    // keeps train_emulators' batched searches identical to the one-emulator ones)
+    if (ctx->chol_outer == 0 && (ctx->chol_pair == 2 || (ctx->chol_pair == 1 && ctx->Np >= 1024 && ctx->Np <= 3072)))
         return launch_potrf_pairs(ctx);
     const int64_t Np = ctx->Np, nb = Np / 64;
     // outer panel width (multiple of 64).  0 = by size (tools/gpu_fit_timing.py, 10 GPs): up to N = 2048 ONE panel — every

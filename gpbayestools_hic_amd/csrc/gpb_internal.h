@@ -166,7 +166,7 @@ struct gpb_ctx {
     unsigned* tile_counter = nullptr;   // 8 ticket queues (stride 16) + done counter [128]; re-armed by the kernel
     int64_t chol_outer = 0;        // outer panel width of the two-level blocked Cholesky (0 = chosen by size, gpb_chol.hip)
     int chol_pair = 1;             // option key 47: column pairs — every second trailing update by two columns at once (k_chol_update2):
-                                   // 1 = where measured faster (1536 < Np <= 3072), 2 = always, 0 = never
+                                   // 1 = where measured faster (1024 <= Np <= 3072), 2 = always, 0 = never
     int chol_lookahead = 1;        // far part of a panel's trailing update on a side stream, under the next panel's chain
     hipStream_t side_stream = nullptr;
     std::vector<hipEvent_t> chol_events;

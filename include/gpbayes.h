@@ -281,7 +281,7 @@ GPB_API int gpb_dist_finalize(gpb_ctx* ctx);
  *   43 route the block log-likelihood through the generic LDS / HBM Cholesky kernel (what M > 64 takes) whatever M;
  *   44 the number of 128x128 predict tiles per 256 CUs from which the rule takes them (0: default 960);
  *   47 Cholesky by column pairs (every second trailing update takes two block columns at once, K = 128): 1 where it is the faster
- *   schedule (default: 1536 < N <= 3072), 2 always, 0 never; results agree to rounding (another order of the same sums);
+ *   schedule (default: 1024 <= N <= 3072), 2 always, 0 never; results agree to rounding (another order of the same sums);
  *   49 the block log-likelihoods of a chain of emulators as one workgroup per (walker tile, emulator) and an ordered sum (1,
  *   default) or as one workgroup per walker tile that walks the emulators (0); same bits.
  *   Keys and values that select a measured-and-rejected kernel variant or a measurement hook (2, 21, 24, 26, 32, 37, 38, 39, 41, 48

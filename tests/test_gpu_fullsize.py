@@ -167,14 +167,14 @@ def test_cholesky_schedules_agree(N, library):
 @pytest.mark.parametrize("N", [1601, 1700, 3072, 129, 190])
 def test_cholesky_by_column_pairs_at_odd_and_even_block_counts(N):
     """the pair schedule (k_chol_update2: every second trailing update by two block columns at once) where the rule takes it
-    (1536 < Np <= 3072: 26, 27 and 48 block columns) and forced at three and three-with-a-ragged-end block columns: the factor
+    (1024 <= Np <= 3072: 26, 27 and 48 block columns) and forced at three and three-with-a-ragged-end block columns: the factor
     against LAPACK's, the inverse against it, LAPACK's info on an indefinite matrix"""
     from gpbayestools_hic_amd import GPEngine
     from oracle import gp_oracle as O
     from scipy.linalg import lapack
     P, d = 2, 6
     eng = GPEngine(0)
-    if N < 1536:
+    if N < 1024:
         eng.tune("chol_pair", 2)
     X, Z, th = _setup(eng, N, d, P, "Matern15", seed=N)
     L, Xi = eng.get("L"), eng.get("Linv")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Cholesky piece alone (product library), N = 1024 / 2048 / 4096, 10 GPs: microseconds per gpb_profile_fit_piece("potrf") with
-the K build's time taken off, and the triangular inverse.     python tools/gpu_chol_ab.py [N ...] [key=value ...]"""
+the K build's time taken off, and the triangular inverse.     python tools/gpu_chol_ab.py [N ...] [P=63] [key=value ...]"""
 import json
 import os
 import sys
@@ -30,6 +30,10 @@ def main():
     P = 10
     sizes = [int(a) for a in sys.argv[1:] if "=" not in a] or [1024, 2048, 4096]
     opts = [a.split("=") for a in sys.argv[1:] if "=" in a]
+    for k, v in opts:
+        if k == "P":                                   # number of GPs per launch (the batched regime of train_emulators: 63)
+            P = int(v)
+    opts = [kv for kv in opts if kv[0] != "P"]
     for N in sizes:
         d = 15 if N == 1024 else 20
         kernel = "Matern25" if N == 4096 else "RBF"
