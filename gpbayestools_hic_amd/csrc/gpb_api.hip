@@ -1093,6 +1093,7 @@ extern "C" int gpb_ctx_option(gpb_ctx* ctx, int key, int value) {
         case 47: if (value < 0 || value > 2) return GPB_E_ARG; ctx->chol_pair = value; break;
         case 48: if (value < 0 || value > 99) return GPB_E_ARG; ctx->kx_overlap = value; break;
         case 49: if (value < 0 || value > 1) return GPB_E_ARG; ctx->lr_split = value; break;
+        case 50: if (value != 0 && value != 64 && value != 128) return GPB_E_ARG; ctx->kinv_tile = value; break;
         case 44: if (value < 0) return GPB_E_ARG; ctx->tile_switch = value > 0 ? value : 960; break;
         case 33: if (value < 0) return GPB_E_ARG; ctx->tile_switch_c = value; break;
         case 34: if (value < 0) return GPB_E_ARG; ctx->mid_switch_c = value; break;

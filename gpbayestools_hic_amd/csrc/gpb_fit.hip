@@ -697,21 +697,25 @@ int launch_lml_value(gpb_ctx* ctx) {
 
 // ------------------------------------------------------------------ LML gradient
 // K^-1 = L^-T L^-1 on the lower 128x128 tiles (TN MFMA GEMM, k >= m_base), into T.
+// 1-D grid, GP fastest (round 5): tile t — the tiles are numbered longest K loop first — of ALL GPs is dispatched before tile t + 1
+// of any; with the GP as grid.y the last GP's heaviest tiles started when the chip was already draining (as in k_chol_update).
+// T_ = 128 or 64 (the tile; an element's sum runs over k in the same order either way: same bits).
+template <int T_>
 __global__ __launch_bounds__(256, 2) void k_kinv(const double* __restrict__ Linv, double* __restrict__ T,
-                                                 int64_t Np) {
-    __shared__ TileLds<128> lds;
-    const int p = blockIdx.y, t = blockIdx.x;
+                                                 int64_t Np, unsigned P) {
+    __shared__ TileLds<T_> lds;
+    const int p = (int)(blockIdx.x % P), t = (int)(blockIdx.x / P);
     int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     while (ti * (ti + 1) / 2 > t) --ti;
     const int tj = t - ti * (ti + 1) / 2;
-    const int64_t mb = (int64_t)ti * 128, nb = (int64_t)tj * 128;
-    const int m_ext = (int)imin64(128, Np - mb), n_ext = (int)imin64(128, Np - nb);
+    const int64_t mb = (int64_t)ti * T_, nb = (int64_t)tj * T_;
+    const int m_ext = (int)imin64(T_, Np - mb), n_ext = (int)imin64(T_, Np - nb);
     const double* Lp = Linv + (int64_t)p * Np * Np;
-    Acc<128> acc;
-    acc_zero<128>(acc);
-    gemm_tile_loop<128,true, false>(Lp, Np, Lp, Np, mb, nb, m_ext, n_ext, mb, Np, lds, acc);
-    tile_store<128>(T + (int64_t)p * Np * Np, Np, mb, nb, m_ext, n_ext, 1.0, false, acc);
+    Acc<T_> acc;
+    acc_zero<T_>(acc);
+    gemm_tile_loop<T_, true, false>(Lp, Np, Lp, Np, mb, nb, m_ext, n_ext, mb, Np, lds, acc);
+    tile_store<T_>(T + (int64_t)p * Np * Np, Np, mb, nb, m_ext, n_ext, 1.0, false, acc);
 }
 
 // grad_t = 1/2 sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta_t  (sk:_gpr.py:625-647), never
@@ -857,8 +861,16 @@ static int launch_grad_kind(gpb_ctx* ctx, int ntiles, double* gfinal) {
 
 int launch_lml_grad(gpb_ctx* ctx, double* grad_dev) {
     const int64_t nt128 = (ctx->Np + 127) / 128;
-    hipLaunchKernelGGL(k_kinv, dim3((unsigned)(nt128 * (nt128 + 1) / 2), (unsigned)ctx->P), dim3(256), 0,
-                       ctx->stream, ctx->Linv, ctx->T, ctx->Np);
+    // 64-wide tiles while 128-wide ones would leave the chip underfilled (the rule of launch_trtri; option key 50 forces one)
+    const bool small = ctx->kinv_tile == 64 || (ctx->kinv_tile == 0 && nt128 * (nt128 + 1) / 2 * ctx->P < 16 * (int64_t)ctx->num_cu);
+    if (small) {
+        const int64_t nt = ctx->Np / 64;
+        hipLaunchKernelGGL(k_kinv<64>, dim3((unsigned)(nt * (nt + 1) / 2 * ctx->P)), dim3(256), 0, ctx->stream, ctx->Linv, ctx->T,
+                           ctx->Np, (unsigned)ctx->P);
+    } else {
+        hipLaunchKernelGGL(k_kinv<128>, dim3((unsigned)(nt128 * (nt128 + 1) / 2 * ctx->P)), dim3(256), 0, ctx->stream, ctx->Linv,
+                           ctx->T, ctx->Np, (unsigned)ctx->P);
+    }
     const int64_t nt64 = ctx->Np / 64;
     const int ntiles = (int)(nt64 * (nt64 + 1) / 2);
     const int64_t need = (int64_t)ctx->P * ntiles * (ctx->d + 2);

@@ -178,6 +178,7 @@ struct gpb_ctx {
     int chol_algo = 1;             // 1 = two launches per step, next diagonal block fused into the update (gpb_chol.hip); 0 = round 1
     int syrk_tile = 0;              // tile of the end-of-panel trailing updates (0 = by fill, 64, 128)
     int trtri_tile = 0;            // tile of the triangular-inverse levels (0 = by fill, 64, 128)
+    int kinv_tile = 0;             // option key 50: tile of K^-1 = L^-T L^-1 (LML gradient; 0 = by fill, 64, 128)
     int chol_inner_tile = 64;      // tile of the K=64 trailing updates inside an outer panel (64 or 128)
     int resident_order = 2;         // k_predict with one workgroup per tile: 0 = ticket queues, 1-3 = static orders (2 = snake)
     unsigned* tile_trace = nullptr; // debug hook: [count, capacity, pad x6][capacity][8] records of k_predict tiles

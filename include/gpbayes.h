@@ -267,8 +267,8 @@ GPB_API int gpb_dist_finalize(gpb_ctx* ctx);
  *   1 / 3 / 6 / 16 persistent predict workgroups per CU (64x64 / 128x128 8-wave / 64x32 / 64x128 tiles); 4 outer panel width
  *   of the blocked Cholesky (0: by size); 5 tile order of a co-resident predict grid (1 sorted, 2 snake, 3 snake of pairs);
  *   7 / 22 switch points of the tile-shape rule (64x64 / 64x128 tiles per 256 CUs), 33 / 34 / 35 the same for compacted
- *   batches; 8 largest batch whose dense block log-likelihood runs one workgroup per walker; 9 / 12 / 14 tile (64, 128; 0 = by
- *   fill) of the in-panel Cholesky updates / the triangular-inverse levels / the end-of-panel updates; 10 wave priority of
+ *   batches; 8 largest batch whose dense block log-likelihood runs one workgroup per walker; 9 / 12 / 14 / 50 tile (64, 128; 0 = by
+ *   fill) of the in-panel Cholesky updates / the triangular-inverse levels / the end-of-panel updates / K^-1 of the LML gradient; 10 wave priority of
  *   predict tiles by K-loop length; 11 the block log-likelihood kernels sum the predict partials themselves; 13 co-resident
  *   workgroups per CU assumed by the static predict launch (0: table); 17 skip the all-zero m-tiles of the predict kernel's
  *   diagonal blocks; 18 distance form of the kernel matrices (1: per GP from theta, see GPB_GET_FORM; 0: difference form for
