@@ -579,6 +579,11 @@ def main():
     rank, world, local = init_from_env()
     assert world == args.gpus
     torch.cuda.set_device(local)
+    if (world > 1 and os.environ.get("GPB_BENCH_DEFAULT_STREAM") != "1") or os.environ.get("GPB_BENCH_OWN_STREAM") == "1":
+        # ranks of a sharded run work on a stream of their own (torch's streams are non-blocking ones): the kernels, the copies
+        # and the in-stream ncclAllGather of the C ABI all go where torch's current stream is, and nothing of the step loop
+        # inherits the legacy default stream's implicit synchronisation with other streams of the process (RCCL's own included)
+        torch.cuda.set_stream(torch.cuda.Stream(device=local))
     phase(0.5, "set-up (training, replication, self-checks)")
     chain, emu, info = build_chain(args.config, device=local)
     N, d, M, P = info["N"], info["d"], info["M"], info["P"]
@@ -741,6 +746,7 @@ def main():
                                       if degraded else ""), "walkers": nwalkers,
                        "parallelism": f"walker-shard x{world}" if world > 1 else "single GPU", "step_loop": loop,
                        "ranks": dist.get_world_size() if world > 1 else 1,
+                       "stream": "torch's default stream" if torch.cuda.current_stream().cuda_stream == 0 else "a non-blocking stream per rank",
                        "devices_used": devices_used,
                        "launched_by": "bench.py itself (bare --gpus N: child torch.distributed.run)"
                                       if os.environ.get("GPB_BENCH_SPAWNED") == "1" else
