@@ -457,3 +457,28 @@ def test_pool_trim_hands_cached_buffers_back_and_contexts_still_work():
     free_trimmed = torch.cuda.mem_get_info()[0]
     assert free_trimmed >= free_cached + 3 * 11 * (1 << 20)          # the three matrices went back to the driver
     assert np.array_equal(alpha(), a0) and np.array_equal(alpha(), a0)       # fresh allocation, then a cached one
+
+
+def test_lml_gradient_bits_do_not_depend_on_the_kinv_tile_or_the_gp_count():
+    """K^-1 = L^-T L^-1 of the LML gradient (k_kinv, sk:_gpr.py:627-629) on 64- or 128-wide tiles (option key 50; the rule picks by
+    fill): every element's sum runs over k in the same order, so value and gradient are the same bits — and a GP's numbers do not
+    depend on how many GPs share the launch (the 1-D grid deals tile t of all GPs before tile t + 1 of any)"""
+    from gpbayestools_hic_amd import GPEngine, synth
+    N, d, P = 300, 7, 5
+    X = synth.lhs(N, d, seed=2)
+    Z = np.random.default_rng(4).standard_normal((P, N))
+    th = synth.fixed_theta(d, P) + 0.1 * np.random.default_rng(5).standard_normal((P, d + 2))
+    outs = []
+    for tile in (0, 64, 128):
+        e = GPEngine(0)
+        e.set_data(X, Z, "Matern25", 0.1)
+        e.tune("kinv_tile", tile)
+        outs.append(e.lml(th))
+        e.close()
+    for v, g in outs[1:]:
+        assert np.array_equal(v, outs[0][0]) and np.array_equal(g, outs[0][1])
+    e = GPEngine(0)
+    e.set_data(X, Z[2:3], "Matern25", 0.1)                       # GP 2 alone
+    v1, g1 = e.lml(th[2:3])
+    e.close()
+    assert v1[0] == outs[0][0][2] and np.array_equal(g1[0], outs[0][1][2])
