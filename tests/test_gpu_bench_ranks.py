@@ -64,7 +64,9 @@ def test_bench_ranks_on_one_gpu_equal_the_single_gpu_run(R, bare):
         assert "outer launcher" in two["config"]["launched_by"]
     assert one["n_gpus"] == 1 and two["n_gpus"] == R
     assert one["config"]["ranks"] == 1 and two["config"]["ranks"] == R          # the world size the communicator reports
-    assert two["config"]["devices_used"] == [0] * R                             # (gloo rehearsal: the ranks share cuda:0)
+    import torch
+    ndev = torch.cuda.device_count()                                            # (gloo rehearsal: the ranks share the box's GPU(s))
+    assert two["config"]["devices_used"] == [r % ndev for r in range(R)]
     assert one["config"]["step_loop"] == "gpb_chain_emcee_run"
     assert two["config"]["step_loop"] == "host-driven"               # no in-stream RCCL collective under gloo
     assert two["config"]["parallelism"] == "walker-shard x%d" % R and "gloo" in two["config"]["allgather"]
