@@ -724,6 +724,19 @@ def main():
                "what": "the same step loop started from walkers uniform in the prior box (SURVEY 8d's walkers)"}
         del su
 
+    # the wire, measured: what ONE all-gather of a batch's shares costs on the kernels' stream (twice per step) — the number the
+    # expected 8-GPU rate hangs on; a failure here must not cost the line that was just timed
+    wire = None
+    if world > 1:
+        phase(0.25, "all-gather probe")
+        try:
+            us = sharding.time_allgather(max(nwalkers // 2 // world, 1))
+            wire = {"us_per_allgather": us, "doubles_per_rank": max(nwalkers // 2 // world, 1), "collectives_per_step": 2,
+                    "share_of_step": (2.0 * us * 1e-3 / (dt / args.steps * 1e3)) if us else None,
+                    "what": "200 back-to-back in-place all-gathers of a half-step's shares on the kernels' stream, HIP events, max over "
+                            "ranks (None under gloo: the rehearsal stages through the host)"}
+        except Exception as e:      # noqa: BLE001
+            wire = {"us_per_allgather": None, "error": "%s: %s" % (type(e).__name__, e)}
     if world == 1:
         dog.arm(0.0, "result line")                      # (extras and the CPU baseline: N = 1 only, minutes)
     else:
@@ -787,6 +800,8 @@ def main():
             out["extras"] = extras(chain, emu, info)
         if uni is not None:
             out.setdefault("extras", {})["uniform_start"] = uni
+        if wire is not None:
+            out.setdefault("extras", {})["allgather_probe"] = wire
         if world == 1 and not args.no_cpu_baseline:
             rows = min(args.cpu_rows or Xnext.shape[0], Xnext.shape[0])
             cb, lp_cpu = cpu_baseline(info, np.ascontiguousarray(Xnext[:rows]),

@@ -233,6 +233,37 @@ class WalkerSharding:
             return why or "direct all-gather failed its self-check on another rank"
         return None
 
+    def time_allgather(self, count, reps=200, warm=20):
+        """Microseconds per all-gather of `count` float64 per rank, back to back on the kernels' stream (HIP events; the MAX over
+        the ranks) — the wire latency the sharded step pays twice: in place, through the path a sharded batch takes (the C ABI's
+        in-stream ncclAllGather when `direct` is set, else torch.distributed's).  Collective.  None under gloo (no CUDA all-gather:
+        the rehearsal stages through the host and its time says nothing about a wire)."""
+        import torch
+        if self.backend() == "gloo":
+            return None
+        dev = torch.device("cuda", torch.cuda.current_device())
+        buf = torch.zeros(count * self.world, dtype=torch.float64, device=dev)
+        mine = buf[self.rank * count:(self.rank + 1) * count]
+
+        def one():
+            if self.direct is not None:
+                self.direct.dist_allgather(mine, buf)
+            else:
+                self.dist.all_gather_into_tensor(buf, mine, group=self.group)
+        for _ in range(warm):
+            one()
+        torch.cuda.synchronize()
+        self.dist.barrier(group=self.group)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            one()
+        e1.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) / reps * 1e3], dtype=torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
     def rows(self, W):
         """(r0, r1, chunk): this rank's row range of a W-row batch; chunk = ceil(W / world)."""
         chunk = -(-W // self.world)

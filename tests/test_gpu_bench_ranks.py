@@ -71,6 +71,8 @@ def test_bench_ranks_on_one_gpu_equal_the_single_gpu_run(R, bare):
     assert two["config"]["step_loop"] == "host-driven"               # no in-stream RCCL collective under gloo
     assert two["config"]["parallelism"] == "walker-shard x%d" % R and "gloo" in two["config"]["allgather"]
     assert two["ranks_hold_identical_ensemble"] is True and one["ranks_hold_identical_ensemble"] is None
+    assert two["extras"]["allgather_probe"]["us_per_allgather"] is None and "error" not in two["extras"]["allgather_probe"]   # gloo: no wire
+    assert "allgather_probe" not in one.get("extras", {})
     # replicated draws + gathered log-probabilities: the sharded ensemble IS the unsharded one
     assert two["ensemble_checksum"] == one["ensemble_checksum"]
     assert two["acceptance_fraction"] == one["acceptance_fraction"]

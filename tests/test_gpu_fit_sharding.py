@@ -185,8 +185,12 @@ def _direct_worker(port, q):
     fn = lambda Xr, o: chain.log_prob_device(Xr, out=o)
     fn(X, a); sh.logprob(fn, X, b)
     torch.cuda.synchronize()
+    us_direct = sh.time_allgather(256, reps=50, warm=5)             # bench.py's wire probe, on both exchange paths
+    keep, sh.direct = sh.direct, None
+    us_torch = sh.time_allgather(256, reps=50, warm=5)
+    sh.direct = keep
     q.put((why, sh.direct is not None, bool(torch.equal(plain.pos, sharded.pos)), bool(torch.equal(plain.lp, sharded.lp)),
-           bool(torch.equal(a, b))))
+           bool(torch.equal(a, b)), us_direct, us_torch))
     dist.destroy_process_group()
 
 
@@ -197,8 +201,9 @@ def test_sampler_over_the_direct_rccl_allgather_one_rank():
     q = ctx.Queue()
     p = ctx.Process(target=_direct_worker, args=(_free_port(), q))
     p.start()
-    why, direct_on, same_pos, same_lp, ragged_ok = q.get(timeout=600)
+    why, direct_on, same_pos, same_lp, ragged_ok, us_direct, us_torch = q.get(timeout=600)
     p.join(timeout=120)
     assert p.exitcode == 0
     assert why is None and direct_on
     assert same_pos and same_lp and ragged_ok
+    assert 0.0 < us_direct < 500.0 and 0.0 < us_torch < 500.0       # (one rank: launch and protocol cost without a wire)
