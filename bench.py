@@ -64,7 +64,7 @@ def cpu_baseline(info, Xw, what):
                       f"box; faithful W x W covariance per GP + per-row LAPACK MVN), {dt:.1f} s, numpy/scipy threaded BLAS"}, lp
 
 
-def extras(chain4, emu4, info4):
+def extras(chain4, emu4, info4, sustain_s=5.5, only_sustained=False):
     """The other two BASELINE metrics, measured on the same box (N=1 only): GP predict points/s on
     BASELINE config 2 (1024 design pts x 15 params, 10 GPs, 10 000 test points) and the fixed-theta fit
     (K build + Cholesky + L^-1 + alpha) at the design sizes of configs 2, 4 and 5, as Cholesky-equivalent GF/s
@@ -135,7 +135,7 @@ def extras(chain4, emu4, info4):
         t1 = time.perf_counter()
         n_l, ms_l, u_l = eng4.profile_read()
         blocks.append((t1 - t0, ms_l / max(n_l, 1), u_l / max(n_l, 1), n_l))
-        if t1 - t_start >= 5.5 or len(blocks) >= 400:
+        if t1 - t_start >= sustain_s or len(blocks) >= 40000:
             break
     t_all = time.perf_counter() - t_start
     eng4.profile(False)
@@ -155,10 +155,12 @@ def extras(chain4, emu4, info4):
                                     "by_block": [round(u, 1) for u in us[::max(len(us) // 24, 1)]]},
         "k_predict_frac_of_peak": {"first_block": fr(blocks[0]), "last_block": fr(blocks[-1]),
                                    "last_quarter": sum(fr(b) for b in tail) / len(tail)},
-        "what": "continuous stretch-move steps of the headline configuration through gpb_chain_emcee_run for >= 5.5 s, in blocks "
+        "what": "continuous stretch-move steps of the headline configuration through gpb_chain_emcee_run for >= %.1f s, in blocks " % sustain_s +
                 "of 40 steps from the same burnt-in ball (every proposal row inside the prior box and evaluated); whole-loop "
                 "rate = walkers x steps / wall time over all blocks incl. the two device copies that reset the ensemble; "
                 "k_predict: HIP-event time per launch, by block (algorithmic flops N^2 per (GP, row))"}
+    if only_sustained:
+        return out
 
     _, emu2, info2 = build_chain(2)
     eng2 = emu2._engine_ready()
@@ -539,6 +541,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-uniform", action="store_true", help="skip the second timed run from the uniform start")
     ap.add_argument("--cpu-rows", type=int, default=None)
+    ap.add_argument("--sustain", type=float, default=5.5, help="seconds of continuous steps behind extras.sustained_cfg4")
+    ap.add_argument("--only-sustained", action="store_true", help="of the extras, run the sustained-rate block alone")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -797,7 +801,7 @@ def main():
         except Exception:
             pass
         if world == 1 and not args.no_extras:
-            out["extras"] = extras(chain, emu, info)
+            out["extras"] = extras(chain, emu, info, args.sustain, args.only_sustained)
         if uni is not None:
             out.setdefault("extras", {})["uniform_start"] = uni
         if wire is not None:
