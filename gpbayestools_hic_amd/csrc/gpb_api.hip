@@ -136,8 +136,11 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     gpb_dist_finalize(ctx);
     free(ctx->h_theta);
     dev_free(&ctx->lr_R); dev_free(&ctx->lr_v0); dev_free(&ctx->lr_blocks);
-    dev_free(&ctx->xmean); dev_free(&ctx->muS); dev_free(&ctx->Xc); dev_free(&ctx->dnorm); dev_free(&ctx->gpform); dev_free(&ctx->kmtiles); dev_free(&ctx->gpN); dev_free(&ctx->gpmap);
-    dev_free(&ctx->X); dev_free(&ctx->Xsc); dev_free(&ctx->ls); dev_free(&ctx->amp); dev_free(&ctx->noise);
+    dev_free(&ctx->xmean); dev_free(&ctx->muS); dev_free(&ctx->Xc); dev_free(&ctx->dnorm); dev_free(&ctx->kmtiles); dev_free(&ctx->gpN);
+    dev_free(&ctx->X); dev_free(&ctx->Xsc); dev_free(&ctx->thblk);
+    ctx->ls = ctx->amp = ctx->noise = nullptr; ctx->gpform = ctx->gpmap = nullptr;         // (carved out of thblk)
+    if (ctx->h_thblk) (void)hipHostFree(ctx->h_thblk);
+    if (ctx->h_res) (void)hipHostFree(ctx->h_res);
     dev_free(&ctx->Z); dev_free(&ctx->K); dev_free(&ctx->Linv); dev_free(&ctx->LinvT); dev_free(&ctx->T); dev_free(&ctx->yv);
     dev_free(&ctx->alpha); dev_free(&ctx->apart); dev_free(&ctx->info); dev_free(&ctx->lmlbuf);
     dev_free(&ctx->gpart); dev_free(&ctx->Xs); dev_free(&ctx->estd); dev_free(&ctx->KsT); dev_free(&ctx->mpart);
@@ -211,13 +214,23 @@ static int gp_set_impl(gpb_ctx* ctx, int64_t P, int64_t d, const int64_t* N_p, c
     int rc;
     if ((rc = dev_alloc(ctx, &ctx->X, PX * Np * dpad))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->Xsc, P * Np * dpad))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->ls, P * dpad))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->xmean, PX * dpad))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->muS, P * dpad))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->Xc, P * Np * dpad))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->dnorm, P * Np))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->amp, P))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->noise, P))) return rc;
+    {   // one block: [ls P x dpad | amp P | noise P] doubles, then [gpform P | gpmap P] ints; its page-locked twin on the host
+        const size_t nd = (size_t)(P * dpad + 2 * P), bytes = sizeof(double) * nd + sizeof(int) * 2 * (size_t)P;
+        if ((rc = dev_alloc(ctx, &ctx->thblk, (int64_t)((bytes + 7) / 8)))) return rc;
+        ctx->ls = ctx->thblk; ctx->amp = ctx->ls + P * dpad; ctx->noise = ctx->amp + P;
+        ctx->gpform = reinterpret_cast<int*>(ctx->noise + P); ctx->gpmap = ctx->gpform + P;
+        if (ctx->h_thblk) { (void)hipHostFree(ctx->h_thblk); ctx->h_thblk = nullptr; }
+        if (ctx->h_res) { (void)hipHostFree(ctx->h_res); ctx->h_res = nullptr; }
+        GPB_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_thblk), bytes, hipHostMallocDefault));
+        GPB_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_res), sizeof(double) * (size_t)(P * 4 + P * (d + 2)) + sizeof(int) * (size_t)P,
+                              hipHostMallocDefault));
+        memset(ctx->h_thblk, 0, bytes);
+        ctx->thblk_bytes = bytes;
+    }
     if ((rc = dev_alloc(ctx, &ctx->Z, P * Np))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->K, P * Np * Np))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->Linv, P * Np * Np))) return rc;
@@ -232,8 +245,6 @@ static int gp_set_impl(gpb_ctx* ctx, int64_t P, int64_t d, const int64_t* N_p, c
     if ((rc = dev_alloc(ctx, &ctx->info, P))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->lmlbuf, P * 4 + P * (d + 2)))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->gpN, P))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->gpmap, P))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->gpform, P))) return rc;
     const int64_t nb64 = ctx->Np / 64;
     if ((rc = dev_alloc(ctx, &ctx->kmtiles, nb64 * (nb64 + 1)))) return rc;
     free(ctx->h_theta);
@@ -313,7 +324,7 @@ extern "C" int gpb_gp_set_multi(gpb_ctx* ctx, int64_t P, int64_t d, const int64_
 // kernels' slope |dk / d r^2| is at most 1/2 (RBF), 3/2 (Matern-3/2), 5/6 (Matern-5/2).  At S <= 1024 the Gram form keeps K and K*
 // within ~2e-13; at the reference's Matern lower bound (l = 1e-3 x extent: S = 1e6, src/emulator.py:292-297) it would lose
 // 3e-10 in K* and 2.5e-9 in the predictive variance, and those GPs take sklearn's own difference form.
-int gpb::choose_forms(gpb_ctx* ctx) {
+int gpb::choose_forms(gpb_ctx* ctx, bool upload) {
     const int64_t P = ctx->P, d = ctx->d;
     int ndiff = 0;
     for (int64_t p = 0; p < P; ++p) {
@@ -329,6 +340,7 @@ int gpb::choose_forms(gpb_ctx* ctx) {
         ndiff += f;
     }
     ctx->n_diff = ndiff;
+    if (!upload) return 0;                              // gpb_gp_set_theta sends the forms with the rest of its block
     GPB_HIP(hipMemcpyAsync(ctx->gpform, ctx->h_form.data(), sizeof(int) * P, hipMemcpyHostToDevice, ctx->stream));
     GPB_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -342,27 +354,36 @@ extern "C" int gpb_gp_set_theta(gpb_ctx* ctx, const double* theta_host) {
     for (int64_t i = 0; i < P * (d + 2); ++i)
         if (!isfinite(theta_host[i])) GPB_FAIL(GPB_E_ARG, "gpb_gp_set_theta: non-finite theta");
     memcpy(ctx->h_theta, theta_host, sizeof(double) * P * (d + 2));
-    std::vector<double> ls((size_t)(P * dpad), 1.0), amp((size_t)P), noise((size_t)P);
+    GPB_HIP(hipSetDevice(ctx->device));
+    GPB_HIP(hipStreamSynchronize(ctx->stream));     // the previous block's copy out of the page-locked twin is done
+    int rc = choose_forms(ctx, false);
+    if (rc) return rc;
+    // length scales, amplitudes, noise levels, distance forms and (a subset evaluation) the slot -> GP map: ONE asynchronous copy
+    // from page-locked memory, ordered in front of the kernels that read them (it was three blocking copies of pageable vectors
+    // plus one for the forms and one for the map, each a blit kernel and a wait)
+    const int64_t Ps = ctx->Pstore;                  // the block's layout is the stored GP count's
+    double* hl = ctx->h_thblk;
+    double* ha = hl + Ps * dpad;
+    double* hn = ha + Ps;
+    int* hf = reinterpret_cast<int*>(hn + Ps);
+    int* hm = hf + Ps;
     for (int64_t p = 0; p < P; ++p) {
         const double* th = theta_host + p * (d + 2);
-        amp[p] = exp(th[0]);
-        for (int64_t k = 0; k < d; ++k) ls[p * dpad + k] = exp(th[1 + k]);
-        noise[p] = exp(th[d + 1]);
+        ha[p] = exp(th[0]);
+        for (int64_t k = 0; k < dpad; ++k) hl[p * dpad + k] = k < d ? exp(th[1 + k]) : 1.0;
+        hn[p] = exp(th[d + 1]);
+        hf[p] = ctx->h_form[(size_t)p];
+        if (ctx->subset) hm[p] = ctx->h_map[(size_t)p];
     }
-    GPB_HIP(hipSetDevice(ctx->device));
-    GPB_HIP(hipStreamSynchronize(ctx->stream));     // host vectors are about to go out of scope
-    GPB_HIP(hipMemcpy(ctx->ls, ls.data(), sizeof(double) * ls.size(), hipMemcpyHostToDevice));
-    GPB_HIP(hipMemcpy(ctx->amp, amp.data(), sizeof(double) * P, hipMemcpyHostToDevice));
-    GPB_HIP(hipMemcpy(ctx->noise, noise.data(), sizeof(double) * P, hipMemcpyHostToDevice));
-    int rc = choose_forms(ctx);
-    if (rc) return rc;
+    GPB_HIP(hipMemcpyAsync(ctx->thblk, ctx->h_thblk, ctx->thblk_bytes, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = launch_scale_design(ctx))) return rc;
     ctx->have_theta = true;
     ctx->factored = false;
     return 0;
 }
 
-static int factor_impl(gpb_ctx* ctx, int* info_host, bool need_inverse) {
+// K build, blocked Cholesky, [triangular inverse, alpha]: enqueued, nothing read back
+static int factor_enqueue(gpb_ctx* ctx, bool need_inverse) {
     if (!ctx->have_theta) GPB_FAIL(GPB_E_STATE, "gpb_gp_factor before gpb_gp_set_theta");
     GPB_HIP(hipSetDevice(ctx->device));
     int rc;
@@ -372,6 +393,12 @@ static int factor_impl(gpb_ctx* ctx, int* info_host, bool need_inverse) {
         if ((rc = launch_trtri(ctx))) return rc;
         if ((rc = launch_alpha(ctx))) return rc;
     }
+    return 0;
+}
+
+static int factor_impl(gpb_ctx* ctx, int* info_host, bool need_inverse) {
+    int rc = factor_enqueue(ctx, need_inverse);
+    if (rc) return rc;
     std::vector<int> info((size_t)ctx->P, 0);
     GPB_HIP(hipMemcpyAsync(info.data(), ctx->info, sizeof(int) * ctx->P, hipMemcpyDeviceToHost, ctx->stream));
     GPB_HIP(hipStreamSynchronize(ctx->stream));
@@ -434,20 +461,25 @@ extern "C" int gpb_gp_get(gpb_ctx* ctx, int what, double* out_host) {
     return 0;
 }
 
+// One evaluation = ONE upload (gpb_gp_set_theta's block), the whole kernel sequence enqueued back to back — factorisation, value,
+// gradient: a failed factorisation leaves NaNs that the read-back replaces, sk:_gpr.py:588-589 — and ONE read-back into
+// page-locked memory with one synchronisation (round 4: five synchronisations, the one behind the factorisation leaving the
+// chip idle while the host launched the rest).
 static int lml_impl(gpb_ctx* ctx, const double* theta_host, double* lml_host, double* grad_host, int* info_host) {
     int rc = gpb_gp_set_theta(ctx, theta_host);
     if (rc) return rc;
-    std::vector<int> info((size_t)ctx->P, 0);
-    rc = factor_impl(ctx, info.data(), true);
-    if (rc < 0) return rc;
+    if ((rc = factor_enqueue(ctx, true))) return rc;
     const int64_t P = ctx->P, d = ctx->d;
     if ((rc = launch_lml_value(ctx))) return rc;
     double* gdev = ctx->lmlbuf + P * 4;
     if (grad_host) {
         if ((rc = launch_lml_grad(ctx, gdev))) return rc;
     }
-    std::vector<double> buf((size_t)(P * 4 + P * (d + 2)));
-    GPB_HIP(hipMemcpyAsync(buf.data(), ctx->lmlbuf, sizeof(double) * buf.size(), hipMemcpyDeviceToHost, ctx->stream));
+    const size_t nbuf = (size_t)(P * 4 + P * (d + 2));
+    double* buf = ctx->h_res;
+    int* info = reinterpret_cast<int*>(ctx->h_res + (size_t)(ctx->Pstore * 4 + ctx->Pstore * (d + 2)));
+    GPB_HIP(hipMemcpyAsync(buf, ctx->lmlbuf, sizeof(double) * nbuf, hipMemcpyDeviceToHost, ctx->stream));
+    GPB_HIP(hipMemcpyAsync(info, ctx->info, sizeof(int) * P, hipMemcpyDeviceToHost, ctx->stream));
     GPB_HIP(hipStreamSynchronize(ctx->stream));
     for (int64_t p = 0; p < P; ++p) {
         const bool bad = info[p] != 0;
@@ -481,9 +513,7 @@ extern "C" int gpb_gp_lml_subset(gpb_ctx* ctx, int64_t n, const int32_t* gp_inde
         ctx->h_map[(size_t)a] = gp_index[a];
     }
     GPB_HIP(hipSetDevice(ctx->device));
-    GPB_HIP(hipStreamSynchronize(ctx->stream));
-    GPB_HIP(hipMemcpy(ctx->gpmap, ctx->h_map.data(), sizeof(int) * n, hipMemcpyHostToDevice));
-    ctx->P = n;
+    ctx->P = n;                                        // (the slot -> GP map goes up with theta: gpb_gp_set_theta's block)
     ctx->subset = true;
     const int rc = lml_impl(ctx, theta_host, lml_host, grad_host, info_host);
     ctx->P = ctx->Pstore;

@@ -168,6 +168,12 @@ struct gpb_ctx {
     int chol_pair = 1;             // option key 47: column pairs — every second trailing update by two columns at once (k_chol_update2):
                                    // 1 = where measured faster (1024 <= Np <= 3072), 2 = always, 0 = never
     int chol_lookahead = 1;        // far part of a panel's trailing update on a side stream, under the next panel's chain
+    // ls / amp / noise / gpform / gpmap are carved out of ONE device block (thblk) so that a new theta goes up in ONE asynchronous
+    // copy from its page-locked twin (h_thblk) — round 5: an LML evaluation made 6 blocking copies and 5 synchronisations
+    double* thblk = nullptr;
+    double* h_thblk = nullptr;
+    size_t thblk_bytes = 0;
+    double* h_res = nullptr;       // page-locked: [lmlbuf doubles | info ints] of an LML evaluation's read-back
     hipStream_t side_stream = nullptr;
     std::vector<hipEvent_t> chol_events;
     int kx_overlap = 0;            // option key 48: per cent of a batch's GPs in the FIRST of two groups; the second group's K*^T runs on
@@ -240,7 +246,7 @@ template <typename T>
 inline hipError_t pool_malloc_t(T** p, size_t bytes) { return pool_malloc(reinterpret_cast<void**>(p), bytes); }
 // fit side (gpb_fit.hip)
 int launch_scale_design(gpb_ctx* ctx);
-int choose_forms(gpb_ctx* ctx);                        // gpb_api.hip: per-GP distance form from h_theta and the design's extents
+int choose_forms(gpb_ctx* ctx, bool upload = true);    // gpb_api.hip: per-GP distance form from h_theta and the design's extents
 int launch_kmat(gpb_ctx* ctx);
 int launch_potrf(gpb_ctx* ctx);
 int launch_trtri(gpb_ctx* ctx);
