@@ -1,0 +1,49 @@
+"""CPU tier: the host side in front of the GPs against the reference itself (golden G9, tools/make_goldens.py::g9_loading):
+`Emulator._load_training_data_pickle` (src/emulator.py:378-415) on a data set with string keys in shuffled order, events over the
+relative-error threshold, a NaN error and a negative value — with and without the log transform and with a custom threshold —
+and the two host helpers `getAvgTrainingDataRelError` (:418-421) and `outputPCAvsParam` (:244-249).
+(The reference's `outputPCAvsParam` also standardises `model_data` in place — `StandardScaler(copy=False)`, :76 — which nothing
+relies on; the drop-in returns the same numbers and leaves `model_data` alone.)"""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    from gpbayestools_hic_amd import synth
+    g = golden("g9_loading.npz")
+    d = tmp_path_factory.mktemp("g9")
+    data = {}
+    for i in g["order"]:                       # the reference's file: string keys, insertion order shuffled
+        data[str(int(i))] = {"parameter": g["X"][i], "obs": np.array([g["Y"][i], g["Yerr"][i]])}
+    tp, pf = os.path.join(d, "train.pkl"), os.path.join(d, "par.txt")
+    with open(tp, "wb") as f:
+        pickle.dump(data, f)
+    synth.write_parameter_file(pf, np.zeros(3), np.ones(3))
+    return g, tp, pf
+
+
+@pytest.mark.parametrize("tag,kw,nev", [("plain", {}, 38), ("thr02", dict(max_rel_uncertainty_data=0.2), 39),
+                                        ("log", dict(logTrafo=True), 38), ("logthr", dict(logTrafo=True, max_rel_uncertainty_data=0.2), 39)])
+def test_loader_and_host_helpers_against_the_reference(files, tag, kw, nev):
+    from gpbayestools_hic_amd import Emulator
+    g, tp, pf = files
+    with np.errstate(all="ignore"):
+        emu = Emulator(training_set_path=tp, parameter_file=pf, npc=3, **kw)
+        rel = emu.getAvgTrainingDataRelError()
+        dp, Zt = emu.outputPCAvsParam()
+    assert emu.nev == int(g[f"{tag}_nev"]) == nev          # 40 events: one (two at the default threshold) discarded
+    assert np.array_equal(emu.design_points, g[f"{tag}_design_points"])            # sorted by int(key), bit for bit
+    assert np.array_equal(emu.design_points_org_, g[f"{tag}_design_points"])
+    assert np.array_equal(emu.model_data, g[f"{tag}_model_data"])
+    assert np.array_equal(emu.model_data_err, g[f"{tag}_model_data_err"])          # |.|, NaN -> 0
+    assert np.array_equal(rel, g[f"{tag}_avg_rel_err"])
+    assert np.array_equal(dp, g[f"{tag}_pca_design"]) and Zt.shape == g[f"{tag}_pca_Zt"].shape == (3, nev)
+    assert np.max(np.abs(Zt - g[f"{tag}_pca_Zt"])) < 1e-11 * np.max(np.abs(g[f"{tag}_pca_Zt"]))
+    assert np.all(np.isfinite(emu.model_data_err)) and emu.model_data_err.min() == 0.0      # the NaN error of event 30
+    assert np.array_equal(emu.model_data, g[f"{tag}_model_data"])                  # ... and the helper left the data alone

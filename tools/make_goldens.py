@@ -323,6 +323,49 @@ def g8_holdout(Emulator):
         np.savez_compressed(os.path.join(OUT, f"g8_holdout_{name}.npz"), **out)
 
 
+def g9_loading(Emulator):
+    """a1 and the two host helpers: `_load_training_data_pickle` on a data set whose keys are STRINGS in shuffled order, with
+    events over the relative-error threshold (discarded), a NaN error and a negative value; with and without the log transform
+    and with a custom threshold (src/emulator.py:378-415); `getAvgTrainingDataRelError` (:418-421) and `outputPCAvsParam`
+    (:244-249) on the loaded data."""
+    import pickle
+    rng = np.random.default_rng(77)
+    N, d, M = 40, 3, 5
+    lo, hi = np.zeros(d), np.ones(d)
+    X = synth.lhs(N, d, seed=78)
+    Y = 2.0 + synth.observables(X, M, seed=79)
+    Yerr = 0.02 * np.abs(Y) * rng.uniform(0.2, 1.0, Y.shape)
+    Yerr[3, 1] = 0.5 * abs(Y[3, 1])            # 50 % error: discarded at every threshold used here
+    Yerr[11, 4] = 0.12 * abs(Y[11, 4])         # discarded at 0.1, kept at 0.2
+    Yerr[17, 0] = 0.099 * abs(Y[17, 0])        # just under 0.1
+    Y[22, 2] = -Y[22, 2]                       # a negative value: |err / val| and log(|val|)
+    Yerr[30, 3] = np.nan                       # NaN error: the comparison is False (kept), nan_to_num -> 0
+    data = {}
+    for i in rng.permutation(N):               # insertion order shuffled; the loader sorts by int(key)
+        data[str(int(i))] = {"parameter": X[i], "obs": np.array([Y[i], Yerr[i]])}
+    tp = os.path.join(_work, "g9_train.pkl")
+    pf = os.path.join(_work, "g9_par.txt")
+    with open(tp, "wb") as f:
+        pickle.dump(data, f)
+    synth.write_parameter_file(pf, lo, hi)
+    out = dict(X=X, Y=Y, Yerr=Yerr, order=np.array([int(k) for k in data.keys()]))
+    for tag, kw in (("plain", {}), ("thr02", dict(max_rel_uncertainty_data=0.2)),
+                    ("log", dict(logTrafo=True)), ("logthr", dict(logTrafo=True, max_rel_uncertainty_data=0.2))):
+        with np.errstate(all="ignore"):
+            emu = Emulator(training_set_path=tp, parameter_file=pf, npc=3, **kw)
+            # (copies: the reference's StandardScaler(copy=False) makes outputPCAvsParam standardise model_data IN PLACE,
+            # src/emulator.py:76,244-249 — a side effect nothing in the reference relies on and the drop-in does not copy)
+            out[f"{tag}_design_points"] = emu.design_points.copy()
+            out[f"{tag}_model_data"] = emu.model_data.copy()
+            out[f"{tag}_model_data_err"] = emu.model_data_err.copy()
+            out[f"{tag}_nev"] = emu.nev
+            out[f"{tag}_avg_rel_err"] = emu.getAvgTrainingDataRelError()
+            dp, Zt = emu.outputPCAvsParam()
+            out[f"{tag}_pca_design"] = dp
+            out[f"{tag}_pca_Zt"] = Zt
+    np.savez_compressed(os.path.join(OUT, "g9_loading.npz"), **out)
+
+
 def g6_mvn(mcmc):
     rng = np.random.default_rng(600)
     out = {}
@@ -348,6 +391,7 @@ def main():
     g6_mvn(mcmc)
     g7_param_pca(Emulator)
     g8_holdout(Emulator)
+    g9_loading(Emulator)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
