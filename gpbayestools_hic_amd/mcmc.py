@@ -103,7 +103,8 @@ class Chain:
             data = pickle.load(fp)
         vals = np.array([data[k]["obs"][0] for k in data.keys()])
         errs = np.nan_to_num(np.abs(np.array([data[k]["obs"][1] for k in data.keys()])))
-        cov = np.diag(errs.flatten() ** 2)
+        cov = np.zeros((vals.shape[1], vals.shape[1]))
+        np.fill_diagonal(cov, errs.flatten() ** 2)       # (nobs x nobs whatever the number of events, as the reference fills it)
         return vals, cov
 
     def state_digest_cached(self):

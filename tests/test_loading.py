@@ -47,3 +47,23 @@ def test_loader_and_host_helpers_against_the_reference(files, tag, kw, nev):
     assert np.max(np.abs(Zt - g[f"{tag}_pca_Zt"])) < 1e-11 * np.max(np.abs(g[f"{tag}_pca_Zt"]))
     assert np.all(np.isfinite(emu.model_data_err)) and emu.model_data_err.min() == 0.0      # the NaN error of event 30
     assert np.array_equal(emu.model_data, g[f"{tag}_model_data"])                  # ... and the helper left the data alone
+
+
+def test_experiment_file_reader_as_the_reference_fills_it(tmp_path):
+    """Chain._read_in_exp_data_pickle (src/mcmc.py:302-324): values per event, |errors| with NaN -> 0, and an nobs x nobs covariance
+    whose diagonal is filled from the flattened errors (with more than one event the reference's np.fill_diagonal takes the first
+    nobs of them).  Expected arrays: the reference's own output on these two files (checked in the build container)."""
+    from gpbayestools_hic_amd import synth
+    from gpbayestools_hic_amd.mcmc import Chain
+    pf = str(tmp_path / "par.txt")
+    synth.write_parameter_file(pf, np.zeros(3), np.ones(3))
+    cases = (({"0": {"obs": np.array([[1.0, -2.0, 3.0], [0.1, np.nan, -0.3]])}},
+              np.array([[1.0, -2.0, 3.0]]), np.diag([0.1 ** 2, 0.0, 0.3 ** 2])),
+             ({"0": {"obs": np.array([[1.0, 2.0], [0.1, 0.2]])}, "1": {"obs": np.array([[3.0, 4.0], [0.3, 0.4]])}},
+              np.array([[1.0, 2.0], [3.0, 4.0]]), np.diag([0.1 ** 2, 0.2 ** 2])))
+    for i, (data, vals, cov) in enumerate(cases):
+        ep = str(tmp_path / ("exp%d.pkl" % i))
+        with open(ep, "wb") as f:
+            pickle.dump(data, f)
+        ch = Chain(mcmc_path=str(tmp_path / "mcmc" / "c.pkl"), expdata_path=ep, model_parafile=pf)
+        assert np.array_equal(ch.expdata, vals) and np.array_equal(ch.expdata_cov, cov) and ch.nobs == vals.shape[1]
