@@ -252,15 +252,21 @@ static int gp_set_impl(gpb_ctx* ctx, int64_t P, int64_t d, const int64_t* N_p, c
     std::vector<double> xp((size_t)(PX * Np * dpad), 0.0), zp((size_t)(P * Np), 0.0), xm((size_t)(PX * dpad), 0.0);
     ctx->h_ext.assign((size_t)(PX * d), 0.0);
     ctx->h_N.assign((size_t)P, 0);
+    // The padding of a design to Np = a multiple of 64 points sits IN FRONT of it (round 5): stored row pad + i holds design point i,
+    // pad = Np - N; rows [0, pad) are the identity block of K and L, zero rows of K*^T, zero targets.  In front, not behind: the
+    // predict kernel's work per row block grows with its index (triangular K loops), so padding costs its rows' share of the
+    // LIGHTEST row block instead of the heaviest, and the leading all-zero K-steps are skipped (launch_vsq) — N = 1000 wasted 4.7 %
+    // of the launch behind, 0.8 % in front.  Designs of a multiple of 64 points (every BASELINE configuration) are unaffected.
     for (int64_t p = 0; p < P; ++p) {
         ctx->h_N[(size_t)p] = (int)N_p[p];
-        for (int64_t i = 0; i < N_p[p]; ++i) zp[p * Np + i] = Z_p[p][i];
+        const int64_t pad = Np - N_p[p];
+        for (int64_t i = 0; i < N_p[p]; ++i) zp[p * Np + pad + i] = Z_p[p][i];
     }
     for (int64_t q = 0; q < PX; ++q) {
         const double* Xq = X_p[q];
-        const int64_t Nq = N_p[q];
+        const int64_t Nq = N_p[q], pad = Np - Nq;
         for (int64_t i = 0; i < Nq; ++i)
-            for (int64_t k = 0; k < d; ++k) xp[(q * Np + i) * dpad + k] = Xq[i * d + k];
+            for (int64_t k = 0; k < d; ++k) xp[(q * Np + pad + i) * dpad + k] = Xq[i * d + k];
         for (int64_t k = 0; k < d; ++k) {
             // column means: the centre of the Gram form (k_kcross, k_kmat_mfma); column extents: what a length scale is
             // compared with when the distance form is chosen (choose_forms)
@@ -382,6 +388,15 @@ extern "C" int gpb_gp_set_theta(gpb_ctx* ctx, const double* theta_host) {
     return 0;
 }
 
+// LAPACK's info of slot p in the design's own numbering: the factorisation reports the first non-positive pivot's 1-based index in
+// the PADDED matrix, whose padding sits in front (gp_set_impl)
+static int info_unpadded(const gpb_ctx* ctx, int64_t p, int info) {
+    if (info <= 0) return info;
+    const int64_t q = ctx->multi ? (ctx->subset ? ctx->h_map[(size_t)p] : p) : 0;
+    const int64_t Nq = ctx->multi ? ctx->h_N[(size_t)q] : ctx->N;
+    return info - (int)(ctx->Np - Nq);
+}
+
 // K build, blocked Cholesky, [triangular inverse, alpha]: enqueued, nothing read back
 static int factor_enqueue(gpb_ctx* ctx, bool need_inverse) {
     if (!ctx->have_theta) GPB_FAIL(GPB_E_STATE, "gpb_gp_factor before gpb_gp_set_theta");
@@ -404,6 +419,7 @@ static int factor_impl(gpb_ctx* ctx, int* info_host, bool need_inverse) {
     GPB_HIP(hipStreamSynchronize(ctx->stream));
     int first = 0;
     for (int64_t p = 0; p < ctx->P; ++p) {
+        info[p] = info_unpadded(ctx, p, info[p]);
         if (info_host) info_host[p] = info[p];
         if (info[p] != 0 && first == 0) first = info[p];
     }
@@ -426,9 +442,16 @@ extern "C" int gpb_gp_get(gpb_ctx* ctx, int what, double* out_host) {
     const int64_t N = ctx->N, Np = ctx->Np, P = ctx->P;
     GPB_HIP(hipSetDevice(ctx->device));
     GPB_HIP(hipStreamSynchronize(ctx->stream));
+    // the design's padding sits in front (gp_set_impl): GP p's own block starts at row / column Np - N_p.  A gpb_gp_set_multi
+    // context's GPs may differ in size: each lands in the top-left corner of its N x N output block (N = the largest design),
+    // the rest of the block being the identity (zero for alpha), as the padded device matrices read
+    auto Nof = [&](int64_t p) { return ctx->multi ? (int64_t)ctx->h_N[(size_t)p] : N; };
     if (what == GPB_GET_ALPHA) {
-        for (int64_t p = 0; p < P; ++p)
-            GPB_HIP(hipMemcpy(out_host + p * N, ctx->alpha + p * Np, sizeof(double) * N, hipMemcpyDeviceToHost));
+        for (int64_t p = 0; p < P; ++p) {
+            const int64_t Nq = Nof(p);
+            for (int64_t i = Nq; i < N; ++i) out_host[p * N + i] = 0.0;
+            GPB_HIP(hipMemcpy(out_host + p * N, ctx->alpha + p * Np + (Np - Nq), sizeof(double) * Nq, hipMemcpyDeviceToHost));
+        }
         return 0;
     }
     if (what == GPB_GET_FORM) {
@@ -436,11 +459,11 @@ extern "C" int gpb_gp_get(gpb_ctx* ctx, int what, double* out_host) {
         return 0;
     }
     if (what == GPB_GET_KSTAR) {                       // KsT is [P][Np][Wld], walker fastest: transposed on the host
-        const int64_t W = ctx->last_W, Wld = ctx->Wld;
+        const int64_t W = ctx->last_W, Wld = ctx->Wld, pad = Np - N;
         if (W <= 0 || !ctx->KsT) GPB_FAIL(GPB_E_STATE, "gpb_gp_get(GPB_GET_KSTAR): no batch has been evaluated");
         std::vector<double> tmp((size_t)(N * W));
         for (int64_t p = 0; p < P; ++p) {
-            GPB_HIP(hipMemcpy2D(tmp.data(), sizeof(double) * W, ctx->KsT + p * Np * Wld, sizeof(double) * Wld,
+            GPB_HIP(hipMemcpy2D(tmp.data(), sizeof(double) * W, ctx->KsT + (p * Np + pad) * Wld, sizeof(double) * Wld,
                                 sizeof(double) * W, (size_t)N, hipMemcpyDeviceToHost));
             for (int64_t w = 0; w < W; ++w)
                 for (int64_t n = 0; n < N; ++n) out_host[(p * W + w) * N + n] = tmp[(size_t)(n * W + w)];
@@ -450,8 +473,14 @@ extern "C" int gpb_gp_get(gpb_ctx* ctx, int what, double* out_host) {
     const double* src = (what == GPB_GET_K || what == GPB_GET_L) ? ctx->K : (what == GPB_GET_LINV ? ctx->Linv : nullptr);
     if (!src) GPB_FAIL(GPB_E_ARG, "gpb_gp_get: unknown selector");
     for (int64_t p = 0; p < P; ++p) {
-        GPB_HIP(hipMemcpy2D(out_host + p * N * N, sizeof(double) * N, src + p * Np * Np, sizeof(double) * Np,
-                            sizeof(double) * N, (size_t)N, hipMemcpyDeviceToHost));
+        const int64_t Nq = Nof(p), pad = Np - Nq;
+        double* o = out_host + p * N * N;
+        if (Nq < N) {
+            for (int64_t i = 0; i < N * N; ++i) o[i] = 0.0;
+            for (int64_t i = Nq; i < N; ++i) o[i * N + i] = 1.0;
+        }
+        GPB_HIP(hipMemcpy2D(o, sizeof(double) * N, src + p * Np * Np + pad * Np + pad, sizeof(double) * Np,
+                            sizeof(double) * Nq, (size_t)Nq, hipMemcpyDeviceToHost));
     }
     if (what == GPB_GET_L) {        // upper blocks hold scratch from the trailing updates: zero them
         for (int64_t p = 0; p < P; ++p)
@@ -461,10 +490,6 @@ extern "C" int gpb_gp_get(gpb_ctx* ctx, int what, double* out_host) {
     return 0;
 }
 
-// One evaluation = ONE upload (gpb_gp_set_theta's block), the whole kernel sequence enqueued back to back — factorisation, value,
-// gradient: a failed factorisation leaves NaNs that the read-back replaces, sk:_gpr.py:588-589 — and ONE read-back into
-// page-locked memory with one synchronisation (round 4: five synchronisations, the one behind the factorisation leaving the
-// chip idle while the host launched the rest).
 static int lml_impl(gpb_ctx* ctx, const double* theta_host, double* lml_host, double* grad_host, int* info_host) {
     int rc = gpb_gp_set_theta(ctx, theta_host);
     if (rc) return rc;
@@ -486,7 +511,7 @@ static int lml_impl(gpb_ctx* ctx, const double* theta_host, double* lml_host, do
         lml_host[p] = bad ? -INFINITY : buf[p * 4];                  // sk:_gpr.py:588-589
         if (grad_host)
             for (int64_t k = 0; k < d + 2; ++k) grad_host[p * (d + 2) + k] = bad ? 0.0 : buf[P * 4 + p * (d + 2) + k];
-        if (info_host) info_host[p] = info[p];
+        if (info_host) info_host[p] = info_unpadded(ctx, p, info[p]);
     }
     ctx->factored = true;
     for (int64_t p = 0; p < P; ++p) if (info[p] != 0) ctx->factored = false;     // see gpb_gp_factor

@@ -168,7 +168,7 @@ __device__ __forceinline__ void kcross_body(KxLds<DPAD, WPL>& L, const double* _
             double kv[WPL];
 #pragma unroll
             for (int u = 0; u < WPL; ++u) kv[u] = 0.0;
-            if (n < N) {
+            if (n >= Np - N) {                          // (rows [0, Np - N) are the padding: zero rows of K*^T)
                 const double* xr = sxr + pt * DPAD;
                 double r2[WPL];
 #pragma unroll
@@ -302,9 +302,14 @@ __device__ __forceinline__ void predict_tile(TileLds<T, TN, KB>& lds, int p, int
     // L^-1 is lower triangular: the 128x128 kernel skips the all-zero 16-row m-tiles of the diagonal block
     // (gemm_tile_loop TRI: the wave rows own the m-tiles alternately, acc.v[i] = m-tile 2i + wave row).
     constexpr bool TRI = (NW == 4);      // (K-steps of 16 or 32)
+    // tri_skip carries two things: bit 0 = skip the diagonal block's zero m-tiles; bits 8.. = the number of LEADING columns of
+    // K*^T that are all zero — the design's padding sits in front (gp_set_impl) — rounded down to whole K-steps by the launcher:
+    // a row block that starts at or behind them begins its K loop there (the products it leaves out are exact zeros: same bits)
+    const int64_t kskip = ((tri_skip >> 8) / KB) * KB;
+    const int64_t k_begin = kskip <= mb ? kskip : 0;
     gemm_tile_loop<T, false, false, NW, TN, KB, T == 64, TRI, PIPE>(Linv + (int64_t)p * Np * Np, Np,
-                                                              KsT + (int64_t)p * Np * Wld, Wld, mb, nb, m_ext, TN, 0,
-                                                              k_end, lds, acc, tri_skip ? mb : k_end);
+                                                              KsT + (int64_t)p * Np * Wld, Wld, mb, nb, m_ext, TN, k_begin,
+                                                              k_end, lds, acc, (tri_skip & 1) ? mb : k_end);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     double* red = &lds.Bs[0][0];                // [2 x 64-row blocks or wave rows][TN columns]
@@ -1244,6 +1249,11 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, con
         Gsum += p0s ? p1s[e] - p0s[e] : ctxs[e]->P;
     }
     const bool multi = E > 1 || p0s != nullptr;        // a GP range of one context: the table form of the same tiles
+    // leading all-zero rows of K*^T (the designs' padding, in front: gp_set_impl) common to every context of the launch, in whole
+    // 16-deep K-steps: the tiles start their K loops behind them
+    int64_t kskip = ctx->Np;
+    for (int e = 0; e < E; ++e) kskip = imin64(kskip, ((ctxs[e]->Np - ctxs[e]->N) / 16) * 16);
+    const int tri_arg = (ctx->tri_skip ? 1 : 0) | ((int)kskip << 8);
     if (multi && Gsum > MAX_MULTI_GP) GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_vsq: too many GPs for one table");
     const int64_t GP = Gsum;                           // GPs of the launch: what the tile counts are made of
     const int nI64 = (int)(ctx->Np / 64);
@@ -1346,19 +1356,19 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, con
             if (T == 128)
                 hipLaunchKernelGGL((k_predict_multi<128, 4, 128, 16, true>), dim3((unsigned)(nblocks < slots ? nblocks : slots)),
                                    dim3(256), 0, ctx->stream, tab, ctx->Np, ctx->Wld, (int)GP, nI, nW, xcd_rows,
-                                   ctx->tile_counter, (unsigned)nblocks, ctx->tile_trace, ctx->tri_skip, nrows_dev);
+                                   ctx->tile_counter, (unsigned)nblocks, ctx->tile_trace, tri_arg, nrows_dev);
             else if (TN == 32)
                 hipLaunchKernelGGL((k_predict_static_multi<64, 4, 32, 16>), dim3(nb_s), dim3(256), 0, ctx->stream, tab, ctx->Np,
                                    ctx->Wld, (int)GP, nI, nW, xr, nb_s, order, (unsigned)(ctx->num_cu / 8),
-                                   ctx->tile_priority ? nI : 0, ctx->tile_trace, ctx->tri_skip, nrows_dev);
+                                   ctx->tile_priority ? nI : 0, ctx->tile_trace, tri_arg, nrows_dev);
             else if (TN == 128)
                 hipLaunchKernelGGL((k_predict_static_multi<64, 4, 128, 16>), dim3(nb_s), dim3(256), 0, ctx->stream, tab, ctx->Np,
                                    ctx->Wld, (int)GP, nI, nW, xr, nb_s, order, (unsigned)(ctx->num_cu / 8),
-                                   ctx->tile_priority ? nI : 0, ctx->tile_trace, ctx->tri_skip, nrows_dev);
+                                   ctx->tile_priority ? nI : 0, ctx->tile_trace, tri_arg, nrows_dev);
             else
                 hipLaunchKernelGGL((k_predict_static_multi<64, 4, 64, 16>), dim3(nb_s), dim3(256), 0, ctx->stream, tab, ctx->Np,
                                    ctx->Wld, (int)GP, nI, nW, xr, nb_s, order, (unsigned)(ctx->num_cu / 8),
-                                   ctx->tile_priority ? nI : 0, ctx->tile_trace, ctx->tri_skip, nrows_dev);
+                                   ctx->tile_priority ? nI : 0, ctx->tile_trace, tri_arg, nrows_dev);
         } else {
 #ifdef GPB_DEBUG_VARIANTS
 #define GPB_PRED(TT, WW, NN, KK)                                                                                 \
@@ -1367,11 +1377,11 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, con
             hipLaunchKernelGGL((k_predict_static<TT, WW, NN, KK>), dim3(grid), dim3(64 * WW), 0, ctx->stream,     \
                                ctx->Linv, ctx->KsT, ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xcd_rows, \
                                (unsigned)nblocks, resident, (unsigned)(ctx->num_cu / 8),                          \
-                               ctx->tile_priority ? nI : 0, ctx->tile_trace, ctx->tri_skip, nrows_dev);           \
+                               ctx->tile_priority ? nI : 0, ctx->tile_trace, tri_arg, nrows_dev);           \
         else                                                                                                     \
             hipLaunchKernelGGL((k_predict<TT, WW, NN, KK>), dim3(grid), dim3(64 * WW), 0, ctx->stream, ctx->Linv,  \
                                ctx->KsT, ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xcd_rows,            \
-                               ctx->tile_counter, (unsigned)nblocks, ctx->tile_trace, ctx->tri_skip, nrows_dev);   \
+                               ctx->tile_counter, (unsigned)nblocks, ctx->tile_trace, tri_arg, nrows_dev);   \
     } while (0)
         // the measured-and-rejected variants (tools, A/B sweeps and the variant tests; built with -DGPB_DEBUG_VARIANTS into
         // libgpbayes_debug.so): persistent 64-row tiles, 8-wave tiles, the 128x128 tile without the fragment read-ahead or
@@ -1401,7 +1411,7 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, con
         else if (ctx->mma_pipe && T == 128 && nwv == 4 && !resident)
             hipLaunchKernelGGL((k_predict<128, 4, 128, 16, true>), dim3(grid), dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT,
                                ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xcd_rows, ctx->tile_counter,
-                               (unsigned)nblocks, ctx->tile_trace, ctx->tri_skip, nrows_dev);
+                               (unsigned)nblocks, ctx->tile_trace, tri_arg, nrows_dev);
 
         else if (ctx->fold_tiles && T == 64 && TN <= 64 && nwv == 4 && !ctx->tile_trace) {
             // folded row-block pairs (k_predict_fold): P * ceil(nI / 2) groups in contiguous ranges per XCD, nW units each
@@ -1426,7 +1436,7 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, con
         if (T == 128) {
             hipLaunchKernelGGL((k_predict<128, 4, 128, 16, true>), dim3(grid128), dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT,
                                ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xcd_rows, ctx->tile_counter,
-                               (unsigned)nblocks, ctx->tile_trace, ctx->tri_skip, nrows_dev);
+                               (unsigned)nblocks, ctx->tile_trace, tri_arg, nrows_dev);
         } else {
             const int order = ctx->resident_order ? ctx->resident_order : 2;
             const int xr = xcd_rows < 2 ? xcd_rows : 0;
@@ -1434,7 +1444,7 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, con
     hipLaunchKernelGGL((k_predict_static<64, 4, NN, 16>), dim3((unsigned)(xr == 1 ? ((ngroups + 7) / 8) * 8 * nW : ngroups * nW)), \
                        dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT, ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xr, \
                        (unsigned)(xr == 1 ? ((ngroups + 7) / 8) * 8 * nW : ngroups * nW), order, (unsigned)(ctx->num_cu / 8), \
-                       ctx->tile_priority ? nI : 0, ctx->tile_trace, ctx->tri_skip, nrows_dev)
+                       ctx->tile_priority ? nI : 0, ctx->tile_trace, tri_arg, nrows_dev)
             if (TN == 32) GPB_PRED(32);
             else if (TN == 128) GPB_PRED(128);
             else GPB_PRED(64);
