@@ -252,19 +252,20 @@ static int gp_set_impl(gpb_ctx* ctx, int64_t P, int64_t d, const int64_t* N_p, c
     std::vector<double> xp((size_t)(PX * Np * dpad), 0.0), zp((size_t)(P * Np), 0.0), xm((size_t)(PX * dpad), 0.0);
     ctx->h_ext.assign((size_t)(PX * d), 0.0);
     ctx->h_N.assign((size_t)P, 0);
-    // The padding of a design to Np = a multiple of 64 points sits IN FRONT of it (round 5): stored row pad + i holds design point i,
-    // pad = Np - N; rows [0, pad) are the identity block of K and L, zero rows of K*^T, zero targets.  In front, not behind: the
-    // predict kernel's work per row block grows with its index (triangular K loops), so padding costs its rows' share of the
-    // LIGHTEST row block instead of the heaviest, and the leading all-zero K-steps are skipped (launch_vsq) — N = 1000 wasted 4.7 %
-    // of the launch behind, 0.8 % in front.  Designs of a multiple of 64 points (every BASELINE configuration) are unaffected.
+    // The padding of a design to Np = a multiple of 64 points sits IN FRONT of it (round 5), in whole 16-row units (pad_front: the
+    // remainder of < 16 rows stays behind): stored row pad + i holds design point i; the padded rows are identity rows of K and L,
+    // zero rows of K*^T, zero targets.  In front, not behind: the predict kernel's work per row block grows with its index
+    // (triangular K loops), so padding costs its rows' share of the LIGHTEST row block instead of the heaviest, and the leading
+    // all-zero K-steps are skipped outright (launch_vsq) — N = 1000 wasted 4.7 % of the launch behind, 0.6 % now.  Designs of a
+    // multiple of 64 points (every BASELINE configuration) are unaffected.
     for (int64_t p = 0; p < P; ++p) {
         ctx->h_N[(size_t)p] = (int)N_p[p];
-        const int64_t pad = Np - N_p[p];
+        const int64_t pad = pad_front(Np, N_p[p]);
         for (int64_t i = 0; i < N_p[p]; ++i) zp[p * Np + pad + i] = Z_p[p][i];
     }
     for (int64_t q = 0; q < PX; ++q) {
         const double* Xq = X_p[q];
-        const int64_t Nq = N_p[q], pad = Np - Nq;
+        const int64_t Nq = N_p[q], pad = pad_front(Np, Nq);
         for (int64_t i = 0; i < Nq; ++i)
             for (int64_t k = 0; k < d; ++k) xp[(q * Np + pad + i) * dpad + k] = Xq[i * d + k];
         for (int64_t k = 0; k < d; ++k) {
@@ -394,7 +395,7 @@ static int info_unpadded(const gpb_ctx* ctx, int64_t p, int info) {
     if (info <= 0) return info;
     const int64_t q = ctx->multi ? (ctx->subset ? ctx->h_map[(size_t)p] : p) : 0;
     const int64_t Nq = ctx->multi ? ctx->h_N[(size_t)q] : ctx->N;
-    return info - (int)(ctx->Np - Nq);
+    return info - (int)pad_front(ctx->Np, Nq);
 }
 
 // K build, blocked Cholesky, [triangular inverse, alpha]: enqueued, nothing read back
@@ -450,7 +451,7 @@ extern "C" int gpb_gp_get(gpb_ctx* ctx, int what, double* out_host) {
         for (int64_t p = 0; p < P; ++p) {
             const int64_t Nq = Nof(p);
             for (int64_t i = Nq; i < N; ++i) out_host[p * N + i] = 0.0;
-            GPB_HIP(hipMemcpy(out_host + p * N, ctx->alpha + p * Np + (Np - Nq), sizeof(double) * Nq, hipMemcpyDeviceToHost));
+            GPB_HIP(hipMemcpy(out_host + p * N, ctx->alpha + p * Np + pad_front(Np, Nq), sizeof(double) * Nq, hipMemcpyDeviceToHost));
         }
         return 0;
     }
@@ -459,7 +460,7 @@ extern "C" int gpb_gp_get(gpb_ctx* ctx, int what, double* out_host) {
         return 0;
     }
     if (what == GPB_GET_KSTAR) {                       // KsT is [P][Np][Wld], walker fastest: transposed on the host
-        const int64_t W = ctx->last_W, Wld = ctx->Wld, pad = Np - N;
+        const int64_t W = ctx->last_W, Wld = ctx->Wld, pad = pad_front(Np, N);
         if (W <= 0 || !ctx->KsT) GPB_FAIL(GPB_E_STATE, "gpb_gp_get(GPB_GET_KSTAR): no batch has been evaluated");
         std::vector<double> tmp((size_t)(N * W));
         for (int64_t p = 0; p < P; ++p) {
@@ -473,7 +474,7 @@ extern "C" int gpb_gp_get(gpb_ctx* ctx, int what, double* out_host) {
     const double* src = (what == GPB_GET_K || what == GPB_GET_L) ? ctx->K : (what == GPB_GET_LINV ? ctx->Linv : nullptr);
     if (!src) GPB_FAIL(GPB_E_ARG, "gpb_gp_get: unknown selector");
     for (int64_t p = 0; p < P; ++p) {
-        const int64_t Nq = Nof(p), pad = Np - Nq;
+        const int64_t Nq = Nof(p), pad = pad_front(Np, Nq);
         double* o = out_host + p * N * N;
         if (Nq < N) {
             for (int64_t i = 0; i < N * N; ++i) o[i] = 0.0;

@@ -3,8 +3,8 @@
 // and its gradient.  Replaces the body of sklearn GPR.fit / log_marginal_likelihood
 // (sk:_gpr.py:346-364, 537-652) that the reference calls from src/emulator.py:309-315.
 //
-// All matrices are padded to Np = multiple of 64 with an identity block IN FRONT (gp_set_impl, gpb_api.hip), so that no kernel
-// has ragged edges in N:  K_pad = [[I,0],[0,K]]  =>  L_pad = [[I,0],[0,L]], same for L^-1.
+// All matrices are padded to Np = multiple of 64 with identity blocks (gp_set_impl, gpb_api.hip: in FRONT of the design in whole
+// 16-row units, the remainder behind), so that no kernel has ragged edges in N:  K_pad = diag(I, K, I)  =>  L_pad = diag(I, L, I), same for L^-1.
 #include "gpb_internal.h"
 #include "gemm_tile.h"
 #include "fast_math.h"
@@ -79,7 +79,7 @@ int launch_scale_design(gpb_ctx* ctx) {
 // in K); rounds 1-2 built every K with it (debug build: tune key 39 = 0).
 // One 64x64 tile per workgroup, tiles of the lower block triangle only (the factorisation reads nothing above
 // it); scaled design rows staged in LDS; HBM-write bound (4*Np^2 bytes per GP).  Diagonal: c*1 + sigma_n^2 + alpha (sk:kernels.py:1559-1560,
-// 1401-1412; sk:_gpr.py:347).  Padding rows/cols (in front of the design: gp_set_impl): identity.
+// 1401-1412; sk:_gpr.py:347).  Padding rows/cols (gp_set_impl: in front of the design in whole 16-row units, the rest behind): identity.
 template <int KIND>
 __global__ __launch_bounds__(256) void k_kmat(const double* __restrict__ Xsc, const double* __restrict__ amp,
                                               const double* __restrict__ noise, double alpha_reg,
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_kmat(const double* __restrict__ Xsc, co
                                               const int* __restrict__ form) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int p = blockIdx.z;
-    const int64_t pad = Np - sel.Nq(sel.q(p));
+    const int64_t pad = pad_front(Np, sel.Nq(sel.q(p))), hi = pad + sel.Nq(sel.q(p));      // the design: rows [pad, hi)
     if (blockIdx.x > blockIdx.y) return;               // lower block triangle only: nothing reads K above it
     if (form && form[p] != 1) return;                  // a Gram-form GP: k_kmat_mfma's
     const int64_t i0 = (int64_t)blockIdx.y * 64, j0 = (int64_t)blockIdx.x * 64;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_kmat(const double* __restrict__ Xsc, co
         for (int b = 0; b < 4; ++b) {
             const int64_t i = i0 + ty + 16 * a, j = j0 + tx + 16 * b;
             double v;
-            if (i < pad || j < pad) v = (i == j) ? 1.0 : 0.0;      // the padding (in front: gp_set_impl): identity
+            if (i < pad || j < pad || i >= hi || j >= hi) v = (i == j) ? 1.0 : 0.0;      // the padding (gp_set_impl): identity
             else if (i == j) v = dg;
             else v = c * shape_fn<KIND>(r2[a][b]);
             Kp[i * Np + j] = v;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_kmat_mfma(const double* __restrict__ Xc
                                                    double alpha_reg, double* __restrict__ K, const GpSel sel, int64_t Np,
                                                    const int* __restrict__ form, const int2* __restrict__ tiles) {
     if (form && form[blockIdx.y] != 0) return;         // a difference-form GP: k_kmat's
-    const int64_t pad = Np - sel.Nq(sel.q(blockIdx.y));
+    const int64_t pad = pad_front(Np, sel.Nq(sel.q(blockIdx.y))), hi = pad + sel.Nq(sel.q(blockIdx.y));     // the design: rows [pad, hi)
     // the tile's two operand blocks (64 design rows x DPAD each, contiguous in Xc) are staged in LDS by coalesced 16-byte
     // loads — fragment-shaped loads straight from global memory touched sixteen 32-byte pieces per instruction, 1920 cache
     // line requests per workgroup — and read back as MFMA fragments (row stride DPAD + 1 doubles: conflict-free)
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_kmat_mfma(const double* __restrict__ Xc
     }
     const double c = amp[p];
     double* Kp = K + (int64_t)p * Np * Np;
-    const bool special = bi == bj || j0 < pad;          // a diagonal or padding in this tile (j0 <= i0; the padding is in front)
+    const bool special = bi == bj || j0 < pad || i0 + 64 > hi;      // a diagonal or padding in this tile (j0 <= i0)
     if (!special) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_kmat_mfma(const double* __restrict__ Xc
             for (int r = 0; r < 4; ++r) {
                 const int64_t i = i0 + m0 + 16 * a + lk + 4 * r, j = j0 + n0 + 16 * b + lr;
                 double v;
-                if (i < pad || j < pad) v = (i == j) ? 1.0 : 0.0;      // the padding (in front: gp_set_impl): identity
+                if (i < pad || j < pad || i >= hi || j >= hi) v = (i == j) ? 1.0 : 0.0;      // the padding (gp_set_impl): identity
                 else if (i == j) v = dg;
                 else v = c * kmat_pair<KIND>(acc[a][b][r], sdi[m0 + 16 * a + lk + 4 * r], dj);
                 Kp[i * Np + j] = v;
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(256) void k_lml_grad(const double* __restrict__ Xsc
                                                   int ntiles) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int p = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
-    const int64_t pad = Np - sel.Nq(sel.q(p));
+    const int64_t pad = pad_front(Np, sel.Nq(sel.q(p))), hi = pad + sel.Nq(sel.q(p));
     int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     while (ti * (ti + 1) / 2 > t) --ti;
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256) void k_lml_grad(const double* __restrict__ Xsc
         for (int b = 0; b < 4; ++b) {
             const int li = ty + 16 * a, lj = tx + 16 * b;
             const int64_t i = i0 + li, j = j0 + lj;
-            if (i < pad || j < pad || j > i) continue;           // (padding in front: gp_set_impl)
+            if (i < pad || j < pad || i >= hi || j > i) continue;           // (the design: rows [pad, hi), gp_set_impl)
             const double w = (ap[i] * ap[j] - Kv[i * Np + j]) * ((i == j) ? 0.5 : 1.0);
             double D[DPAD];
             double r2 = 0.0;

@@ -33,6 +33,11 @@ struct GpSel {
     __device__ __forceinline__ int64_t Nq(int qq) const { return n ? (int64_t)n[qq] : (int64_t)N; }
 };
 
+// Where a design of N points sits among the Np = multiple of 64 stored rows: rows [pad_front, pad_front + N).  The padding goes in
+// FRONT in whole 16-row units — the predict tiles' K-step: those leading zero rows of K*^T are skipped outright and their rows of V
+// fall into the lightest row block — and the remainder (< 16 rows) behind.
+__host__ __device__ __forceinline__ int64_t pad_front(int64_t Np, int64_t N) { return ((Np - N) / 16) * 16; }
+
 struct LoopGroup;
 struct gpb_ctx {
     int device = 0;

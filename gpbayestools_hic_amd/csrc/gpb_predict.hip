@@ -168,7 +168,7 @@ __device__ __forceinline__ void kcross_body(KxLds<DPAD, WPL>& L, const double* _
             double kv[WPL];
 #pragma unroll
             for (int u = 0; u < WPL; ++u) kv[u] = 0.0;
-            if (n >= Np - N) {                          // (rows [0, Np - N) are the padding: zero rows of K*^T)
+            if (n >= pad_front(Np, N) && n < pad_front(Np, N) + N) {      // (the other rows are the padding: zero rows of K*^T)
                 const double* xr = sxr + pt * DPAD;
                 double r2[WPL];
 #pragma unroll
@@ -1252,7 +1252,7 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, con
     // leading all-zero rows of K*^T (the designs' padding, in front: gp_set_impl) common to every context of the launch, in whole
     // 16-deep K-steps: the tiles start their K loops behind them
     int64_t kskip = ctx->Np;
-    for (int e = 0; e < E; ++e) kskip = imin64(kskip, ((ctxs[e]->Np - ctxs[e]->N) / 16) * 16);
+    for (int e = 0; e < E; ++e) kskip = imin64(kskip, pad_front(ctxs[e]->Np, ctxs[e]->N));
     const int tri_arg = (ctx->tri_skip ? 1 : 0) | ((int)kskip << 8);
     if (multi && Gsum > MAX_MULTI_GP) GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_vsq: too many GPs for one table");
     const int64_t GP = Gsum;                           // GPs of the launch: what the tile counts are made of
