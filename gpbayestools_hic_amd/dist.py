@@ -236,25 +236,37 @@ class WalkerSharding:
     def time_allgather(self, count, reps=200, warm=20):
         """Microseconds per all-gather of `count` float64 per rank, back to back on the kernels' stream (HIP events; the MAX over
         the ranks) — the wire latency the sharded step pays twice: in place, through the path a sharded batch takes (the C ABI's
-        in-stream ncclAllGather when `direct` is set, else torch.distributed's).  Collective.  None under gloo (no CUDA all-gather:
-        the rehearsal stages through the host and its time says nothing about a wire)."""
+        in-stream ncclAllGather when `direct` is set, else torch.distributed's).  The collectives are enqueued BEHIND a few
+        milliseconds of unrelated device work, so that they are all in the queue when the first one starts: the interval between the
+        two events is device time, not the host's enqueue rate (as in the step loop, whose kernels the C ABI enqueues far ahead).
+        Collective.  None under gloo (no CUDA all-gather: the rehearsal stages through the host and its time says nothing about a
+        wire)."""
         import torch
+        from . import _native as nat
         if self.backend() == "gloo":
             return None
         dev = torch.device("cuda", torch.cuda.current_device())
         buf = torch.zeros(count * self.world, dtype=torch.float64, device=dev)
         mine = buf[self.rank * count:(self.rank + 1) * count]
+        if self.direct is not None:
+            eng = self.direct
+            eng._track_stream()
+            eng._dev(mine, (count,), "send"); eng._dev(buf, (count * self.world,), "recv")     # validated once, then the bare call
+            sp, rp, h, fn = nat.VP(mine.data_ptr()), nat.VP(buf.data_ptr()), eng.h, eng.lib.gpb_dist_allgather
 
-        def one():
-            if self.direct is not None:
-                self.direct.dist_allgather(mine, buf)
-            else:
+            def one():
+                eng._ck(fn(h, sp, rp, count))
+        else:
+            def one():
                 self.dist.all_gather_into_tensor(buf, mine, group=self.group)
         for _ in range(warm):
             one()
+        plug = torch.empty((4096, 4096), dtype=torch.float32, device=dev).normal_()
         torch.cuda.synchronize()
         self.dist.barrier(group=self.group)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(8):                             # ~ a few ms of device work in front: the host gets ahead of the device
+            plug = torch.mm(plug, plug).clamp_(-1.0, 1.0)
         e0.record()
         for _ in range(reps):
             one()
