@@ -406,3 +406,55 @@ def test_contexts_come_and_go_through_the_buffer_cache():
                 old.close()
     for e in keep:
         e.close()
+
+
+@pytest.mark.parametrize("N", [100, 70, 127, 129, 1000])
+def test_designs_that_are_not_a_multiple_of_64_points(N):
+    """The stored matrices are padded to Np = a multiple of 64 rows with identity blocks — in FRONT of the design in whole 16-row
+    units (the predict tiles' K-step: those leading zero rows of K*^T are skipped and the padded rows of V fall into the lightest
+    row block), the remainder of fewer than 16 rows behind (csrc: pad_front, gp_set_impl).  Nothing of that may show at the
+    boundary: K, L, L^-1, alpha and K* come back in the design's own numbering, LAPACK's info counts the design's pivots, and
+    every number meets the oracle's — for front paddings of 16 / 48 / 0 / 48 / 16 rows and 12 / 10 / 1 / 15 / 8 behind."""
+    from gpbayestools_hic_amd import GPEngine, synth
+    from oracle import gp_oracle as O
+    from scipy.linalg import lapack
+    d, P, W = 5, 3, 37
+    X = synth.lhs(N, d, seed=N)
+    rng = np.random.default_rng(N)
+    Z = rng.standard_normal((P, N))
+    th = np.array([np.concatenate([[rng.uniform(-0.3, 0.3)], np.log(rng.uniform(0.5, 2.0, d)), [np.log(rng.uniform(0.02, 0.1))]])
+                   for _ in range(P)])
+    eng = GPEngine(0)
+    eng.set_data(X, Z, "Matern25", 0.1)
+    eng.set_theta(th)
+    eng.fit_piece("kmat")                              # K(X,X) alone (the factorisation overwrites it with L)
+    K = eng.get("K")
+    eng.factor()
+    Xs = synth.walkers(W, d, seed=N + 1)
+    Xs[5] = X[N - 1]; Xs[6] = X[0]                     # queries ON the last and the first design point
+    mean, var = eng.predict(Xs)
+    L, Li, al, Ks = eng.get("L"), eng.get("Linv"), eng.get("alpha"), eng.get("Kstar", W)
+    assert K.shape == (P, N, N) and Ks.shape == (P, W, N) and al.shape == (P, N)
+    kind = O.KIND_NAMES["Matern25"]
+    for p in range(P):
+        Ko = O.kernel_train(X, th[p], kind, 0.1)
+        Lo, ao = O.gp_factor(X, Z[p], th[p], kind, 0.1)
+        assert np.max(np.abs(np.tril(K[p]) - np.tril(Ko))) < 1e-13 * np.max(np.abs(Ko))      # (the lower triangle is what is built)
+        assert np.max(np.abs(L[p] - Lo)) < 1e-11 * np.max(np.abs(Lo)) and np.max(np.abs(al[p] - ao)) < 1e-10 * np.max(np.abs(ao))
+        assert np.max(np.abs(Li[p] @ Lo - np.eye(N))) < 1e-10
+        assert np.max(np.abs(Ks[p] - O.kernel_cross(Xs, X, th[p], kind))) < 1e-13
+        mo, vo = O.gp_predict(Xs, X, th[p], Lo, ao, kind)
+        assert np.max(np.abs(mean[:, p] - mo)) < 1e-11 * max(np.max(np.abs(mo)), 1.0)
+        assert np.max(np.abs(var[:, p] - vo)) < 1e-10 * np.max(np.abs(vo))
+    lml, grad = eng.lml(th)
+    for p in range(P):
+        vo, go = O.lml(th[p], X, Z[p], kind, 0.1, eval_gradient=True)
+        assert abs(lml[p] - vo) < 1e-10 * abs(vo) and np.max(np.abs(grad[p] - go)) < 1e-9 * max(np.max(np.abs(go)), 1.0)
+    # an indefinite matrix: LAPACK's info (first non-positive pivot, 1-based) in the DESIGN's numbering
+    eng.set_data(X, Z, "Matern25", alpha=-1.3)
+    eng.set_theta(th)
+    info = eng.factor(raise_on_fail=False)
+    for p in range(P):
+        _, ref_info = lapack.dpotrf(O.kernel_train(X, th[p], kind, -1.3), lower=1)
+        assert ref_info > 0 and info[p] == ref_info, (p, info[p], ref_info)
+    eng.close()
