@@ -583,7 +583,16 @@ def main():
     rank, world, local = init_from_env()
     assert world == args.gpus
     torch.cuda.set_device(local)
-    if (world > 1 and os.environ.get("GPB_BENCH_DEFAULT_STREAM") != "1") or os.environ.get("GPB_BENCH_OWN_STREAM") == "1":
+    # GPB_BENCH_ONE_RANK_SHARDED=1 (with --gpus 1): the SHARDED branch of this file over a one-rank RCCL communicator — every
+    # nccl-only line (replicate, try_direct, the in-stream all-gather, the self-check, the probe) on the one GPU a build box
+    # has; only the wire between ranks is missing (tests/test_gpu_bench_ranks.py).  Off, N = 1 is the plain single-GPU line.
+    sharded = world > 1
+    if world == 1 and os.environ.get("GPB_BENCH_ONE_RANK_SHARDED") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+        sharded = True
+    if (sharded and os.environ.get("GPB_BENCH_DEFAULT_STREAM") != "1") or os.environ.get("GPB_BENCH_OWN_STREAM") == "1":
         # ranks of a sharded run work on a stream of their own (torch's streams are non-blocking ones): the kernels, the copies
         # and the in-stream ncclAllGather of the C ABI all go where torch's current stream is, and nothing of the step loop
         # inherits the legacy default stream's implicit synchronisation with other streams of the process (RCCL's own included)
@@ -592,7 +601,7 @@ def main():
     chain, emu, info = build_chain(args.config, device=local)
     N, d, M, P = info["N"], info["d"], info["M"], info["P"]
     nwalkers = args.walkers or 2 * info["W"]
-    sharding = WalkerSharding() if world > 1 else None
+    sharding = WalkerSharding() if sharded else None
     if sharding is not None:
         # every rank has just trained the same emulator on the same synthetic data — but the host part of a training (scaler
         # + PCA: an N x M SVD in numpy) rounds differently under a different BLAS threading, so the replicas are rank 0's
@@ -615,7 +624,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -632,7 +641,7 @@ def main():
     # itself lets the ranks agree that gpb_chain_emcee_prepare succeeded everywhere before any of them enqueues a
     # collective.
     loop = "gpb_chain_emcee_run" if sampler._resident_engine() is not None else "host-driven"
-    if world > 1 and loop == "gpb_chain_emcee_run":
+    if sharded and loop == "gpb_chain_emcee_run":
         ok = True
         try:
             ref = StretchSampler(chain, nwalkers, seed=777, sharding=sharding, device=local)
@@ -670,7 +679,7 @@ def main():
         launches, kms, units = eng.profile_read()
         eng.profile(False)
         tt = torch.tensor([dt, units], dtype=torch.float64, device="cuda")
-        if world > 1:
+        if sharded:
             mx, sm = tt.clone(), tt.clone()
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
             dist.all_reduce(sm, op=dist.ReduceOp.SUM)
@@ -691,12 +700,12 @@ def main():
               f"(--steps {args.steps} --warmup {args.warmup}: more than ~60 steps in all); `value` counts evaluated "
               f"walkers only", file=sys.stderr)
     devices_used = [local]
-    if world > 1:       # which GPU each rank ran on, as the communicator's ranks report it
+    if sharded:         # which GPU each rank ran on, as the communicator's ranks report it
         dv = [None] * world
         dist.all_gather_object(dv, int(local))
         devices_used = dv
     consistent = None
-    if world > 1:       # replicated RNG + gathered log-probabilities: every rank must hold the same ensemble
+    if sharded:         # replicated RNG + gathered log-probabilities: every rank must hold the same ensemble
         chk = torch.stack([sampler.pos.sum(), sampler.lp.sum()])
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -731,7 +740,7 @@ def main():
     # the wire, measured: what ONE all-gather of a batch's shares costs on the kernels' stream (twice per step) — the number the
     # expected 8-GPU rate hangs on; a failure here must not cost the line that was just timed
     wire = None
-    if world > 1:
+    if sharded:
         phase(0.25, "all-gather probe")
         try:
             us = sharding.time_allgather(max(nwalkers // 2 // world, 1))
@@ -761,15 +770,16 @@ def main():
                                    f"around theta*)"
                                    + ("; the ensemble reached the box inside the timed region: value = evaluated walkers only"
                                       if degraded else ""), "walkers": nwalkers,
-                       "parallelism": f"walker-shard x{world}" if world > 1 else "single GPU", "step_loop": loop,
-                       "ranks": dist.get_world_size() if world > 1 else 1,
+                       "parallelism": f"walker-shard x{world}" + ("" if world > 1 else " (one-rank RCCL rehearsal)") if sharded else "single GPU",
+                       "step_loop": loop,
+                       "ranks": dist.get_world_size() if sharded else 1,
                        "stream": "torch's default stream" if torch.cuda.current_stream().cuda_stream == 0 else "a non-blocking stream per rank",
                        "devices_used": devices_used,
                        "launched_by": "bench.py itself (bare --gpus N: child torch.distributed.run)"
                                       if os.environ.get("GPB_BENCH_SPAWNED") == "1" else
                                       ("an outer launcher (WORLD_SIZE set)" if world > 1 else "single process"),
                        "untimed_preheat": f"{args.preheat} steps of the same loop on a scratch ensemble before the W warm-up steps (clocks, RCCL channels)",
-                       "allgather": None if world == 1 else (
+                       "allgather": None if not sharded else (
                            "gpb_dist_allgather (ncclAllGather on the kernel stream)" if sharding.direct is not None
                            else "torch.distributed " + dist.get_backend()
                                 + (" (direct path not used: %s)" % direct_why if direct_why else ""))},
@@ -817,7 +827,7 @@ def main():
             cb["same_rows_outside_box"] = bool(np.array_equal(fin, np.isfinite(lp_gpu)))
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

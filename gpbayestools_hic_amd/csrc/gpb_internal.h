@@ -267,6 +267,7 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
 // its three phases, for callers that batch the middle one over several contexts (chains of emulators)
 int launch_kcross(gpb_ctx* ctx, const double* Xs_dev, int64_t W, const int* nrows_dev);
 int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, int64_t W, const int* nrows_dev);
+int launch_param_maps(gpb_ctx* const* ctxs, int n, const double* X_dev, int64_t W);      // gpb_pmap.hip
 // p0s / p1s (optional): the launch covers GPs [p0s[e], p1s[e]) of context e instead of all of them (the shared-launch kernels with a
 // table of those GPs: same tiles, same bits).  prof_begin / prof_end: a pair of launches timed as one (ctx->prof_open).
 int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, const int* p0s = nullptr, const int* p1s = nullptr,

@@ -1587,14 +1587,22 @@ int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, doub
     // (3) the block log-likelihoods, added up in emuList order: one launch that walks the emulators (k_loglike_lowrank_multi)
     //     when every block takes the low-rank kernel, else one launch per emulator.
     const double* Xg[64];
+    gpb_ctx* mapped[64];
+    int nmapped = 0;
     for (int e = 0; e < E; ++e) {
         gpb_ctx* c = ctxs[e];
         Xg[e] = c0->cmp_X;
         c->hint_from = c0;
         if (c->pmap_d_in > 0) {                        // this emulator's GPs see the PCA-reduced parameters
-            if ((rc = gpb_param_map(c, c0->cmp_X, W, c->Xs))) { c0->err = c->err; return rc; }
+            mapped[nmapped++] = c;
             Xg[e] = c->Xs;
         }
+    }
+    if (nmapped > 1 && c0->chain_batch) {              // the maps of all mapped emulators over the gathered rows: one launch
+        if ((rc = launch_param_maps(mapped, nmapped, c0->cmp_X, W))) { c0->err = mapped[0]->err; return rc; }
+    } else {
+        for (int i = 0; i < nmapped; ++i)
+            if ((rc = gpb_param_map(mapped[i], c0->cmp_X, W, mapped[i]->Xs))) { c0->err = mapped[i]->err; return rc; }
     }
     bool overlap = false;
 #ifdef GPB_DEBUG_VARIANTS
@@ -1608,7 +1616,7 @@ int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, doub
     int64_t Gall = 0;
     for (int e = 0; e < E && overlap; ++e) {
         const gpb_ctx* c = ctxs[e];
-        overlap = c->n_diff == 0 && c->Np == c0->Np && c->d == c0->d && c->dpad == c0->dpad && !c->multi;
+        overlap = c->n_diff == 0 && c->Np == c0->Np && c->dpad == c0->dpad && !c->multi;
         Gall += c->P;
     }
     overlap = overlap && Gall >= 2 && Gall <= GPB_MAX_MULTI_GP;
@@ -1666,9 +1674,9 @@ int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, doub
         if (rc) { c0->err = cb[0]->err; return rc; }
     }
 #endif
-    for (int e = 0; e < E && !overlap;) {              // K*^T: one launch per run of emulators of equal padded size and input count
-        int n = 1;
-        while (c0->chain_batch && e + n < E && ctxs[e + n]->Np == ctxs[e]->Np && ctxs[e + n]->d == ctxs[e]->d && n < 32) ++n;
+    for (int e = 0; e < E && !overlap;) {              // K*^T: one launch per run of emulators of equal padded size and PADDED input
+        int n = 1;                                     // count (parameterTrafoPCA emulators keep 17-19 of 20 inputs each: one launch)
+        while (c0->chain_batch && e + n < E && ctxs[e + n]->Np == ctxs[e]->Np && ctxs[e + n]->dpad == ctxs[e]->dpad && n < 32) ++n;
         if ((rc = launch_kcross_group(ctxs + e, Xg + e, n, W, cmpv))) { c0->err = ctxs[e]->err; return rc; }
         e += n;
     }

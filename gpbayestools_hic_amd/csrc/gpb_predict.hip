@@ -245,8 +245,8 @@ constexpr int MAX_KX_CTX = 32;
 struct KxCtx {
     const double *Xs, *Xc, *ls, *amp, *alpha, *dnorm, *muS;
     double *KsT, *mpart;
-    int N, P, kind, g0, p0;      // g0: index of the entry's first GP in the launch; p0: that GP's index in its context
-};
+    int N, P, kind, g0, p0, d;   // g0: index of the entry's first GP in the launch; p0: that GP's index in its context;
+};                               // d: the context's own input count (contexts of one launch share the padded count only)
 struct KxTable { KxCtx c[MAX_KX_CTX]; int E; };
 
 template <int DPAD, int WPL>
@@ -259,13 +259,13 @@ __global__ __launch_bounds__(256) void k_kcross_multi(const KxTable tab, int64_t
     const KxCtx& c = tab.c[e];
     const int p = g - c.g0 + c.p0;
     if (c.kind == GPB_KERNEL_RBF)
-        kcross_body<GPB_KERNEL_RBF, DPAD, true, WPL>(lds, c.Xs, W, d, c.Xc, c.ls, c.amp, c.alpha, c.KsT, c.mpart, c.N, Np, Wld,
+        kcross_body<GPB_KERNEL_RBF, DPAD, true, WPL>(lds, c.Xs, W, c.d, c.Xc, c.ls, c.amp, c.alpha, c.KsT, c.mpart, c.N, Np, Wld,
                                                      c.P, c.dnorm, c.muS, chunks_per_wg, nrows, p);
     else if (c.kind == GPB_KERNEL_MATERN15)
-        kcross_body<GPB_KERNEL_MATERN15, DPAD, true, WPL>(lds, c.Xs, W, d, c.Xc, c.ls, c.amp, c.alpha, c.KsT, c.mpart, c.N, Np,
+        kcross_body<GPB_KERNEL_MATERN15, DPAD, true, WPL>(lds, c.Xs, W, c.d, c.Xc, c.ls, c.amp, c.alpha, c.KsT, c.mpart, c.N, Np,
                                                           Wld, c.P, c.dnorm, c.muS, chunks_per_wg, nrows, p);
     else
-        kcross_body<GPB_KERNEL_MATERN25, DPAD, true, WPL>(lds, c.Xs, W, d, c.Xc, c.ls, c.amp, c.alpha, c.KsT, c.mpart, c.N, Np,
+        kcross_body<GPB_KERNEL_MATERN25, DPAD, true, WPL>(lds, c.Xs, W, c.d, c.Xc, c.ls, c.amp, c.alpha, c.KsT, c.mpart, c.N, Np,
                                                           Wld, c.P, c.dnorm, c.muS, chunks_per_wg, nrows, p);
 }
 
@@ -1121,7 +1121,7 @@ int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, in
     for (int e = 0; e < E; ++e)
         if (ctxs[e]->multi) GPB_FAIL(GPB_E_STATE, "gpb: a gpb_gp_set_multi context is fit-only (its GPs have different designs)");
     for (int e = 0; e < E && ok; ++e)           // (the shared launch is the Gram form's: a context with a difference-form GP takes its own)
-        ok = ctxs[e]->n_diff == 0 && ctxs[e]->Np == ctx->Np && ctxs[e]->d == ctx->d && ctxs[e]->dpad == ctx->dpad && ctxs[e]->stream == ctx->stream;
+        ok = ctxs[e]->n_diff == 0 && ctxs[e]->Np == ctx->Np && ctxs[e]->dpad == ctx->dpad && ctxs[e]->stream == ctx->stream;
     if (!ok) {
         for (int e = 0; e < E; ++e) {
             const int rc = launch_kcross(ctxs[e], Xs[e], W, nrows_dev);
@@ -1139,7 +1139,7 @@ int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, in
         c->Wld = Wuse;
         c->last_W = W;
         tab.c[e] = KxCtx{Xs[e], c->Xc, c->ls, c->amp, c->alpha, c->dnorm, c->muS, c->KsT, c->mpart, (int)c->N, (int)c->P,
-                         c->kind, G, 0};
+                         c->kind, G, 0, (int)c->d};
         G += (int)c->P;
     }
     tab.E = E;
@@ -1189,13 +1189,13 @@ int launch_kcross_ranges(gpb_ctx* const* ctxs, const double* const* Xs, int E, c
     int G = 0;
     for (int e = 0; e < E; ++e) {
         gpb_ctx* c = ctxs[e];
-        if (c->multi || !c->factored || W > c->Wcap || c->n_diff != 0 || c->Np != ctx->Np || c->d != ctx->d || c->dpad != ctx->dpad ||
+        if (c->multi || !c->factored || W > c->Wcap || c->n_diff != 0 || c->Np != ctx->Np || c->dpad != ctx->dpad ||
             p0s[e] < 0 || p1s[e] > c->P || p0s[e] >= p1s[e])
             GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_kcross_ranges over a context that does not qualify");
         c->Wld = Wuse;
         c->last_W = W;
         tab.c[e] = KxCtx{Xs[e], c->Xc, c->ls, c->amp, c->alpha, c->dnorm, c->muS, c->KsT, c->mpart, (int)c->N, (int)c->P,
-                         c->kind, G, p0s[e]};
+                         c->kind, G, p0s[e], (int)c->d};
         G += p1s[e] - p0s[e];
     }
     tab.E = E;

@@ -38,10 +38,11 @@ def build_chain(cfg, workdir=None, device=0, N=None, W=None):
     return chain, emu, info
 
 
-def build_multi_chain(specs, d, workdir=None, device=0):
+def build_multi_chain(specs, d, workdir=None, device=0, mapped=False):
     """A chain of several emulators over one parameter space, as real analyses run it (nine emulators, sum of
     observables ~540: RunBayesianAnalysis.ipynb:35-48; src/mcmc.py:139-166).  specs: [(N, M, P, kernel)], every
-    emulator with its own design, observables and (fixed) hyper-parameters.  Returns (chain, emulators, info)."""
+    emulator with its own design, observables and (fixed) hyper-parameters.  mapped: every emulator with parameterTrafoPCA
+    (its GPs over the PCA-reduced parameters, src/emulator.py:492-551; d = 20).  Returns (chain, emulators, info)."""
     from .emulator import Emulator
     from .mcmc import Chain
     workdir = workdir or tempfile.mkdtemp(prefix="gpb_multi_")
@@ -55,10 +56,14 @@ def build_multi_chain(specs, d, workdir=None, device=0):
         Y = synth.observables(X, M, seed=synth.SEED + 200 + i)
         tp = os.path.join(workdir, "train%d.pkl" % i)
         synth.write_training_pickle(tp, X, Y, 0.01)
-        emu = Emulator(training_set_path=tp, parameter_file=pf, npc=P, device=device)
+        emu = Emulator(training_set_path=tp, parameter_file=pf, npc=P, device=device, parameterTrafoPCA=mapped)
         ktype = {"RBF": "RBF", "Matern15": "Matern", "Matern25": "Matern25"}[kernel]
-        emu.trainEmulator([True] * emu.nev, kernel_type=ktype,
-                          thetas=synth.fixed_theta(d, P, ell=1.2 + 0.1 * i, noise=0.03 + 0.01 * i))
+        th = synth.fixed_theta(d, P, ell=1.2 + 0.1 * i, noise=0.03 + 0.01 * i)
+        if mapped:      # length scales in units of each reduced input's extent, as the reference's bounds are (src/emulator.py:292-297)
+            ext = np.ptp(emu.PCA_new_design_points, axis=0)
+            th = synth.fixed_theta(len(ext), P, ell=1.2 + 0.1 * i, noise=0.03 + 0.01 * i)
+            th[:, 1:-1] += np.log(ext)[None, :]
+        emu.trainEmulator([True] * emu.nev, kernel_type=ktype, thetas=th)
         yexp.append(emu.predict(xstar[None, :], return_cov=False)[0])
         emus.append(emu)
         data.append((X, Y))

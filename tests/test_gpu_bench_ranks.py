@@ -102,3 +102,25 @@ def test_bare_bench_refuses_more_nccl_ranks_than_gpus():
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
     assert "2 ranks on this node but 1 visible GPU" in r.stderr.decode(), r.stderr.decode()[-3000:]
+
+
+def test_bench_sharded_branch_over_a_one_rank_rccl_communicator():
+    """Every nccl-only line of bench.py's sharded branch on the one GPU of a build box (GPB_BENCH_ONE_RANK_SHARDED=1): rank 0's
+    state replicated through torch.distributed's nccl backend, the C ABI's own communicator formed (try_direct), the C loop with
+    the in-stream ncclAllGather checked against the host-driven loop, the max-over-ranks timing, the ensemble consistency
+    all-reduce and the all-gather probe.  Only the wire between ranks is missing — and the ensemble must equal the plain run's."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "WORLD_SIZE", "RANK", "LOCAL_RANK", "GPB_DIST_BACKEND"):
+        env.pop(k, None)
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS, env, "one_plain")
+    sh = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS,
+              dict(env, GPB_BENCH_ONE_RANK_SHARDED="1", MASTER_PORT=str(_free_port())), "one_rank_rccl")
+    cfg = sh["config"]
+    assert sh["n_gpus"] == 1 and cfg["ranks"] == 1 and "one-rank RCCL rehearsal" in cfg["parallelism"]
+    assert cfg["allgather"].startswith("gpb_dist_allgather"), cfg["allgather"]       # the direct path passed its self-check
+    assert cfg["step_loop"] == "gpb_chain_emcee_run"                                  # ... and the sharded C loop its own
+    assert cfg["stream"] == "a non-blocking stream per rank" and cfg["devices_used"] == [0]
+    assert sh["ranks_hold_identical_ensemble"] is True
+    probe = sh["extras"]["allgather_probe"]
+    assert "error" not in probe and 0.0 < probe["us_per_allgather"] < 500.0
+    assert sh["ensemble_checksum"] == one["ensemble_checksum"] and sh["acceptance_fraction"] == one["acceptance_fraction"]

@@ -303,3 +303,53 @@ def test_chain_block_likelihoods_split_over_workgroups_give_the_walks_bits(tmp_p
     ref = _oracle_chain(info)(X[:40])
     ins = np.isfinite(ref)
     assert relerr(outs[1][0][0][:40][ins], ref[ins]) < 1e-10
+
+
+def test_parameter_maps_of_several_emulators_in_one_launch(tmp_path):
+    """Three parameterTrafoPCA emulators (their own designs, so their own maps; src/emulator.py:492-551) and a plain one in one
+    chain: the maps of the three run as ONE launch over the gathered rows (k_param_map_multi) — the same bits as one launch per
+    emulator (tune chain_batch 0) and as the per-emulator calls from Python, through the log-posterior and the C step loop."""
+    from conftest import golden
+    from gpbayestools_hic_amd import Chain, Emulator, StretchSampler, synth
+    g = golden("g7_param_pca.npz")
+    lo, hi = g["lo"], g["hi"]
+    d = len(lo)
+    pf, ep = str(tmp_path / "p.txt"), str(tmp_path / "e.pkl")
+    synth.write_parameter_file(pf, lo, hi)
+    emus = []
+    for i, (n, m, npc, on) in enumerate(((0, 4, 3, True), (80, 6, 2, True), (70, 5, 3, True), (90, 12, 4, False))):
+        X = g["X"] if n == 0 else synth.lhs(n, d, seed=20 + i, lo=lo, hi=hi)
+        Y = g["Y"] if n == 0 else synth.observables((X - lo) / (hi - lo), m, seed=30 + i)
+        tp = str(tmp_path / ("t%d.pkl" % i))
+        synth.write_training_pickle(tp, X, Y, 0.01)
+        e = Emulator(training_set_path=tp, parameter_file=pf, npc=npc, parameterTrafoPCA=on)
+        th = synth.fixed_theta(d, npc, ell=2.0)
+        if on:          # length scales in units of each reduced input's extent: these GPs take the Gram form, and the three
+            ext = np.ptp(e.PCA_new_design_points, axis=0)      # emulators (22, 23 and 22 reduced inputs) share ONE cross launch
+            th = synth.fixed_theta(len(ext), npc, ell=2.0)
+            th[:, 1:-1] += np.log(ext)[None, :]
+        e.trainEmulator([True] * e.nev, thetas=g["thetas"] if n == 0 else th)
+        emus.append(e)
+    assert len({e.PCA_new_design_points.shape[1] for e in emus[:3]}) > 1          # different input counts, one padded count
+    x0 = 0.5 * (lo + hi)
+    yexp = np.concatenate([e.predict(x0[None], return_cov=False)[0] for e in emus])
+    synth.write_experiment_pickle(ep, yexp, 0.05 * np.abs(yexp) + 1e-3)
+    chain = Chain(mcmc_path=str(tmp_path / "mcmc" / "c.pkl"), expdata_path=ep, model_parafile=pf)
+    chain.emuList = emus
+    X = lo + (hi - lo) * np.random.default_rng(5).uniform(-0.01, 1.01, (700, d))
+    ins = np.all((X > lo) & (X < hi), axis=1)
+    one = chain.log_posterior(X)
+    assert 0 < ins.sum() < 700 and np.array_equal(np.isfinite(one), ins)
+    eng0 = emus[0]._engine_ready()
+    eng0.tune("chain_batch", 0)
+    assert np.array_equal(chain.log_posterior(X), one)                  # one map launch per emulator
+    start = x0 + 0.01 * (hi - lo) * np.random.default_rng(6).standard_normal((40, d))
+    s0 = StretchSampler(chain, 40, seed=3)
+    s0.run(start, 6, status=10 ** 9)
+    eng0.tune("chain_batch", 1)
+    s1 = StretchSampler(chain, 40, seed=3)
+    assert s1._resident_engine()[2] == 4
+    s1.run(start, 6, status=10 ** 9)
+    assert np.array_equal(s0.chain, s1.chain) and np.array_equal(s0.lnprobability, s1.lnprobability)
+    chain.use_chain_call = False                                        # the per-emulator calls from Python
+    assert np.array_equal(chain.log_posterior(X), one)

@@ -25,7 +25,8 @@ def main():
         if a.startswith("--walkers="):
             nw = int(a[10:])
     specs = [(1000, 60, 6 + i % 3, ("RBF", "Matern25", "RBF")[i % 3]) for i in range(9)]
-    chain, emus, info = build_multi_chain(specs, d)
+    mapped = "--mapped" in sys.argv[2:]          # every emulator with parameterTrafoPCA: nine parameter maps per half-step
+    chain, emus, info = build_multi_chain(specs, d, mapped=mapped)
     for a in sys.argv[2:]:
         if a.startswith("--tune="):
             k, v = a[7:].split(":")
@@ -49,7 +50,7 @@ def main():
     n_l, ms_l, u_l = e0.profile_read()
     e0.profile(False)
     rows = u_l / gps
-    print(json.dumps({"walkers": nw, "steps": steps, "ms_per_step": dt * 1e3, "predict_launches_per_step": n_l / steps,
+    print(json.dumps({"walkers": nw, "steps": steps, "parameterTrafoPCA": mapped, "ms_per_step": dt * 1e3, "predict_launches_per_step": n_l / steps,
                       "predict_ms_per_step": ms_l / steps, "outside_predict_ms_per_step": dt * 1e3 - ms_l / steps,
                       "outside_predict_share": 1.0 - ms_l / steps / (dt * 1e3),
                       "rows_inside_box_fraction": rows / (nw * steps),
