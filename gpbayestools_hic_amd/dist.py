@@ -169,7 +169,7 @@ class WalkerSharding:
         if getattr(self, "_cs_key", None) != key:
             self._cs_w = torch.arange(v.numel(), dtype=torch.int64, device=v.device) * 2 + 1
             self._cs_key = key
-        c = ((v * self._cs_w).sum() + v.numel()).reshape(1)
+        c = (((v * self._cs_w).sum() + v.numel()) >> 1).reshape(1)      # (>> 1: -c never overflows)
         if digest is not None:
             dk = (bytes(digest), self._coll_device())
             if getattr(self, "_dg_key", None) != dk:         # the digest's words on the collective's device: uploaded once

@@ -354,12 +354,20 @@ class Chain:
         root = sh is None or sh.rank == 0
         share = (lambda obj: obj) if sh is None else sh.broadcast_object
         chain_data = {}
+        failed = None
         if root:
             try:
                 with open(self.mcmc_path, "rb") as f:
                     chain_data = pickle.load(f)
             except FileNotFoundError:
                 pass
+            except Exception as e:          # an unreadable chain file: the other ranks must not wait for rank 0 in a collective
+                if sh is None:
+                    raise
+                failed = "%s: %s" % (type(e).__name__, e)
+        failed = share(failed)
+        if failed:
+            raise RuntimeError("run_mcmc: rank 0 could not read %s (%s)" % (self.mcmc_path, failed))
         burn = share("chain" not in chain_data)
         if nburnsteps is None or nwalkers is None:
             log.error("must specify nburnsteps and nwalkers to start chain")
@@ -391,10 +399,18 @@ class Chain:
         self.chain = chain_data["chain"] if root else thinned
         self.acceptance_fraction = sampler.acceptance_fraction
         if root:
-            with open(self.mcmc_path, "wb") as f:
-                pickle.dump(chain_data, f)
+            try:
+                with open(self.mcmc_path, "wb") as f:
+                    pickle.dump(chain_data, f)
+            except Exception as e:
+                if sh is None:
+                    raise
+                failed = "%s: %s" % (type(e).__name__, e)
         if sh is not None:
             self.chain = share(self.chain if root else None)          # (also: nobody returns before the file is written)
+            failed = share(failed)
+            if failed:
+                raise RuntimeError("run_mcmc: rank 0 could not write %s (%s)" % (self.mcmc_path, failed))
 
     def run_pocoMC(self, n_effective=1000, n_active=250, n_prior=2000, sample="tpcn", n_max_steps=200,
                    random_state=42, n_total=5000, n_evidence=5000, pool=None, prior=None):

@@ -41,8 +41,8 @@ def build_chain(cfg, workdir=None, device=0, N=None, W=None):
 def build_multi_chain(specs, d, workdir=None, device=0, mapped=False):
     """A chain of several emulators over one parameter space, as real analyses run it (nine emulators, sum of
     observables ~540: RunBayesianAnalysis.ipynb:35-48; src/mcmc.py:139-166).  specs: [(N, M, P, kernel)], every
-    emulator with its own design, observables and (fixed) hyper-parameters.  mapped: every emulator with parameterTrafoPCA
-    (its GPs over the PCA-reduced parameters, src/emulator.py:492-551; d = 20).  Returns (chain, emulators, info)."""
+    emulator with its own design, observables and (fixed) hyper-parameters.  mapped (True, or one flag per emulator): with
+    parameterTrafoPCA (the GPs over the PCA-reduced parameters, src/emulator.py:492-551; d = 20).  Returns (chain, emulators, info)."""
     from .emulator import Emulator
     from .mcmc import Chain
     workdir = workdir or tempfile.mkdtemp(prefix="gpb_multi_")
@@ -51,7 +51,9 @@ def build_multi_chain(specs, d, workdir=None, device=0, mapped=False):
     synth.write_parameter_file(pf, lo, hi)
     xstar = synth.truth_point(d)
     emus, data, yexp = [], [], []
+    flags = [bool(mapped)] * len(specs) if isinstance(mapped, (bool, int)) else [bool(m) for m in mapped]
     for i, (N, M, P, kernel) in enumerate(specs):
+        mapped = flags[i]
         X = synth.lhs(N, d, seed=synth.SEED + 100 + i)
         Y = synth.observables(X, M, seed=synth.SEED + 200 + i)
         tp = os.path.join(workdir, "train%d.pkl" % i)

@@ -204,7 +204,18 @@ def _mcmc_worker(rank, world, port, workdir, q):
         out = _mcmc_calls(chain)
         wrote = os.path.exists(chain.mcmc_path)
         dist.barrier()
-        q.put((rank, "ok", out, wrote))
+        # rank 0's chain file unreadable: EVERY rank raises (none is left waiting for rank 0 in a broadcast)
+        if rank == 0:
+            with open(chain.mcmc_path, "wb") as f:
+                f.write(b"not a pickle")
+        dist.barrier()
+        try:
+            chain.run_mcmc(nsteps=3, nburnsteps=4, nwalkers=32, seed=9, status=100)
+            refused = None
+        except RuntimeError as e:
+            refused = str(e)
+        dist.barrier()
+        q.put((rank, "ok", out, (wrote, refused)))
         dist.destroy_process_group()
     except BaseException:                             # noqa: BLE001
         q.put((rank, "ERROR", traceback.format_exc(), None))
@@ -238,7 +249,8 @@ def test_run_mcmc_walker_sharded_over_two_ranks_is_the_single_gpu_chain(tmp_path
     ref = _mcmc_calls(chain)
     assert ref[0].shape == (32, 4, info["d"]) and ref[1].shape == (32, 6, info["d"])
     for r in range(world):
-        out, wrote = got[r]
+        out, (wrote, refused) = got[r]
         for a, b in zip(out, ref):
             assert np.array_equal(a, b), r
         assert wrote == (r == 0)
+        assert refused is not None and "could not read" in refused, (r, refused)

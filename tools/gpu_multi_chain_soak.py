@@ -24,15 +24,28 @@ def main():
             M = int(rng.integers(3, 71)); P = int(rng.integers(2, min(M, 8) + 1))
             specs.append((int(rng.choice([30, 64, 100, 128, 129, 200, 260])), M, P, ["RBF", "Matern15", "Matern25"][int(rng.integers(0, 3))]))
         W = int(rng.choice([1, 9, 64, 200, 700]))
-        tag = dict(case=c, E=E, D=D, W=W, specs=specs)
+        # one case in five: 20 parameters and parameterTrafoPCA on some of the emulators (their maps in one launch, their cross
+        # kernels grouped by PADDED input count).  The oracle restates no parameter PCA (its parity is G7's): these cases check
+        # the rows outside the box and the bit-identity of the three forms only
+        flags = [False] * E
+        if rng.random() < 0.2:
+            D = 20
+            flags = [bool(rng.random() < 0.7) for _ in range(E)]
+        tag = dict(case=c, E=E, D=D, W=W, specs=specs, mapped=flags)
         with tempfile.TemporaryDirectory() as wd:
             try:
-                chain, emus, info = build_multi_chain(specs, D, workdir=wd)
-                logpost = _oracle_chain(info)
+                chain, emus, info = build_multi_chain(specs, D, workdir=wd, mapped=flags)
                 X = rng.uniform(-0.1, 1.1, size=(W, D)) if rng.random() < 0.6 else np.clip(info["xstar"] + 0.05 * rng.standard_normal((W, D)), 0.0, 1.0)
-                got = np.asarray(chain.log_posterior(X)); ref = logpost(X)
-                fin = np.isfinite(ref)
-                if not np.array_equal(np.isneginf(got), ~fin):
+                got = np.asarray(chain.log_posterior(X))
+                if any(flags):
+                    ins = np.all((X > 0.0) & (X < 1.0), axis=1)
+                    ref, inside, fin = None, ins, np.zeros(W, dtype=bool)
+                    if not np.all(np.isfinite(got[ins])):
+                        bad.append(dict(tag, err="non-finite log-posterior inside the box")); print(json.dumps(bad[-1]), flush=True)
+                else:
+                    ref = _oracle_chain(info)(X)
+                    inside = fin = np.isfinite(ref)
+                if not np.array_equal(np.isneginf(got), ~inside):
                     bad.append(dict(tag, err="rows outside the box differ")); print(json.dumps(bad[-1]), flush=True)
                 if fin.any():
                     e = float(np.max(np.abs(got[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1.0)))
