@@ -431,6 +431,63 @@ class Emulator:
             self.gps = [FittedGP(self, i) for i in range(self._ngp)]
 
     # ------------------------------------------------------------------ prediction
+    def print_learning_curve(self):
+        """Learning curves of the GPs over the principal components (src/emulator.py:424-462): sklearn's `learning_curve` — five
+        unshuffled folds (sk:model_selection/_split.py KFold), training sets of 0.2 / 0.4 / 0.6 / 0.8 / 0.9 of a fold's training
+        events (the first n of them), scored by R^2 on those events and on the held-out fold — over fits of
+        `GPR(1. * RBF(ptp, ptp x (.01, 100)) + WhiteKernel(.01**2, (.001**2, 1)), alpha=0.)`.  Returns, per GP, the table
+        [train size, mean train score, mean test score].  The reference runs the 25 hyper-parameter searches of every GP one
+        after the other; here the five folds of one train size (same padded size) and all GPs are ONE lock-step batch on the
+        device.  The reference refits `self.scaler` / `self.pca` on all events as a side effect; the drop-in works on copies and
+        leaves a trained emulator as it is."""
+        S = Standardizer().fit_transform(self.model_data)
+        Z = WhitenedPCA().fit_transform(S)[:, :self.npc]
+        X = np.ascontiguousarray(self.PCA_new_design_points if self.parameterTrafoPCA_ else self.design_points, dtype=np.float64)
+        ptp = self.design_max - self.design_min
+        d, P, n = ptp.shape[0], Z.shape[1], X.shape[0]
+        theta0 = np.concatenate([[0.0], np.log(ptp), [np.log(.01 ** 2)]])
+        bounds = np.empty((d + 2, 2))
+        bounds[0] = np.log([1e-5, 1e5])                   # the constant kernel's default bounds
+        bounds[1:1 + d] = np.log(np.outer(ptp, (.01, 100)))
+        bounds[d + 1] = np.log([.001 ** 2, 1])
+        nfold = 5
+        if n < nfold:
+            raise ValueError("Cannot have number of splits n_splits=%d greater than the number of samples: n_samples=%d." % (nfold, n))
+        fold_sizes = np.full(nfold, n // nfold)
+        fold_sizes[:n % nfold] += 1
+        stops = np.cumsum(fold_sizes)
+        folds = [(np.r_[0:b - m, b:n], np.arange(b - m, b)) for b, m in zip(stops, fold_sizes)]       # (train, test), in order
+        n_max = len(folds[0][0])
+        sizes = np.unique(np.clip((np.array([0.2, 0.4, 0.6, 0.8, 0.9]) * n_max).astype(int), 1, n_max))
+        r2 = lambda y, m: 1.0 - ((y - m) ** 2).sum(0) / ((y - y.mean(0)) ** 2).sum(0)
+        train = np.empty((len(sizes), nfold, P))
+        test = np.empty_like(train)
+        for si, m in enumerate(sizes):
+            rows = [tr[:m] for tr, _ in folds]
+            # the searches of all folds and GPs at this size: virtual GP f * P + i = fold f, GP i
+            se = _SearchEngine(self.device, [X[r] for r in rows for _ in range(P)], [Z[r, i] for r in rows for i in range(P)],
+                               "RBF", 0.0)
+            thetas, _ = search_hyperparameters(lambda idx: se, nfold * P, theta0, bounds, 0, close=True)
+            for f, (r, (_, te)) in enumerate(zip(rows, folds)):
+                eng = GPEngine(self.device)
+                try:
+                    eng.set_data(X[r], Z[r].T, "RBF", 0.0)
+                    eng.set_theta(thetas[f * P:(f + 1) * P])
+                    eng.factor()
+                    train[si, f] = r2(Z[r], eng.predict(X[r], return_var=False))
+                    test[si, f] = r2(Z[te], eng.predict(X[te], return_var=False))
+                finally:
+                    eng.close()
+        trainStatus = []
+        for i in range(P):
+            trainStatus.append(np.array([sizes, train[:, :, i].mean(1), test[:, :, i].mean(1)]).transpose())
+            log.info("GP %d:", i)
+            for m, a, b in zip(sizes, train[:, :, i], test[:, :, i]):
+                log.info("%d samples were used to train the model", m)
+                log.info("The average train accuracy is %.2f", a.mean())
+                log.info("The average test accuracy is %.2f", b.mean())
+        return trainStatus
+
     def _map_parameters(self, X):
         return self._ppca.transform(X) if self.parameterTrafoPCA_ else X
 

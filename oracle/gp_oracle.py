@@ -186,6 +186,38 @@ def gp_fit_theta(X, z, theta0, bounds, kind=KIND_RBF, alpha=0.1):
     return res.x, -res.fun
 
 
+def learning_curve(X, Z, design_min, design_max):
+    """`Emulator.print_learning_curve` (src/emulator.py:424-462) for the GP targets Z[N, npc] over the design X[N, d]: sklearn's
+    `learning_curve` with its defaults — KFold(5) without shuffling (contiguous test blocks, the first N % 5 one longer), train
+    sizes (0.2, 0.4, 0.6, 0.8, 0.9) x the first fold's training count truncated to int, the FIRST n training events of a fold —
+    over GPR(1. * RBF(ptp, ptp x (.01, 100)) + WhiteKernel(.01**2, (.001**2, 1)), alpha=0.) fits (one L-BFGS-B search each),
+    scored by R^2 (GPR.score) on the n training events and on the held-out fold.  Returns [npc, sizes, (n, mean train, mean test)]."""
+    X, Z = np.asarray(X, float), np.asarray(Z, float)
+    N, d = X.shape
+    ptp = np.asarray(design_max, float) - np.asarray(design_min, float)
+    theta0 = np.concatenate([[0.0], np.log(ptp), [math.log(.01 ** 2)]])
+    bounds = np.vstack([np.log([[1e-5, 1e5]]), np.log(np.outer(ptp, (.01, 100))), np.log([[.001 ** 2, 1]])])
+    fold = np.full(5, N // 5)
+    fold[:N % 5] += 1
+    stops = np.cumsum(fold)
+    folds = [(np.r_[0:b - m, b:N], np.arange(b - m, b)) for b, m in zip(stops, fold)]
+    n_max = len(folds[0][0])
+    sizes = np.unique(np.clip((np.array([0.2, 0.4, 0.6, 0.8, 0.9]) * n_max).astype(int), 1, n_max))
+    r2 = lambda y, m: 1.0 - ((y - m) ** 2).sum() / ((y - y.mean()) ** 2).sum()
+    out = np.empty((Z.shape[1], len(sizes), 3))
+    for i in range(Z.shape[1]):
+        for si, n in enumerate(sizes):
+            tr_s, te_s = [], []
+            for tr, te in folds:
+                r = tr[:n]
+                th, _ = gp_fit_theta(X[r], Z[r, i], theta0, bounds, KIND_RBF, 0.0)
+                L, a = gp_factor(X[r], Z[r, i], th, KIND_RBF, 0.0)
+                tr_s.append(r2(Z[r, i], kernel_cross(X[r], X[r], th) @ a))
+                te_s.append(r2(Z[te, i], kernel_cross(X[te], X[r], th) @ a))
+            out[i, si] = n, np.mean(tr_s), np.mean(te_s)
+    return out
+
+
 # --------------------------------------------------------------------------- GP predict
 def prior_var(theta, d):
     """diag k(x*,x*) for the composite kernel: c*1 + sigma_n^2 (White adds on the

@@ -168,3 +168,16 @@ def test_g8_holdout_split(name):
     z = g["y_train"].T
     r2 = 1.0 - ((z - m) ** 2).sum(0) / ((z - z.mean(0)) ** 2).sum(0)
     assert np.max(np.abs(r2 - g["gp_score"])) < 1e-11
+
+
+def test_g10_learning_curve():
+    """`Emulator.print_learning_curve` (src/emulator.py:424-462): the oracle's restatement of sklearn's learning_curve over the
+    reference's GPR fits against the reference's own table.  The scores hang on where 50 L-BFGS-B searches end (the same scipy
+    routine on the same objective): the bar is the optimiser's tolerance carried into R^2."""
+    g = golden("g10_learning_curve.npz")
+    mean, scale, _ = O.standardize_fit(g["Y"])
+    Z, _, _, _ = O.pca_whiten_fit((g["Y"] - mean) / scale)
+    got = O.learning_curve(g["X"], Z[:, :int(g["npc"])], g["lo"], g["hi"])
+    ref = g["status"]
+    assert got.shape == ref.shape and np.array_equal(got[:, :, 0], ref[:, :, 0])
+    assert np.max(np.abs(got[:, :, 1:] - ref[:, :, 1:])) < 1e-5

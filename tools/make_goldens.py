@@ -366,6 +366,23 @@ def g9_loading(Emulator):
     np.savez_compressed(os.path.join(OUT, "g9_loading.npz"), **out)
 
 
+def g10_learning_curve(Emulator):
+    """`Emulator.print_learning_curve` (src/emulator.py:424-462): sklearn's learning_curve (5 unshuffled folds, train sizes 0.2 .. 0.9
+    of a fold's training set) over GPR(1. * RBF(ptp, ptp x (.01, 100)) + White(1e-4, (1e-6, 1)), alpha = 0) fits of every principal
+    component — 25 hyper-parameter searches per GP.  Stored: the inputs and the returned [train size, mean train R^2, mean test R^2]
+    tables, plus the scaler / PCA state the call leaves behind (it refits both on ALL events)."""
+    N, d, M, npc = 60, 3, 5, 2
+    lo, hi, X, Y, Yerr = _make_inputs("learning_curve", N, d, M, 1000)
+    tp = os.path.join(_work, "lc_train.pkl")
+    pf = os.path.join(_work, "lc_par.txt")
+    synth.write_training_pickle(tp, X, Y, Yerr)
+    synth.write_parameter_file(pf, lo, hi)
+    emu = Emulator(training_set_path=tp, parameter_file=pf, npc=npc)
+    status = emu.print_learning_curve()
+    np.savez_compressed(os.path.join(OUT, "g10_learning_curve.npz"), lo=lo, hi=hi, X=X, Y=Y, Yerr=Yerr, npc=npc,
+                        status=np.array(status), scaler_mean=emu.scaler.mean_, pca_components=emu.pca.components_[:npc])
+
+
 def g6_mvn(mcmc):
     rng = np.random.default_rng(600)
     out = {}
@@ -392,6 +409,7 @@ def main():
     g7_param_pca(Emulator)
     g8_holdout(Emulator)
     g9_loading(Emulator)
+    g10_learning_curve(Emulator)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
