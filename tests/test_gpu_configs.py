@@ -61,6 +61,16 @@ def test_cfg2_predict_10000_points_with_covariance(tmp_path):
     gm_ref, gv_ref = oe.gp_predict(Xs[rows])
     assert maxrel(gm[rows], gm_ref) < 1e-11 and relerr(gv[rows], gv_ref) < 1e-10
     assert np.all(gv > 0)
+    # the host-to-host call (numpy in, page-locked numpy out) gives the bits of the device-resident one (torch in, torch out)
+    import torch
+    md, cd = emu._engine_ready().emu_predict(torch.as_tensor(Xs, device="cuda"), True, 0.0)
+    assert np.array_equal(md.cpu().numpy(), mean) and np.array_equal(cd.cpu().numpy(), cov)
+    del md, cd
+    es_all = np.linspace(0.0, 0.3, 10000)                    # ... and with a per-row extra_std
+    m3, c3 = emu.predict(Xs, return_cov=True, extra_std=es_all)
+    _, c3_ref = oe.predict(Xs[rows], True, es_all[rows])
+    assert np.array_equal(m3, mean) and maxrel(c3[rows], c3_ref) < 1e-10
+    del m3, c3
     # mean-only call and a non-zero extra_std
     assert np.array_equal(emu.predict(Xs[:300], return_cov=False), mean[:300])
     es = np.linspace(0.0, 0.3, 64)
