@@ -187,6 +187,90 @@ class Emulator:
             self.paramTrafoScaler_shear, self.paramTrafoPCA_shear = shear.scaler, shear.pca
             self.paramTrafoScaler_yloss, self.paramTrafoPCA_yloss = yloss.scaler, yloss.pca
 
+    @classmethod
+    def from_reference(cls, ref, device=0):
+        """Take over a TRAINED emulator object of the reference (`src.emulator.Emulator` after `trainEmulator`: what the dill
+        pickles of examples/EmulatorTraining.ipynb hold and `Chain.loadEmulator` reads, src/mcmc.py:145-150) without retraining:
+        its fitted scaler and PCA, the GPs' training inputs, targets and hyper-parameters (`gp.X_train_`, `gp.y_train_`,
+        `gp.kernel_.theta`, `gp.alpha`: sk:_gpr.py:260-364), its flags and — with parameterTrafoPCA — its three fitted parameter
+        maps go into a drop-in `Emulator`; the factorisation is redone on the device at first use.  Nothing of `ref` is called:
+        attributes are read (duck-typed), so the reference package is needed only to unpickle `ref`.  Raises ValueError for an
+        object that is not a trained emulator of that kind (an `EmulatorBAND`, a kernel outside RBF / Matern-3/2 / 5/2, GPs
+        over different inputs)."""
+        gps = list(getattr(ref, "gps", None) or [])
+        if not gps or not all(hasattr(g, "kernel_") and hasattr(g, "X_train_") and hasattr(g, "y_train_") for g in gps):
+            raise ValueError("from_reference: not a trained emulator with scikit-learn GPs (`gps[i].kernel_`, `X_train_`, `y_train_`)")
+
+        def family(g):
+            try:
+                inner, white = g.kernel_.k1.k2, g.kernel_.k2
+                name = type(inner).__name__
+                if type(white).__name__ != "WhiteKernel" or type(g.kernel_.k1.k1).__name__ != "ConstantKernel":
+                    raise AttributeError
+            except AttributeError:
+                raise ValueError("from_reference: kernel is not `c * RBF|Matern(length_scale) + WhiteKernel`") from None
+            if name == "RBF":
+                return "RBF"
+            if name == "Matern" and float(inner.nu) in (1.5, 2.5):
+                return "Matern" if float(inner.nu) == 1.5 else "Matern25"
+            raise ValueError("from_reference: kernel family %s is not RBF / Matern-3/2 / Matern-5/2" % name)
+
+        kinds = {family(g) for g in gps}
+        X = np.ascontiguousarray(gps[0].X_train_, dtype=np.float64)
+        if len(kinds) != 1 or len({float(g.alpha) for g in gps}) != 1 or \
+                any(np.shape(g.X_train_) != X.shape or not np.array_equal(g.X_train_, X) for g in gps[1:]):
+            raise ValueError("from_reference: the GPs differ in kernel family, alpha or training inputs")
+        thetas = np.array([np.asarray(g.kernel_.theta, dtype=np.float64) for g in gps])
+        if thetas.shape != (len(gps), X.shape[1] + 2):
+            raise ValueError("from_reference: kernel_.theta is not [log c, log l_1..d, log noise] (anisotropic length scales expected)")
+        emu = cls.__new__(cls)
+        emu.logTrafo_ = bool(getattr(ref, "logTrafo_", False))
+        emu.parameterTrafoPCA_ = bool(getattr(ref, "parameterTrafoPCA_", False))
+        emu.max_rel_uncertainty_data_ = getattr(ref, "max_rel_uncertainty_data_", 0.1)
+        emu.exp_and_cov_diagonal_ = bool(getattr(ref, "exp_and_cov_diagonal_", False))
+        emu.perform_no_PCA_ = bool(getattr(ref, "perform_no_PCA_", False))
+        emu.pardict = getattr(ref, "pardict", None)
+        emu.design_min, emu.design_max = np.array(ref.design_min, dtype=np.float64), np.array(ref.design_max, dtype=np.float64)
+        emu.design_points = np.array(ref.design_points, dtype=np.float64)
+        emu.design_points_org_ = np.array(getattr(ref, "design_points_org_", ref.design_points), dtype=np.float64)
+        emu.model_data = np.array(ref.model_data, dtype=np.float64)
+        emu.model_data_err = np.array(getattr(ref, "model_data_err", np.zeros_like(emu.model_data)), dtype=np.float64)
+        emu.npc, emu.nrestarts = int(ref.npc), int(getattr(ref, "nrestarts", 0))
+        emu.nev, emu.nobs = emu.model_data.shape
+        emu.scaler, emu.pca = Standardizer(), WhitenedPCA()
+        for name in ("mean_", "scale_", "var_"):
+            setattr(emu.scaler, name, np.array(getattr(ref.scaler, name), dtype=np.float64))
+        if not emu.perform_no_PCA_:
+            for name in ("mean_", "components_", "explained_variance_", "explained_variance_ratio_"):
+                setattr(emu.pca, name, np.array(getattr(ref.pca, name), dtype=np.float64))
+            emu.pca.n_components_ = int(ref.pca.n_components_)
+        emu.device, emu.alpha = device, float(gps[0].alpha)
+        emu._engine, emu._like_key, emu.fit_sharding = None, None, None
+        if emu.parameterTrafoPCA_:
+            from . import param_pca as _pp
+            emu._ppca = _pp.ParameterPCA.from_fitted(
+                [(ref.paramTrafoScaler_bulk, ref.paramTrafoPCA_bulk), (ref.paramTrafoScaler_shear, ref.paramTrafoPCA_shear),
+                 (ref.paramTrafoScaler_yloss, ref.paramTrafoPCA_yloss)], ref.PCA_new_design_points, emu.design_min, emu.design_max)
+            emu.PCA_new_design_points = emu._ppca.new_design_points
+            emu.targetVariance = getattr(ref, "targetVariance", _pp.TARGET_VARIANCE)
+            bulk, shear, yloss = emu._ppca.groups
+            emu.indices_zeta_s_parameters = list(_pp.IDX_BULK)
+            emu.indices_eta_s_parameters = list(_pp.IDX_SHEAR)
+            emu.indices_yloss_parameters = list(_pp.IDX_YLOSS)
+            emu.paramTrafoScaler_bulk, emu.paramTrafoPCA_bulk = bulk.scaler, bulk.pca
+            emu.paramTrafoScaler_shear, emu.paramTrafoPCA_shear = shear.scaler, shear.pca
+            emu.paramTrafoScaler_yloss, emu.paramTrafoPCA_yloss = yloss.scaler, yloss.pca
+        emu._X_train = X
+        emu._Z_train = np.ascontiguousarray([np.asarray(g.y_train_, dtype=np.float64).reshape(-1) for g in gps])
+        emu.kernel_type_, emu._ngp = kinds.pop(), len(gps)
+        emu.thetas_ = thetas
+        emu.lml_ = np.array([float(getattr(g, "log_marginal_likelihood_value_", np.nan)) for g in gps])
+        emu._state_serial = next(_STATE_SERIAL)
+        emu._build_transform()
+        emu._trained = True
+        emu.gps = [FittedGP(emu, i) for i in range(emu._ngp)]
+        return emu
+
     # scalar forms of the parametrised functions behind parameterTrafoPCA (src/emulator.py:102-126)
     def parametrization_zeta_over_s_vs_T(self, zeta_max, T_zeta0, sigma_plus, sigma_minus, T, mu_B):
         from .param_pca import zeta_over_s

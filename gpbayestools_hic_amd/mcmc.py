@@ -134,11 +134,23 @@ class Chain:
             h.update(repr(a.shape).encode()); h.update(a.tobytes())
         return h.digest()
 
-    def loadEmulator(self, emulatorPathList):
+    def loadEmulator(self, emulatorPathList, adopt=True):
+        """src/mcmc.py:145-150.  A pickle that holds a trained emulator of the REFERENCE (its `src.emulator.Emulator` with
+        scikit-learn GPs inside: what EmulatorTraining.ipynb dumps) is taken over onto the device without retraining
+        (Emulator.from_reference) unless adopt=False; anything else with the predict protocol stays a foreign emulator
+        (host predictions, device likelihood)."""
         import dill
+        from .emulator import Emulator
         for path in emulatorPathList:
             with open(path, "rb") as f:
-                self.emuList.append(dill.load(f))
+                emu = dill.load(f)
+            if adopt and not isinstance(emu, Emulator) and getattr(emu, "gps", None) and hasattr(emu, "scaler"):
+                try:
+                    emu = Emulator.from_reference(emu, device=self.device)
+                    log.info("%s: a trained emulator of the reference, taken over onto device %s", path, self.device)
+                except ValueError as e:
+                    log.info("%s: kept as a foreign emulator (%s)", path, e)
+            self.emuList.append(emu)
         log.info("Number of Emulators: %d", len(self.emuList))
 
     def random_pos(self, n=1):

@@ -85,6 +85,25 @@ class ParameterPCA:
         self.design_min, self.design_max = dmin, dmax
         self.n_components = [g.pca.n_components_ for g in self.groups]
 
+    @classmethod
+    def from_fitted(cls, fitted, new_design_points, design_min, design_max):
+        """The map as ANOTHER object fitted it: `fitted` = [(scaler, pca)] of the bulk, shear and y-loss groups (anything with
+        sklearn's attributes: scaler.mean_ / scale_ / var_, pca.mean_ / components_ / explained_variance_ /
+        explained_variance_ratio_ / n_components_) — a trained emulator of the reference taken over without refitting
+        (Emulator.from_reference)."""
+        self = cls.__new__(cls)
+        self.groups = [_Group(IDX_BULK, zeta_over_s), _Group(IDX_SHEAR, eta_over_s), _Group(IDX_YLOSS, y_loss)]
+        for g, (sc, pc) in zip(self.groups, fitted):
+            for name in ("mean_", "scale_", "var_"):
+                setattr(g.scaler, name, np.array(getattr(sc, name), dtype=np.float64))
+            for name in ("mean_", "components_", "explained_variance_", "explained_variance_ratio_"):
+                setattr(g.pca, name, np.array(getattr(pc, name), dtype=np.float64))
+            g.pca.n_components_ = int(pc.n_components_)
+        self.new_design_points = np.array(new_design_points, dtype=np.float64)
+        self.design_min, self.design_max = np.array(design_min, dtype=np.float64), np.array(design_max, dtype=np.float64)
+        self.n_components = [g.pca.n_components_ for g in self.groups]
+        return self
+
     def transform(self, X):
         """X[W, ndim_original] -> GP input [W, ndim_reduced]  (src/emulator.py:492-549)"""
         X = np.atleast_2d(np.asarray(X, dtype=np.float64))

@@ -383,6 +383,78 @@ def g10_learning_curve(Emulator):
                         status=np.array(status), scaler_mean=emu.scaler.mean_, pca_components=emu.pca.components_[:npc])
 
 
+def _dump_trained(emu, prefix, out):
+    """the attributes of a TRAINED reference emulator that Emulator.from_reference reads, as plain arrays"""
+    out[prefix + "flags"] = np.array([emu.logTrafo_, emu.parameterTrafoPCA_, emu.exp_and_cov_diagonal_, emu.perform_no_PCA_], dtype=np.int64)
+    out[prefix + "npc"] = emu.npc
+    for name in ("design_points", "model_data", "model_data_err", "design_min", "design_max"):
+        out[prefix + name] = np.array(getattr(emu, name), dtype=np.float64)
+    for name in ("mean_", "scale_", "var_"):
+        out[prefix + "scaler_" + name] = getattr(emu.scaler, name)
+    if not emu.perform_no_PCA_:
+        for name in ("mean_", "components_", "explained_variance_", "explained_variance_ratio_"):
+            out[prefix + "pca_" + name] = getattr(emu.pca, name)
+        out[prefix + "pca_n_components_"] = emu.pca.n_components_
+    g0 = emu.gps[0]
+    out[prefix + "gp_family"] = np.array([type(g0.kernel_.k1.k1).__name__, type(g0.kernel_.k1.k2).__name__, type(g0.kernel_.k2).__name__])
+    out[prefix + "gp_nu"] = float(getattr(g0.kernel_.k1.k2, "nu", 0.0))
+    out[prefix + "gp_alpha"] = float(g0.alpha)
+    out[prefix + "gp_X_train"] = np.array(g0.X_train_)
+    out[prefix + "gp_y_train"] = np.array([gp.y_train_ for gp in emu.gps])
+    out[prefix + "gp_theta"] = np.array([gp.kernel_.theta for gp in emu.gps])
+    out[prefix + "gp_lml"] = np.array([gp.log_marginal_likelihood_value_ for gp in emu.gps])
+    if emu.parameterTrafoPCA_:
+        out[prefix + "PCA_new_design_points"] = emu.PCA_new_design_points
+        for tag in ("bulk", "shear", "yloss"):
+            sc, pc = getattr(emu, "paramTrafoScaler_" + tag), getattr(emu, "paramTrafoPCA_" + tag)
+            for name in ("mean_", "scale_", "var_"):
+                out[prefix + tag + "_scaler_" + name] = getattr(sc, name)
+            for name in ("mean_", "components_", "explained_variance_", "explained_variance_ratio_"):
+                out[prefix + tag + "_pca_" + name] = getattr(pc, name)
+            out[prefix + tag + "_pca_n_components_"] = pc.n_components_
+
+
+def g11_trained_objects(Emulator):
+    """Trained emulator OBJECTS of the reference as its pickles hold them (src/mcmc.py:145-150 loads them): the attributes
+    `Emulator.from_reference` reads — fitted scaler / PCA, flags, the sklearn GPs' X_train_ / y_train_ / kernel_.theta / alpha, the
+    parameter maps — and the object's own predictions, for: PCA + RBF trained on a MASKED event set, log transform +
+    exp_and_cov_diagonal + Matern-3/2, perform_no_PCA, and parameterTrafoPCA."""
+    out = {}
+    cases = (("mask", 64, 6, 5, 3, "RBF", {}), ("logexp", 56, 5, 4, 2, "Matern", dict(logTrafo=True, exp_and_cov_diagonal=True)),
+             ("nopca", 48, 4, 3, 3, "RBF", dict(perform_no_PCA=True)))
+    for ci, (name, N, d, M, npc, ktype, kw) in enumerate(cases):
+        lo, hi, X, Y, Yerr = _make_inputs("trained_" + name, N, d, M, 1100 + 10 * ci)
+        if kw.get("logTrafo"):
+            Y = np.abs(Y) + 0.5
+        tp, pf = os.path.join(_work, f"tr_{name}_train.pkl"), os.path.join(_work, f"tr_{name}_par.txt")
+        synth.write_training_pickle(tp, X, Y, Yerr)
+        synth.write_parameter_file(pf, lo, hi)
+        emu = Emulator(training_set_path=tp, parameter_file=pf, npc=npc, **kw)
+        mask = np.ones(emu.nev, dtype=bool)
+        if name == "mask":
+            mask[[3, 17, 18, 40, 63]] = False
+        emu.trainEmulator(mask, kernel_type=ktype)
+        rng = np.random.default_rng(1150 + ci)
+        Xs = lo + (hi - lo) * rng.random((12, d))
+        es = np.linspace(0.0, 0.2, 12)
+        mean, cov = emu.predict(Xs, return_cov=True, extra_std=es)
+        out[name + "_lo"], out[name + "_hi"], out[name + "_Xs"], out[name + "_es"] = lo, hi, Xs, es
+        out[name + "_mean"], out[name + "_cov"] = mean, cov
+        _dump_trained(emu, name + "_", out)
+    # parameterTrafoPCA (the inputs of g7)
+    g7 = np.load(os.path.join(OUT, "g7_param_pca.npz"))
+    tp, pf = os.path.join(_work, "tr_ppca_train.pkl"), os.path.join(_work, "tr_ppca_par.txt")
+    synth.write_training_pickle(tp, g7["X"], g7["Y"], np.full_like(g7["Y"], 0.01))
+    synth.write_parameter_file(pf, g7["lo"], g7["hi"])
+    emu = Emulator(training_set_path=tp, parameter_file=pf, npc=int(g7["npc"]), parameterTrafoPCA=True)
+    emu.trainEmulatorAutoMask()
+    mean, cov = emu.predict(g7["Xs"], return_cov=True, extra_std=np.zeros(len(g7["Xs"])))
+    out["ppca_lo"], out["ppca_hi"], out["ppca_Xs"], out["ppca_es"] = g7["lo"], g7["hi"], g7["Xs"], np.zeros(len(g7["Xs"]))
+    out["ppca_mean"], out["ppca_cov"] = mean, cov
+    _dump_trained(emu, "ppca_", out)
+    np.savez_compressed(os.path.join(OUT, "g11_trained_objects.npz"), **out)
+
+
 def g6_mvn(mcmc):
     rng = np.random.default_rng(600)
     out = {}
@@ -410,6 +482,7 @@ def main():
     g8_holdout(Emulator)
     g9_loading(Emulator)
     g10_learning_curve(Emulator)
+    g11_trained_objects(Emulator)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
