@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgpbayes.so")
 LIB_DEBUG = os.path.join(HERE, "libgpbayes_debug.so")
-SOURCES = ["gpb_api.hip", "gpb_fit.hip", "gpb_chol.hip", "gpb_predict.hip", "gpb_like.hip", "gpb_cov.hip", "gpb_pmap.hip", "gpb_pool.hip"]
+SOURCES = ["gpb_api.hip", "gpb_fit.hip", "gpb_chol.hip", "gpb_predict.hip", "gpb_sliced.hip", "gpb_like.hip", "gpb_cov.hip", "gpb_pmap.hip", "gpb_pool.hip"]
 HEADERS = ["gpb_internal.h", "gemm_tile.h", "chol_block.h", "fast_math.h", os.path.join("..", "..", "include", "gpbayes.h"),
            os.path.join("..", "..", "include", "gpbayes_debug.h")]
 

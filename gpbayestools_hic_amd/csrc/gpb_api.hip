@@ -142,6 +142,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     if (ctx->h_thblk) (void)hipHostFree(ctx->h_thblk);
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);
     dev_free(&ctx->Z); dev_free(&ctx->K); dev_free(&ctx->Linv); dev_free(&ctx->LinvT); dev_free(&ctx->T); dev_free(&ctx->yv);
+    gpb::sliced_free(ctx);
     dev_free(&ctx->alpha); dev_free(&ctx->apart); dev_free(&ctx->info); dev_free(&ctx->lmlbuf);
     dev_free(&ctx->gpart); dev_free(&ctx->Xs); dev_free(&ctx->estd); dev_free(&ctx->KsT); dev_free(&ctx->mpart);
     dev_free(&ctx->spart); dev_free(&ctx->mean_pc); dev_free(&ctx->var_pc); dev_free(&ctx->out_stage);
@@ -236,6 +237,7 @@ static int gp_set_impl(gpb_ctx* ctx, int64_t P, int64_t d, const int64_t* N_p, c
     if ((rc = dev_alloc(ctx, &ctx->Linv, P * Np * Np))) return rc;
     dev_free(&ctx->LinvT);                             // the k-major copy follows the new shape on its next use
     ctx->linvT_valid = false;
+    gpb::sliced_free(ctx);                             // ... and so do the digit planes
     // zeroed ONCE: the factorisation writes the diagonal blocks (with zeros above the diagonal) and the blocks below
     // them, never the blocks above — and the 128-wide tiles of the predict / K^-1 products read those as zeros
     GPB_HIP(hipMemsetAsync(ctx->Linv, 0, sizeof(double) * P * Np * Np, ctx->stream));
@@ -464,6 +466,10 @@ extern "C" int gpb_gp_get(gpb_ctx* ctx, int what, double* out_host) {
         if (W <= 0 || !ctx->KsT) GPB_FAIL(GPB_E_STATE, "gpb_gp_get(GPB_GET_KSTAR): no batch has been evaluated");
         std::vector<double> tmp((size_t)(N * W));
         for (int64_t p = 0; p < P; ++p) {
+            if (ctx->batch_sliced) {                   // option 51: the batch left k_kcross as int8 digit planes: what they hold
+                const int rc = gpb::sliced_read_kstar(ctx, p, pad, N, W, tmp.data());
+                if (rc) return rc;
+            } else
             GPB_HIP(hipMemcpy2D(tmp.data(), sizeof(double) * W, ctx->KsT + (p * Np + pad) * Wld, sizeof(double) * Wld,
                                 sizeof(double) * W, (size_t)N, hipMemcpyDeviceToHost));
             for (int64_t w = 0; w < W; ++w)
@@ -1150,6 +1156,10 @@ extern "C" int gpb_ctx_option(gpb_ctx* ctx, int key, int value) {
         case 48: if (value < 0 || value > 99) return GPB_E_ARG; ctx->kx_overlap = value; break;
         case 49: if (value < 0 || value > 1) return GPB_E_ARG; ctx->lr_split = value; break;
         case 50: if (value != 0 && value != 64 && value != 128) return GPB_E_ARG; ctx->kinv_tile = value; break;
+        case 51:        // V = L^-1 K*^T on the int8 matrix pipe (gpb_sliced.hip): 0 = never (default), 1 = where the rule admits, 2 = rule off
+            if (value < 0 || value > 2) return GPB_E_ARG;
+            ctx->predict_sliced = value;
+            break;
         case 44: if (value < 0) return GPB_E_ARG; ctx->tile_switch = value > 0 ? value : 960; break;
         case 33: if (value < 0) return GPB_E_ARG; ctx->tile_switch_c = value; break;
         case 34: if (value < 0) return GPB_E_ARG; ctx->mid_switch_c = value; break;

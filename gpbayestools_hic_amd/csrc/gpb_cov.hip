@@ -99,7 +99,9 @@ int launch_predict_cov(gpb_ctx* ctx, const double* Xs_dev, int64_t W, double* co
         GPB_HIP(pool_malloc_t(&ctx->covbuf, need_c * sizeof(double)));
         ctx->covbuf_cap = need_c;
     }
+    ctx->want_kst = true;                                    // (the joint covariance reads the fp64 K*^T itself: no digit planes here)
     int rc = launch_predict(ctx, Xs_dev, W, false);          // K*^T and the mean
+    ctx->want_kst = false;
     if (rc) return rc;
     dim3 gv((unsigned)(Wc / 128), (unsigned)((Np + 127) / 128), (unsigned)P);
     hipLaunchKernelGGL(k_vmat, gv, dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT, ctx->vbuf, Np, Wld);

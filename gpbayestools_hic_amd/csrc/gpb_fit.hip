@@ -578,6 +578,7 @@ __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict
 int launch_trtri(gpb_ctx* ctx) {
     const int64_t Np = ctx->Np;
     ctx->linvT_valid = false;                          // the k-major copy (LDS-DMA predict tiles) is rebuilt on its next use
+    ctx->slA_valid = false;                            // the digit planes of L^-1 (gpb_sliced.hip) likewise
     for (int64_t hs = 64; hs < Np; hs *= 2) {
         const int ngroups = (int)((Np + 2 * hs - 1) / (2 * hs));
         // 64-wide tiles while 128-wide ones would leave the chip underfilled or badly quantised (measured faster up

@@ -85,6 +85,16 @@ struct gpb_ctx {
     double* Linv = nullptr;        // [P][Np][Np]
     double* LinvT = nullptr;       // [P][Np][Np] k-major copy (LinvT[k][m] = Linv[m][k]) for the LDS-DMA predict tiles, made on first use
     bool linvT_valid = false;      // ... cleared by every factorisation
+    // sliced-integer predict (gpb_sliced.hip, option key 51): int8 digit planes of L^-1 (made on first use after a factorisation)
+    // and of the current K*^T batch, row / column scales
+    int predict_sliced = 0;        // 0 = fp64 kernel always; 1 = the int8 kernel where its rule admits the context; 2 = rule off (tests)
+    int8_t* slA = nullptr;         // [P][6][Np/16][Np128][16]
+    int8_t* slB = nullptr;         // [P][6][Np/16][Wcap][16] (leading dimension of a batch: Wld)
+    double* sl_scale = nullptr;    // rowscale [P][Np128] | colscale [P] | rowexp (int) [P][Np128]
+    bool slA_valid = false;
+    int64_t slB_cap = 0;
+    bool batch_sliced = false;     // the current batch's K*^T exists as digit planes (launch_kcross), not as fp64
+    bool want_kst = false;         // the caller of launch_kcross needs the fp64 K*^T itself (joint covariance)
     int predict_dma = 0;           // tune key 41: the 64-row predict tiles stage their operands by LDS-DMA (k_predict_static_dma)
     double* T = nullptr;           // [P][Np][Np]  workspace (trtri / K^-1)
     double* yv = nullptr;          // [P][Np]      L^-1 z
@@ -265,7 +275,7 @@ int ensure_wcap(gpb_ctx* ctx, int64_t W);
 int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var, bool finalize = true,
                    const int* nrows_dev = nullptr);
 // its three phases, for callers that batch the middle one over several contexts (chains of emulators)
-int launch_kcross(gpb_ctx* ctx, const double* Xs_dev, int64_t W, const int* nrows_dev);
+int launch_kcross(gpb_ctx* ctx, const double* Xs_dev, int64_t W, const int* nrows_dev, bool allow_planes = true);
 int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, int64_t W, const int* nrows_dev);
 int launch_param_maps(gpb_ctx* const* ctxs, int n, const double* X_dev, int64_t W);      // gpb_pmap.hip
 // p0s / p1s (optional): the launch covers GPs [p0s[e], p1s[e]) of context e instead of all of them (the shared-launch kernels with a
@@ -276,6 +286,13 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, con
 int launch_kcross_ranges(gpb_ctx* const* ctxs, const double* const* Xs, int E, const int* p0s, const int* p1s, int64_t W,
                          const int* nrows_dev, hipStream_t stream);
 int launch_finalize(gpb_ctx* ctx, int64_t W, bool need_var);
+// gpb_sliced.hip: the int8 form of launch_vsq's 128 x 128 launch for ONE context (rule: sliced_applies)
+bool sliced_applies(const gpb_ctx* ctx);
+int sliced_prepare(gpb_ctx* ctx);                    // buffers, and the planes of L^-1 after a new factorisation
+const double* sliced_colscale(const gpb_ctx* ctx);   // device [P]: the power-of-two scale of each GP's K*^T digits
+int launch_vsq_sliced(gpb_ctx* ctx, int64_t W, const int* nrows_dev, int kskip);
+void sliced_free(gpb_ctx* ctx);
+int sliced_read_kstar(gpb_ctx* ctx, int64_t p, int64_t pad, int64_t N, int64_t W, double* out);
 constexpr int GPB_MAX_MULTI_GP = 96;      // GPs one batched launch can address (its table is a kernel argument)
 int launch_predict_cov(gpb_ctx* ctx, const double* Xs_dev, int64_t W, double* cov_dev);
 // likelihood (gpb_like.hip)

@@ -57,14 +57,19 @@ struct KxLds {
     double sal[KX_CHUNK];
 };
 
-template <int KIND, int DPAD, bool DOT, int WPL>
+// SLICE (option key 51, gpb_sliced.hip): K*^T leaves the kernel as the six int8 digit planes the int8 predict kernel reads —
+// plane[p][t][k / 16][walker][16 bytes] — instead of fp64 (6 bytes per element instead of 8, no second pass over the batch).  A
+// wave then owns 16 CONSECUTIVE design points of the chunk (one 16-byte granule per plane and walker) instead of every fourth,
+// so the four mean partials of a chunk group the points differently: the mean's last bits differ from the fp64 form's.
+template <int KIND, int DPAD, bool DOT, int WPL, bool SLICE = false>
 __device__ __forceinline__ void kcross_body(KxLds<DPAD, WPL>& L, const double* __restrict__ Xs, int64_t W, int d,
                                             const double* __restrict__ Xsc, const double* __restrict__ ls,
                                             const double* __restrict__ amp, const double* __restrict__ alpha,
                                             double* __restrict__ KsT, double* __restrict__ mpart, int64_t N, int64_t Np,
                                             int64_t Wld, int P, const double* __restrict__ dnorm,
                                             const double* __restrict__ muS, int chunks_per_wg,
-                                            const int* __restrict__ nrows, const int p) {
+                                            const int* __restrict__ nrows, const int p,
+                                            int8_t* __restrict__ planes = nullptr, const double* __restrict__ colscale = nullptr) {
     constexpr int WT = 64 * WPL;                        // walkers per workgroup: lane l holds walkers l, l + 64, ...
     // compacted batches (gpb_logpost): only the first *nrows rows (those inside the prior box) exist; the launch
     // geometry was sized for the whole batch and the workgroups beyond them leave at once
@@ -145,6 +150,9 @@ __device__ __forceinline__ void kcross_body(KxLds<DPAD, WPL>& L, const double* _
     }
     const double c = amp[p];
     double* Kp = KsT + (int64_t)p * Np * Wld;
+    // SLICE: x 2^47 / 2^e_c and + 2^52 leave the rounded 47-bit integer in the mantissa (K* in [0, c] <= 0.99 2^e_c)
+    const double slice_sc = SLICE ? 140737488355328.0 / colscale[p] : 0.0;
+    const int64_t plane_sz = (Np / 16) * Wld * 16;
     for (int64_t chunk = chunk0; chunk < chunk1; ++chunk) {
         const int64_t nbeg = chunk * KX_CHUNK;
         __syncthreads();                                // the walker tile / the previous chunk's rows are done with
@@ -162,8 +170,18 @@ __device__ __forceinline__ void kcross_body(KxLds<DPAD, WPL>& L, const double* _
         double msum[WPL];
 #pragma unroll
         for (int u = 0; u < WPL; ++u) msum[u] = 0.0;
+        unsigned pw[SLICE ? WPL : 1][SLICE ? 6 : 1][SLICE ? 4 : 1];     // SLICE: this wave's granule of every plane, per walker
+        if (SLICE) {
+#pragma unroll
+            for (int u = 0; u < WPL; ++u)
+#pragma unroll
+                for (int tp = 0; tp < 6; ++tp)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) pw[u][tp][g] = 0u;
+        }
+#pragma unroll(SLICE ? KX_CHUNK / 4 : 1)
         for (int t = 0; t < KX_CHUNK / 4; ++t) {
-            const int pt = wave + 4 * t;                // wave-uniform
+            const int pt = SLICE ? 16 * wave + t : wave + 4 * t;      // wave-uniform
             const int64_t n = nbeg + pt;
             double kv[WPL];
 #pragma unroll
@@ -203,8 +221,28 @@ __device__ __forceinline__ void kcross_body(KxLds<DPAD, WPL>& L, const double* _
                     msum[u] = fma(sal[pt], kv[u], msum[u]);
                 }
             }
+            if (SLICE) {
 #pragma unroll
-            for (int u = 0; u < WPL; ++u) GPB_KSTAR_STORE(&Kp[n * Wld + w0 + lane + 64 * u], kv[u]);
+                for (int u = 0; u < WPL; ++u) {
+                    // the six signed radix-256 digits: bytes of (a + 0x808080808080) ^ 0x808080808080, byte t & 3 of word t >> 2
+                    const unsigned long long a = (unsigned long long)__double_as_longlong(fma(kv[u], slice_sc, 4503599627370496.0)) & 0xfffffffffffffull;
+                    const unsigned long long dg = (a + 0x808080808080ull) ^ 0x808080808080ull;
+#pragma unroll
+                    for (int tp = 0; tp < 6; ++tp)
+                        pw[u][tp][t >> 2] |= (unsigned)((dg >> (8 * tp)) & 0xffull) << (8 * (t & 3));
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < WPL; ++u) GPB_KSTAR_STORE(&Kp[n * Wld + w0 + lane + 64 * u], kv[u]);
+            }
+        }
+        if (SLICE) {
+            int8_t* dst = planes + (int64_t)p * 6 * plane_sz + ((chunk * 4 + wave) * Wld + w0 + lane) * 16;
+#pragma unroll
+            for (int u = 0; u < WPL; ++u)
+#pragma unroll
+                for (int tp = 0; tp < 6; ++tp)
+                    *reinterpret_cast<uint4*>(dst + tp * plane_sz + (int64_t)u * 64 * 16) = make_uint4(pw[u][tp][0], pw[u][tp][1], pw[u][tp][2], pw[u][tp][3]);
         }
         // red: written here, read by wave 0 below; the next write is behind the two barriers at the top of the loop
 #pragma unroll
@@ -220,7 +258,7 @@ __device__ __forceinline__ void kcross_body(KxLds<DPAD, WPL>& L, const double* _
     }
 }
 
-template <int KIND, int DPAD, bool DOT, int WPL>
+template <int KIND, int DPAD, bool DOT, int WPL, bool SLICE = false>
 __global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, int64_t W, int d,
                                                 const double* __restrict__ Xsc, const double* __restrict__ ls,
                                                 const double* __restrict__ amp, const double* __restrict__ alpha,
@@ -228,13 +266,14 @@ __global__ __launch_bounds__(256) void k_kcross(const double* __restrict__ Xs, i
                                                 int64_t N, int64_t Np, int64_t Wld, int P,
                                                 const double* __restrict__ dnorm, const double* __restrict__ muS,
                                                 int chunks_per_wg, const int* __restrict__ nrows,
-                                                const int* __restrict__ form) {
+                                                const int* __restrict__ form, int8_t* __restrict__ planes = nullptr,
+                                                const double* __restrict__ colscale = nullptr) {
     // form (optional): the per-GP distance form (gpb_ctx::gpform); this launch computes the GPs of ITS form, the workgroups
     // of the others leave at once (their launch is the other instantiation, on the same stream)
     if (form && form[blockIdx.y] != (DOT ? 0 : 1)) return;
     __shared__ KxLds<DPAD, WPL> lds;
-    kcross_body<KIND, DPAD, DOT, WPL>(lds, Xs, W, d, Xsc, ls, amp, alpha, KsT, mpart, N, Np, Wld, P, dnorm, muS,
-                                      chunks_per_wg, nrows, (int)blockIdx.y);
+    kcross_body<KIND, DPAD, DOT, WPL, SLICE>(lds, Xs, W, d, Xsc, ls, amp, alpha, KsT, mpart, N, Np, Wld, P, dnorm, muS,
+                                             chunks_per_wg, nrows, (int)blockIdx.y, planes, colscale);
 }
 
 // The cross kernels of ALL emulators of a chain in one launch (round 3): grid.y runs over the GPs of every emulator of the
@@ -1039,7 +1078,7 @@ int ensure_wcap(gpb_ctx* ctx, int64_t W) {
 }
 
 template <int KIND>
-static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int64_t Wuse, const int* nrows_dev) {
+static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int64_t Wuse, const int* nrows_dev, bool planes) {
     const int nchunk = (int)((ctx->Np + KX_CHUNK - 1) / KX_CHUNK);
     // chunks per workgroup: as many as still leave >= 4 workgroups per CU (a geometry choice: the per-chunk
     // partials and their order do not depend on it; measured, cfg 4: 1 / 2 / 4 chunks at 512 / 1024 / 2048+ walkers)
@@ -1063,10 +1102,19 @@ static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int
     // choose_forms) and is left out when no GP has it — the usual case is the Gram launch alone, with no form table to read
     const int* form = (ctx->n_diff > 0 && ctx->n_diff < ctx->P) ? ctx->gpform : nullptr;
     const bool gram = ctx->n_diff < ctx->P, diff = ctx->n_diff > 0;
+    int8_t* const slB = planes ? ctx->slB : nullptr;
+    const double* const slcs = planes ? sliced_colscale(ctx) : nullptr;
 #define GPB_KX_LAUNCH(DP, DOT_, WPL_, XD)                                                                         \
-    hipLaunchKernelGGL((k_kcross<KIND, DP, DOT_, WPL_>), grid, dim3(256), 0, ctx->stream, Xs_dev, W, (int)ctx->d, \
-                       XD, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT, ctx->mpart, ctx->N, ctx->Np, ctx->Wld,       \
-                       (int)ctx->P, ctx->dnorm, ctx->muS, cpw, nrows_dev, form)
+    do {                                                                                                          \
+        if (planes)                                                                                               \
+            hipLaunchKernelGGL((k_kcross<KIND, DP, DOT_, WPL_, true>), grid, dim3(256), 0, ctx->stream, Xs_dev, W, (int)ctx->d, \
+                               XD, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT, ctx->mpart, ctx->N, ctx->Np, ctx->Wld,       \
+                               (int)ctx->P, ctx->dnorm, ctx->muS, cpw, nrows_dev, form, slB, slcs);               \
+        else                                                                                                      \
+            hipLaunchKernelGGL((k_kcross<KIND, DP, DOT_, WPL_>), grid, dim3(256), 0, ctx->stream, Xs_dev, W, (int)ctx->d, \
+                               XD, ctx->ls, ctx->amp, ctx->alpha, ctx->KsT, ctx->mpart, ctx->N, ctx->Np, ctx->Wld,       \
+                               (int)ctx->P, ctx->dnorm, ctx->muS, cpw, nrows_dev, form, nullptr, nullptr);        \
+    } while (0)
 #define GPB_KX(DP)                                                                                               \
     do {                                                                                                         \
         if (wpl == 2) {                                                                                          \
@@ -1092,20 +1140,29 @@ static int launch_kcross_kind(gpb_ctx* ctx, const double* Xs_dev, int64_t W, int
 }
 
 // K*^T and the mean partials of a batch: Xs_dev [W][d] on the device.  Sets the leading dimension of the batch's workspaces.
-int launch_kcross(gpb_ctx* ctx, const double* Xs_dev, int64_t W, const int* nrows_dev) {
+int launch_kcross(gpb_ctx* ctx, const double* Xs_dev, int64_t W, const int* nrows_dev, bool allow_planes) {
     if (ctx->multi) GPB_FAIL(GPB_E_STATE, "gpb: a gpb_gp_set_multi context is fit-only (its GPs have different designs)");
     if (!ctx->factored) GPB_FAIL(GPB_E_STATE, "gpb: predict before gpb_gp_factor");
     if (W > ctx->Wcap) GPB_FAIL(GPB_E_STATE, "gpb: internal: W exceeds workspace");
     const int64_t Wuse = round_up(W, WPAD);
+    // option key 51 (gpb_sliced.hip): the batch leaves this kernel as int8 digit planes for the int8 predict kernel — for EVERY
+    // batch size once the rule admits the context (a walker's bits must not depend on the batch it arrives in) — unless the
+    // caller needs K*^T itself (the joint covariance, gpb_gp_get) or shares the predict launch with other contexts
+    const bool planes = allow_planes && !ctx->want_kst && sliced_applies(ctx);
+    ctx->batch_sliced = planes;
+    if (planes) {
+        const int rc = sliced_prepare(ctx);
+        if (rc) return rc;
+    }
     // leading dimension of this batch's workspaces (K*^T, partials, per-GP means / variances): the padded batch, not the
     // capacity — with the capacity left at 4096 by an earlier call a 256-walker batch read its 64-walker tile rows
     // 32 KB apart and k_predict_static ran 13 % slower (117 -> 133 us), k_kcross 24 % (20 -> 25 us)
     ctx->Wld = Wuse;
     ctx->last_W = W;
     int rc;
-    if (ctx->kind == GPB_KERNEL_RBF) rc = launch_kcross_kind<GPB_KERNEL_RBF>(ctx, Xs_dev, W, Wuse, nrows_dev);
-    else if (ctx->kind == GPB_KERNEL_MATERN15) rc = launch_kcross_kind<GPB_KERNEL_MATERN15>(ctx, Xs_dev, W, Wuse, nrows_dev);
-    else rc = launch_kcross_kind<GPB_KERNEL_MATERN25>(ctx, Xs_dev, W, Wuse, nrows_dev);
+    if (ctx->kind == GPB_KERNEL_RBF) rc = launch_kcross_kind<GPB_KERNEL_RBF>(ctx, Xs_dev, W, Wuse, nrows_dev, planes);
+    else if (ctx->kind == GPB_KERNEL_MATERN15) rc = launch_kcross_kind<GPB_KERNEL_MATERN15>(ctx, Xs_dev, W, Wuse, nrows_dev, planes);
+    else rc = launch_kcross_kind<GPB_KERNEL_MATERN25>(ctx, Xs_dev, W, Wuse, nrows_dev, planes);
     if (rc) return rc;
     GPB_HIP(hipGetLastError());
     return 0;
@@ -1122,6 +1179,9 @@ int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, in
         if (ctxs[e]->multi) GPB_FAIL(GPB_E_STATE, "gpb: a gpb_gp_set_multi context is fit-only (its GPs have different designs)");
     for (int e = 0; e < E && ok; ++e)           // (the shared launch is the Gram form's: a context with a difference-form GP takes its own)
         ok = ctxs[e]->n_diff == 0 && ctxs[e]->Np == ctx->Np && ctxs[e]->dpad == ctx->dpad && ctxs[e]->stream == ctx->stream;
+    // option key 51: an emulator's bits must not depend on the company it is evaluated in, so a context the int8 rule admits
+    // takes its own launches (digit planes out, int8 predict kernel: launch_vsq) inside a chain too
+    for (int e = 0; e < E && ok; ++e) ok = !sliced_applies(ctxs[e]);
     if (!ok) {
         for (int e = 0; e < E; ++e) {
             const int rc = launch_kcross(ctxs[e], Xs[e], W, nrows_dev);
@@ -1138,6 +1198,7 @@ int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, in
         if (W > c->Wcap) GPB_FAIL(GPB_E_STATE, "gpb: internal: W exceeds workspace");
         c->Wld = Wuse;
         c->last_W = W;
+        c->batch_sliced = false;
         tab.c[e] = KxCtx{Xs[e], c->Xc, c->ls, c->amp, c->alpha, c->dnorm, c->muS, c->KsT, c->mpart, (int)c->N, (int)c->P,
                          c->kind, G, 0, (int)c->d};
         G += (int)c->P;
@@ -1194,6 +1255,7 @@ int launch_kcross_ranges(gpb_ctx* const* ctxs, const double* const* Xs, int E, c
             GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_kcross_ranges over a context that does not qualify");
         c->Wld = Wuse;
         c->last_W = W;
+        c->batch_sliced = false;
         tab.c[e] = KxCtx{Xs[e], c->Xc, c->ls, c->amp, c->alpha, c->dnorm, c->muS, c->KsT, c->mpart, (int)c->N, (int)c->P,
                          c->kind, G, p0s[e], (int)c->d};
         G += p1s[e] - p0s[e];
@@ -1240,6 +1302,30 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, con
                bool prof_end) {
     gpb_ctx* ctx = ctxs[0];
     const int64_t Wuse = round_up(W, WPAD);
+    if (E > 1) {
+        // option key 51: contexts whose batch exists as int8 digit planes take their own launches (see launch_kcross_group);
+        // the timing events of the whole group still go to ctxs[0]
+        bool any_sliced = false;
+        for (int e = 0; e < E; ++e) any_sliced = any_sliced || ctxs[e]->batch_sliced;
+        if (any_sliced) {
+            if (p0s) GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_vsq: GP ranges over a sliced batch");
+            for (int e = 0; e < E; ++e) {
+                gpb_ctx* one[1] = {ctxs[e]};
+                const bool prof = ctxs[e]->profile;
+                ctxs[e]->profile = ctx->profile;
+                const int rc = launch_vsq(one, 1, W, nrows_dev, nullptr, nullptr, true, true);
+                if (ctxs[e] != ctx) {
+                    for (auto& ev : ctxs[e]->prof_events) ctx->prof_events.push_back(ev);
+                    ctxs[e]->prof_events.clear();
+                    ctx->prof_units += ctxs[e]->prof_units; ctxs[e]->prof_units = 0.0;
+                    ctx->prof_compacted = ctx->prof_compacted || ctxs[e]->prof_compacted; ctxs[e]->prof_compacted = false;
+                    ctxs[e]->profile = prof;
+                }
+                if (rc) { ctx->err = ctxs[e]->err; return rc; }
+            }
+            return 0;
+        }
+    }
     int64_t Gsum = 0;
     for (int e = 0; e < E; ++e) {
         if (ctxs[e]->Np != ctx->Np || ctxs[e]->Wld != Wuse || ctxs[e]->stream != ctx->stream)
@@ -1343,7 +1429,12 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, con
         const unsigned grid = (unsigned)((resident || nblocks < slots) ? nblocks : slots);
         const unsigned grid128 = (unsigned)(nblocks < slots ? nblocks : slots);      // the persistent 128x128 launch
         (void)grid; (void)grid128;
-        if (multi) {
+        if (ctx->batch_sliced) {
+            // the int8 kernel (option key 51, gpb_sliced.hip) on the digit planes k_kcross left: same partials' layout and meaning
+            if (multi) GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_vsq: a sliced batch in a shared launch");
+            const int rc = launch_vsq_sliced(ctx, W, nrows_dev, (int)kskip);
+            if (rc) return rc;
+        } else if (multi) {
             // one launch over the GPs of all the emulators (see k_predict_multi): the product shapes only
             PredTable tab;
             int g = 0;

@@ -216,6 +216,18 @@ class Emulator:
             raise ValueError("from_reference: kernel family %s is not RBF / Matern-3/2 / Matern-5/2" % name)
 
         kinds = {family(g) for g in gps}
+        # sklearn's normalize_y (sk:_gpr.py:265-282) rescales the targets and the predictions: the reference never sets it
+        # (src/emulator.py:309-311) and the device state has no slot for it — such a GP would be adopted with wrong means and variances
+        for g in gps:
+            ym, ys = np.asarray(getattr(g, "_y_train_mean", 0.0)), np.asarray(getattr(g, "_y_train_std", 1.0))
+            if bool(getattr(g, "normalize_y", False)) or np.any(ym != 0.0) or np.any(ys != 1.0):
+                raise ValueError("from_reference: a GP was fitted with normalize_y (_y_train_mean / _y_train_std are not 0 / 1)")
+            if np.ndim(g.alpha) != 0:
+                raise ValueError("from_reference: a GP has a per-point alpha (array), not the reference's scalar")
+        want = int(np.shape(ref.model_data)[1]) if bool(getattr(ref, "perform_no_PCA_", False)) else int(ref.npc)
+        if len(gps) != want:
+            raise ValueError("from_reference: %d GPs for %d %s" % (len(gps), want, "observables (perform_no_PCA)" if bool(
+                getattr(ref, "perform_no_PCA_", False)) else "principal components (npc)"))
         X = np.ascontiguousarray(gps[0].X_train_, dtype=np.float64)
         if len(kinds) != 1 or len({float(g.alpha) for g in gps}) != 1 or \
                 any(np.shape(g.X_train_) != X.shape or not np.array_equal(g.X_train_, X) for g in gps[1:]):
@@ -557,9 +569,22 @@ class Emulator:
                 try:
                     eng.set_data(X[r], Z[r].T, "RBF", 0.0)
                     eng.set_theta(thetas[f * P:(f + 1) * P])
-                    eng.factor()
-                    train[si, f] = r2(Z[r], eng.predict(X[r], return_var=False))
-                    test[si, f] = r2(Z[te], eng.predict(X[te], return_var=False))
+                    info = np.asarray(eng.factor(raise_on_fail=False))
+                    good = np.nonzero(info == 0)[0]
+                    if len(good) < P:
+                        # sklearn's learning_curve records error_score = nan for a fit that fails and keeps the others
+                        # (src/emulator.py:449-455: alpha = 0 and a noise bound of 1e-6 leave K barely positive definite);
+                        # the engine installs no factorisation when any GP fails, so the others are factored again alone
+                        log.warning("print_learning_curve: K not positive definite for GP(s) %s at train size %d, fold %d: scores set to NaN",
+                                    np.nonzero(info != 0)[0].tolist(), m, f)
+                        train[si, f], test[si, f] = np.nan, np.nan
+                        if len(good):
+                            eng.set_data(X[r], Z[r][:, good].T, "RBF", 0.0)
+                            eng.set_theta(thetas[f * P:(f + 1) * P][good])
+                            eng.factor()
+                    if len(good):
+                        train[si, f, good] = r2(Z[r][:, good], eng.predict(X[r], return_var=False))
+                        test[si, f, good] = r2(Z[te][:, good], eng.predict(X[te], return_var=False))
                 finally:
                     eng.close()
         trainStatus = []

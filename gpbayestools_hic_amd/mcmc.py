@@ -112,8 +112,17 @@ class Chain:
         the key is rank-local, and only ever decides which VALUE this rank contributes to a check — never whether it takes part"""
         # (an emulator's fitted state by its serial number — new with every training and every __setstate__, never reused;
         # the experiment block by identity AND a content probe: id() alone can come back after an array was dropped)
+        # ... the WHOLE covariance (an in-place edit off the diagonal must not leave the digest stale): its bytes up to 128
+        # observables, two weighted sums over every element beyond that (a 540 x 540 block is 2.3 MB per call otherwise)
+        cov = np.atleast_2d(np.asarray(self.expdata_cov, dtype=np.float64))
+        if cov.size <= 128 * 128:
+            cov_probe = cov.tobytes()
+        else:
+            w = 1.0 + np.arange(cov.shape[1], dtype=np.float64) / cov.shape[1]
+            u = 1.0 + np.arange(cov.shape[0], dtype=np.float64)[::-1] / cov.shape[0]
+            cov_probe = (float(cov.sum()), float(u @ cov @ w), np.diagonal(cov).tobytes())
         key = (id(self.expdata), id(self.expdata_cov), np.asarray(self.expdata).tobytes(),
-               np.diagonal(np.atleast_2d(self.expdata_cov)).tobytes(), self.min.tobytes(), self.max.tobytes(),
+               cov_probe, self.min.tobytes(), self.max.tobytes(),
                tuple((id(e), getattr(e, "_state_serial", None)) for e in self.emuList))
         if any(k[1] is None for k in key[-1]):           # a foreign emulator: no serial to trust, hash every time
             return self.state_digest()
@@ -148,8 +157,10 @@ class Chain:
                 try:
                     emu = Emulator.from_reference(emu, device=self.device)
                     log.info("%s: a trained emulator of the reference, taken over onto device %s", path, self.device)
-                except ValueError as e:
-                    log.info("%s: kept as a foreign emulator (%s)", path, e)
+                except (ValueError, AttributeError, TypeError, KeyError) as e:
+                    # an object that is not quite a trained reference emulator (a missing attribute, an array alpha, a GP
+                    # fitted with normalize_y): it keeps the predict protocol and stays a foreign emulator, as before
+                    log.info("%s: kept as a foreign emulator (%s: %s)", path, type(e).__name__, e)
             self.emuList.append(emu)
         log.info("Number of Emulators: %d", len(self.emuList))
 

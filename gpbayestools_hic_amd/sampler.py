@@ -120,9 +120,12 @@ class StretchSampler:
     def _snapshot(self):
         return (self.pos.clone(), self.lp.clone(), self.naccept.clone(), self.iterations, self._step_counter)
 
-    def _restore(self, snap):
+    def _restore(self, snap, keep_counter=False):
+        """back to a snapshot; keep_counter: the ensemble only — the step counter (the key of the counter-based generators) runs
+        on, so the next steps draw FRESH proposals from the restored ensemble instead of replaying the same ones"""
         self.pos.copy_(snap[0]); self.lp.copy_(snap[1]); self.naccept.copy_(snap[2])
-        self.iterations, self._step_counter = snap[3], snap[4]
+        if not keep_counter:
+            self.iterations, self._step_counter = snap[3], snap[4]
 
     def run(self, X0, nsteps, status=None, store=True):
         """Advance `nsteps` stretch-move steps from X0[nwalkers, ndim]; returns the final positions

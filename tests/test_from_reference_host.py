@@ -52,3 +52,56 @@ def test_refusals():
     ref.gps[0].kernel_.k1.k2.nu = 0.5
     with pytest.raises(ValueError):
         Emulator.from_reference(ref)                                      # Matern-1/2: not on the device path
+
+
+def test_refusals_for_what_the_device_state_cannot_hold():
+    """A GP fitted with normalize_y, a per-point alpha, a GP count that does not match npc: ValueError, never a silent take-over."""
+    from gpbayestools_hic_amd.emulator import Emulator
+    g = golden("g11_trained_objects.npz")
+    ref = rebuild(g, "mask")
+    ref.gps[1]._y_train_mean, ref.gps[1]._y_train_std = np.float64(0.3), np.float64(2.0)
+    with pytest.raises(ValueError, match="normalize_y"):
+        Emulator.from_reference(ref)
+    ref = rebuild(g, "mask")
+    ref.gps[0].normalize_y = True
+    with pytest.raises(ValueError, match="normalize_y"):
+        Emulator.from_reference(ref)
+    ref = rebuild(g, "mask")
+    for gp in ref.gps:
+        gp.alpha = np.full(gp.X_train_.shape[0], 0.1)
+    with pytest.raises(ValueError, match="alpha"):
+        Emulator.from_reference(ref)
+    ref = rebuild(g, "mask")
+    ref.gps = ref.gps[:-1]
+    with pytest.raises(ValueError, match="GPs for"):
+        Emulator.from_reference(ref)
+    ref = rebuild(g, "nopca")
+    ref.gps = ref.gps[:-1]
+    with pytest.raises(ValueError, match="observables"):
+        Emulator.from_reference(ref)
+
+
+def test_load_emulator_keeps_an_incomplete_object_foreign(tmp_path):
+    """Chain.loadEmulator: a pickle that looks like a reference emulator but lacks what from_reference reads (AttributeError,
+    TypeError, KeyError — not only ValueError) stays a foreign emulator instead of aborting the load."""
+    import dill
+    from gpbayestools_hic_amd.mcmc import Chain
+
+    chain = Chain.__new__(Chain)
+    chain.emuList, chain.device = [], 0
+    g = golden("g11_trained_objects.npz")
+    cases = []
+    ref = rebuild(g, "mask"); del ref.design_min; cases.append(ref)                   # AttributeError inside from_reference
+    ref = rebuild(g, "mask"); ref.npc = None; cases.append(ref)                       # TypeError (int(None))
+    ref = rebuild(g, "mask"); del ref.scaler.var_; cases.append(ref)                  # AttributeError on the scaler
+    ref = rebuild(g, "mask"); ref.gps[0]._y_train_std = np.float64(3.0); cases.append(ref)   # ValueError (normalize_y)
+    paths = []
+    for i, ref in enumerate(cases):
+        path = tmp_path / ("emu%d.pkl" % i)
+        with open(path, "wb") as f:
+            dill.dump(ref, f)
+        paths.append(str(path))
+    chain.loadEmulator(paths)
+    assert len(chain.emuList) == len(cases)
+    from gpbayestools_hic_amd.emulator import Emulator
+    assert not any(isinstance(e, Emulator) for e in chain.emuList)

@@ -374,12 +374,15 @@ __device__ __forceinline__ void mma_step8(const Frags8<D, WTN>& f, v16i (&acc)[2
             }
 }
 
-// register-lean: A fragments once, B fragments of one n-tile at a time, read where they are used
-template <int D, int LOW, int WTN>
-__device__ __forceinline__ void mma_step8_streamed(const char* lds, int buf, int wm, int wn, int lane, v16i (&acc)[2 * D - 1 - LOW][WTN]) {
+// register-lean: A fragments once, B fragments of one n-tile at a time, read where they are used.  `dma` (this wave's DMA issue
+// of stage s + 2) runs at position POS: 0 = before the reads, 1 = behind the first reads (a, b0) while they fly, 2 = behind the
+// first n-tile's MFMAs, 3 = waves 0-3 as 1, waves 4-7 as 2 (the two waves of a SIMD out of step)
+template <int D, int LOW, int WTN, int POS, class F>
+__device__ __forceinline__ void mma_step8_streamed(const char* lds, int buf, int wm, int wn, int lane, int wave, v16i (&acc)[2 * D - 1 - LOW][WTN], F dma) {
     typedef Geo<D, 2, WTN> G;
     const char* base = lds + buf * G::STAGE_BYTES;
     const int q = lane >> 5, r = lane & 31;
+    if (POS == 0) dma();
     v4i a[D];
 #pragma unroll
     for (int t = 0; t < D; ++t) a[t] = *reinterpret_cast<const v4i*>(base + ((t * 2 + q) * G::BM + wm * 32 + r) * 16);
@@ -389,6 +392,8 @@ __device__ __forceinline__ void mma_step8_streamed(const char* lds, int buf, int
 #pragma unroll
         for (int t = 0; t < D; ++t)
             b[t] = *reinterpret_cast<const v4i*>(base + G::A_CHUNKS * 1024 + ((t * 2 + q) * G::BN + wn * 32 * WTN + 32 * j + r) * 16);
+        if (j == 0 && (POS == 1 || ((POS == 3 || POS == 4 || POS == 6) && wave < 4))) dma();
+        if (j == 1 && (POS == 2 || ((POS == 3 || POS == 6) && wave >= 4) || (POS == 5 && wave < 4))) dma();
 #pragma unroll
         for (int tb = 0; tb < D; ++tb)
 #pragma unroll
@@ -397,9 +402,11 @@ __device__ __forceinline__ void mma_step8_streamed(const char* lds, int buf, int
                 acc[ta + tb - LOW][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ta], b[tb], acc[ta + tb - LOW][j], 0, 0, 0);
             }
     }
+    if (WTN == 1 && POS >= 2) dma();
+    if (WTN == 2 && (((POS == 4 || POS == 5) && wave >= 4) || POS == 7)) dma();      // behind all of the step's MFMAs
 }
 
-template <int D, int LOW, int MODE, bool PF, int WTN>
+template <int D, int LOW, int MODE, bool PF, int WTN, int POS = 0>
 __global__ __launch_bounds__(512, 2) void k_sliced8(const int8_t* __restrict__ A, const int8_t* __restrict__ B,
                                                     const double* __restrict__ rowscale, const double* __restrict__ colscale,
                                                     double* __restrict__ spart, const TileRec* __restrict__ tiles, int64_t Np,
@@ -421,6 +428,7 @@ __global__ __launch_bounds__(512, 2) void k_sliced8(const int8_t* __restrict__ A
     if (tid < G::BM) rs[tid] = rowscale[(int64_t)p * Np + mb + tid];
     const int nsteps = (int)((mb + G::BM) / 32);
     const bool fullc = Geo8<D, WTN>::REM == 0 || wave < Geo8<D, WTN>::REM;
+    if (POS == 6 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     v16i acc[NLEV][WTN];
 #pragma unroll
     for (int l = 0; l < NLEV; ++l)
@@ -471,8 +479,11 @@ __global__ __launch_bounds__(512, 2) void k_sliced8(const int8_t* __restrict__ A
             if (MODE & 1) wait_stages<D, WTN>(s + 1 < nsteps ? 1 : 0, fullc);          // stage s has landed
             __builtin_amdgcn_s_barrier();
             if (STAMP) stall += __builtin_amdgcn_s_memtime() - w0;
-            if ((MODE & 1) && s + 2 < nsteps) dma_stage8<D, WTN>(lds, (s + 2) % 3, Ap, Bp, Np, Wld, mb, nb, 2 * (int64_t)(s + 2), wave, lane);
-            if ((MODE & 6) == 6) mma_step8_streamed<D, LOW, WTN>(lds, s % 3, wm, wn, lane, acc);
+            auto dma = [&]() {
+                if ((MODE & 1) && s + 2 < nsteps) dma_stage8<D, WTN>(lds, (s + 2) % 3, Ap, Bp, Np, Wld, mb, nb, 2 * (int64_t)(s + 2), wave, lane);
+            };
+            if ((MODE & 6) != 6) dma();
+            if ((MODE & 6) == 6) mma_step8_streamed<D, LOW, WTN, POS>(lds, s % 3, wm, wn, lane, wave, acc, dma);
             else if (MODE & 4) {
                 Frags8<D, WTN> f;
 #pragma unroll
@@ -668,14 +679,14 @@ static int check() {
     return bad;
 }
 
-template <int D, int LOW, int MODE, bool PF, int WTN = 1>
+template <int D, int LOW, int MODE, bool PF, int WTN = 1, int POS = 0>
 static double run8(Problem& pr, int map, int RG, int CG, int reps, const char* name, bool print = true) {
     typedef Geo<D, 2, WTN> G;
     const int nI = (int)(pr.Np / G::BM), nW = (int)(pr.W / G::BN);
     std::vector<TileRec> tiles = make_tiles(pr.P, nI, nW, map, RG, CG);
     TileRec* dt; CK(hipMalloc(&dt, tiles.size() * sizeof(TileRec)));
     CK(hipMemcpy(dt, tiles.data(), tiles.size() * sizeof(TileRec), hipMemcpyHostToDevice));
-    auto kern = k_sliced8<D, LOW, MODE, PF, WTN>;
+    auto kern = k_sliced8<D, LOW, MODE, PF, WTN, POS>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     unsigned long long* dst; CK(hipMalloc(&dst, tiles.size() * 24)); CK(hipMemset(dst, 0, tiles.size() * 24));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -753,62 +764,50 @@ static int check8() {
 
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 10;
+    const bool all = argc > 2;
     int bad = 0;
     bad += check<7, 6, 2, 1>();
     bad += check<6, 5, 2, 1>();
-    bad += check<6, 5, 2, 2>();
     bad += check8<7, 6, true>();
-    bad += check8<7, 6, false>();
-    bad += check8<6, 5, true>();
     bad += check8<6, 5, false, 2>();
     if (bad) { printf("layout or loop error: timings not taken\n"); return 1; }
-    {
+    if (all) {
         Problem pr; make_problem(pr, 10, 2048, 2048, 7, false);
         run<7, 6, 2, 1, 7>(pr, 0, 1, 1, reps, "D7 28prod full loop map0");
-        run<7, 6, 2, 1, 7>(pr, 1, 4, 8, reps, "D7 28prod full loop superblk 4x8");
-        run<7, 6, 2, 1, 7>(pr, 1, 2, 16, reps, "D7 28prod full loop superblk 2x16");
         run<7, 6, 2, 1, 7>(pr, 1, 8, 4, reps, "D7 28prod full loop superblk 8x4");
         run<7, 6, 2, 1, 7, false>(pr, 1, 4, 8, reps, "D7 28prod full, compiler's order");
         run<7, 6, 2, 1, 4>(pr, 1, 4, 8, reps, "D7 28prod MFMA only");
         run<7, 6, 2, 1, 6>(pr, 1, 4, 8, reps, "D7 28prod MFMA + LDS reads");
-        run<7, 6, 2, 1, 6, false>(pr, 1, 4, 8, reps, "D7 MFMA + LDS reads, compiler's order");
         run<7, 6, 2, 1, 1>(pr, 1, 4, 8, reps, "D7 DMA only");
         run<7, 6, 2, 1, 1>(pr, 0, 1, 1, reps, "D7 DMA only map0");
-        run<7, 6, 2, 1, 1>(pr, 2, 1, 1, reps, "D7 DMA only, every block the same tile");
-        run<7, 6, 2, 1, 7>(pr, 2, 1, 1, reps, "D7 full, every block the same tile");
         run8<7, 6, 7, true>(pr, 1, 4, 8, reps, "D7 8w full superblk 4x8");
-        run8<7, 6, 7, true>(pr, 1, 8, 4, reps, "D7 8w full superblk 8x4");
-        run8<7, 6, 7, true>(pr, 0, 1, 1, reps, "D7 8w full map0");
         run8<7, 6, 7, false>(pr, 1, 4, 8, reps, "D7 8w full superblk 4x8");
         run8<7, 6, 4, true>(pr, 1, 4, 8, reps, "D7 8w MFMA only (random regs)");
-        run8<7, 6, 6, true>(pr, 1, 4, 8, reps, "D7 8w MFMA + LDS reads");
-        run8<7, 6, 6, false>(pr, 1, 4, 8, reps, "D7 8w MFMA + LDS reads");
-        run8<7, 6, 1, true>(pr, 1, 4, 8, reps, "D7 8w DMA only");
         free_problem(pr);
     }
     {
         Problem pr; make_problem(pr, 10, 2048, 2048, 6, false);
-        run<6, 5, 2, 1, 7>(pr, 0, 1, 1, reps, "D6 21prod 128x64 map0");
-        run<6, 5, 2, 1, 7>(pr, 1, 4, 8, reps, "D6 21prod 128x64 superblk 4x8");
-        run<6, 5, 2, 1, 7>(pr, 1, 2, 16, reps, "D6 21prod 128x64 superblk 2x16");
-        run<6, 5, 2, 1, 4>(pr, 1, 4, 8, reps, "D6 21prod 128x64 MFMA only");
-        run<6, 5, 2, 1, 1>(pr, 1, 4, 8, reps, "D6 128x64 DMA only");
-        run8<6, 5, 7, true>(pr, 1, 4, 8, reps, "D6 8w full superblk 4x8");
-        run8<6, 5, 7, false>(pr, 1, 4, 8, reps, "D6 8w full superblk 4x8");
-        run8<6, 5, 4, true>(pr, 1, 4, 8, reps, "D6 8w MFMA only (random regs)");
-        run8<6, 5, 1, true>(pr, 1, 4, 8, reps, "D6 8w DMA only");
-        run8<6, 5, 7, false, 2>(pr, 1, 4, 8, reps, "D6 8w 128x128 full superblk 4x8");
-        run8<6, 5, 7, false, 2>(pr, 1, 2, 16, reps, "D6 8w 128x128 full superblk 2x16");
-        run8<6, 5, 7, false, 2>(pr, 1, 8, 4, reps, "D6 8w 128x128 full superblk 8x4");
-        run8<6, 5, 7, false, 2>(pr, 0, 1, 1, reps, "D6 8w 128x128 full map0");
-        run8<6, 5, 4, false, 2>(pr, 1, 4, 8, reps, "D6 8w 128x128 MFMA only (random regs)");
-        run8<6, 5, 1, false, 2>(pr, 1, 4, 8, reps, "D6 8w 128x128 DMA only");
-        run<6, 5, 2, 2, 7>(pr, 1, 4, 8, reps, "D6 21prod 128x128 superblk 4x8 (spills)");
+        if (all) {
+            run<6, 5, 2, 1, 7>(pr, 1, 2, 16, reps, "D6 21prod 128x64 superblk 2x16");
+            run<6, 5, 2, 1, 4>(pr, 1, 4, 8, reps, "D6 21prod 128x64 MFMA only");
+            run<6, 5, 2, 1, 1>(pr, 1, 4, 8, reps, "D6 128x64 DMA only");
+            run8<6, 5, 7, false>(pr, 1, 4, 8, reps, "D6 8w full superblk 4x8");
+        }
+        run8<6, 5, 7, false, 2, 0>(pr, 1, 8, 4, reps, "D6 8w 128x128 DMA first (pos 0)");
+        run8<6, 5, 7, false, 2, 1>(pr, 1, 8, 4, reps, "D6 8w 128x128 DMA behind reads (pos 1)");
+        run8<6, 5, 7, false, 2, 2>(pr, 1, 8, 4, reps, "D6 8w 128x128 DMA mid-step (pos 2)");
+        run8<6, 5, 7, false, 2, 3>(pr, 1, 8, 4, reps, "D6 8w 128x128 DMA staggered (pos 3)");
+        run8<6, 5, 7, false, 2, 4>(pr, 1, 8, 4, reps, "D6 8w 128x128 pos 4 (early / end)");
+        run8<6, 5, 7, false, 2, 5>(pr, 1, 8, 4, reps, "D6 8w 128x128 pos 5 (mid / end)");
+        run8<6, 5, 7, false, 2, 6>(pr, 1, 8, 4, reps, "D6 8w 128x128 pos 6 (3 + setprio)");
+        run8<6, 5, 7, false, 2, 7>(pr, 1, 8, 4, reps, "D6 8w 128x128 pos 7 (all at the end)");
+        run8<6, 5, 7, false, 2, 3>(pr, 1, 8, 4, reps, "D6 8w 128x128 pos 3 again");
+        run8<6, 5, 7, false, 2, 3>(pr, 1, 4, 8, reps, "D6 8w 128x128 pos 3 superblk 4x8");
+        run8<6, 5, 4, false, 2>(pr, 1, 8, 4, reps, "D6 8w 128x128 MFMA only (random regs)");
+        run8<6, 5, 1, false, 2>(pr, 1, 8, 4, reps, "D6 8w 128x128 DMA only");
         CK(hipMemset(pr.dA, 0, (size_t)pr.P * pr.D * pr.Np * pr.Np)); CK(hipMemset(pr.dB, 0, (size_t)pr.P * pr.D * pr.Np * pr.W));
-        run<6, 5, 2, 1, 7>(pr, 1, 2, 16, reps, "D6 21prod 128x64 full on ZERO planes");
-        run8<6, 5, 7, false>(pr, 1, 4, 8, reps, "D6 8w full on ZERO planes");
-        run8<6, 5, 7, false, 2>(pr, 1, 4, 8, reps, "D6 8w 128x128 full on ZERO planes");
-        run<6, 5, 2, 2, 1>(pr, 1, 4, 8, reps, "D6 128x128 DMA only");
+        run8<6, 5, 7, false, 2, 0>(pr, 1, 8, 4, reps, "D6 8w 128x128 pos 0 on ZERO planes");
+        run8<6, 5, 7, false, 2, 3>(pr, 1, 8, 4, reps, "D6 8w 128x128 pos 3 on ZERO planes");
         free_problem(pr);
     }
     return 0;
