@@ -95,7 +95,7 @@ def extras(chain4, emu4, info4, sustain_s=5.5, only_sustained=False):
     (P N^3/3 flops / time) and with its own roofline block."""
     import torch
     from gpbayestools_hic_amd import synth
-    from gpbayestools_hic_amd.workload import build_chain
+    from gpbayestools_hic_amd.workload import build_chain, flops_per_walker
 
     def timed(fn, reps):
         fn(); torch.cuda.synchronize()
@@ -190,7 +190,8 @@ def extras(chain4, emu4, info4, sustain_s=5.5, only_sustained=False):
     # variances from the fp64 path, and the step loop with it switched on.
     try:
         INT8_PEAK_TOPS = 5000.0
-        m64, v64 = eng4.predict(Xin[:512])
+        Xh512 = Xin[:512].cpu().numpy()
+        m64, v64 = eng4.predict(Xh512)
         eng4.tune("predict_sliced", 1)
         lp_s = torch.empty_like(lp)
         for _ in range(3):
@@ -201,7 +202,7 @@ def extras(chain4, emu4, info4, sustain_s=5.5, only_sustained=False):
             chain4.log_prob_device(Xin, lp_s)
         n_s, ms_s, units_s = eng4.profile_read()
         eng4.profile(False)
-        ms8, v8 = eng4.predict(Xin[:512])
+        ms8, v8 = eng4.predict(Xh512)
         fin = torch.isfinite(lp)
         t_s = ms_s / max(n_s, 1) * 1e-3
         alg = units_s / max(n_s, 1) * float(info4["N"]) ** 2
@@ -245,6 +246,49 @@ def extras(chain4, emu4, info4, sustain_s=5.5, only_sustained=False):
             pass
     if only_sustained:
         return out
+
+    # cfg 4's second shape ("also report P = 64 via perform_no_PCA", src/emulator.py:562-565,589-592): one GP per
+    # observable — 64 GPs of N = 2048, 6.4 x the predict work per walker, the dense 64 x 64 likelihood kernels instead of the
+    # low-rank form.  Same walkers, same ball, the same C-driven step loop.
+    try:
+        chain64, emu64, info64 = build_chain(4, no_pca=True)
+        eng64 = emu64._engine_ready()
+        lp64 = torch.empty(info64["W"], dtype=torch.float64, device="cuda")
+        for _ in range(2):
+            chain64.log_prob_device(Xin, lp64)
+        torch.cuda.synchronize()
+        t_batch = timed(lambda: chain64.log_prob_device(Xin, lp64), 5)
+        eng64.profile(True); eng64.profile_read()
+        for _ in range(5):
+            chain64.log_prob_device(Xin, lp64)
+        n6, ms6, u6 = eng64.profile_read()
+        eng64.profile(False)
+        X064 = synth.walkers_ball(nw4, info64["xstar"], ball4, lo=info64["lo"], hi=info64["hi"])
+        s64 = StretchSampler(chain64, nw4, seed=2468)
+        s64.run(X064, 0, status=10 ** 9, store=False)
+        snap64 = s64._snapshot()
+        s64.run(None, 4, status=10 ** 9, store=False)
+        s64._restore(snap64, keep_counter=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s64.run(None, 10, status=10 ** 9, store=False)
+        torch.cuda.synchronize()
+        t_step = (time.perf_counter() - t0) / 10
+        tf6 = u6 / max(n6, 1) * float(info64["N"]) ** 2 / (ms6 / max(n6, 1) * 1e-3) / 1e12
+        out["cfg4_nopca_p64"] = {
+            "gps": info64["P"], "observables": info64["M"], "walkers": nw4,
+            "ms_per_step": t_step * 1e3, "walker_evals_per_s": nw4 / t_step,
+            "batch_2048_rows_ms": t_batch * 1e3,
+            "k_predict_avg_launch_ms": ms6 / max(n6, 1), "k_predict_tflops": tf6, "k_predict_frac": tf6 / FP64_MFMA_PEAK_TFLOPS,
+            "outside_predict_launch_ms_per_batch": t_batch * 1e3 - ms6 / max(n6, 1),
+            "tflops_algorithmic": flops_per_walker(info64["N"], info64["d"], info64["P"], info64["M"], "RBF") * nw4 / t_step / 1e12,
+            "what": "cfg 4 with perform_no_PCA: 64 GPs (one per observable) of N = 2048, 4096 walkers; ms_per_step over 10 steps of "
+                    "the C-driven loop from the burnt-in ball; k_predict: HIP events round the 64-GP launch of a 2048-row batch; "
+                    "outside_predict_launch = K*^T (k_kcross) + the dense 64 x 64 likelihood kernel (k_loglike_reg/wg) + the rest "
+                    "of one 2048-row log-posterior batch"}
+        del s64, chain64, emu64, eng64
+    except Exception as e:      # noqa: BLE001
+        out["cfg4_nopca_p64"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     _, emu2, info2 = build_chain(2)
     eng2 = emu2._engine_ready()
@@ -344,7 +388,6 @@ def extras(chain4, emu4, info4, sustain_s=5.5, only_sustained=False):
     # BASELINE config 3 (1 x MI355X: 1024 design pts x 15 params, emcee stretch move with 1024 walkers, src/mcmc.py:372-412):
     # the resident step loop on a burnt-in ensemble, every proposal row evaluated, as the headline is measured
     from gpbayestools_hic_amd.sampler import StretchSampler
-    from gpbayestools_hic_amd.workload import flops_per_walker
     chain3, emu3, info3 = build_chain(3)
     eng3 = emu3._engine_ready()
     nw3, warm3, nst3 = 2 * info3["W"], 3, 40
@@ -627,7 +670,12 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=None)
     ap.add_argument("--sustain", type=float, default=5.5, help="seconds of continuous steps behind extras.sustained_cfg4")
     ap.add_argument("--only-sustained", action="store_true", help="of the extras, run the sustained-rate block alone")
+    ap.add_argument("--sliced", action="store_true",
+                    help="NOT the headline: the whole run with the int8 predict kernel (option key 51, csrc/gpb_sliced.hip) switched on; "
+                         "the line says so in config.variant and prices its roofline against the dense int8 MFMA peak")
     args = ap.parse_args()
+    if args.sliced:
+        os.environ["GPB_PREDICT_SLICED"] = "1"
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
 
@@ -881,19 +929,45 @@ def main():
                          "frac": (achieved / FP64_MFMA_PEAK_TFLOPS) if achieved else None, "traffic": None,
                          "launches": launches, "avg_launch_ms": kms / max(launches, 1)},
         }
+        if args.sliced:
+            tops = 21.0 * alg_flops_per_launch / (kms / max(launches, 1) * 1e-3) / 1e12 if launches else None
+            out["config"]["variant"] = ("int8 predict kernel switched on (bench.py --sliced, option key 51): NOT the default path; "
+                                        "variance within ~1e-11 of the fp64 kernel, see extras.k_predict_sliced_cfg4 of the default run")
+            out["roofline"] = {"bound": "mfma", "kernel": "k_predict_sliced (V = L^-1 K*^T on v_mfma_i32_32x32x32_i8, 21 digit products, fused sum of squares)",
+                               "achieved": tops, "peak": 5000.0, "unit": "TOP/s (int8, dense)", "frac": (tops / 5000.0) if tops else None,
+                               "fp64_equivalent_tflops": achieved, "traffic": None, "launches": launches, "avg_launch_ms": kms / max(launches, 1)}
+            out["dtype"] = "f64 (V = L^-1 K*^T through int8 digit planes, exact int32 sums, fp64 combine)"
         # HBM-side traffic of the dominant kernel: PMC counters need rocprofv3, so the per-launch figure comes
         # from the committed summary of the same command (profiles/r05_pmc_traffic.json), when it matches.
+        # (the newest profiles/rNN_pmc_traffic.json whose workload AND kernel-source fingerprint match this build: a profile older
+        # than the kernel is not quoted — roofline.traffic_note says why)
         try:
-            with open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            wl = pmc["workload"]
-            if (wl["config"], wl["N"], wl["P"], wl["W_per_launch"]) == (args.config, N, P, nwalkers // 2) and world == 1 \
-                    and wl.get("burnt_in"):
-                out["roofline"]["traffic"] = pmc["k_predict"]["bytes_per_launch_corrected"]
-                out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r05_pmc_traffic.json)"
-                out["roofline"]["algorithmic_bytes"] = pmc["k_predict"]["algorithmic_bytes_per_launch"]
-        except Exception:
-            pass
+            import glob
+            import hashlib
+            key = "k_predict_sliced" if args.sliced else "k_predict"
+            srcs = ["gpb_sliced.hip"] if args.sliced else ["gpb_predict.hip", "gemm_tile.h"]
+            fp = hashlib.sha256(b"".join(open(os.path.join(ROOT, "gpbayestools_hic_amd", "csrc", f), "rb").read() for f in srcs)).hexdigest()[:16]
+            note = "no profiles/r*_pmc_traffic.json for this workload"
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+                with open(path) as f:
+                    pmc = json.load(f)
+                wl = pmc["workload"]
+                if key not in pmc or (wl["config"], wl["N"], wl["P"], wl["W_per_launch"]) != (args.config, N, P, nwalkers // 2) \
+                        or world != 1 or not wl.get("burnt_in"):
+                    continue
+                if pmc[key].get("source_sha16") != fp:
+                    note = "%s was collected on an older build of %s (fingerprint %s, now %s): not quoted" % (
+                        os.path.basename(path), "+".join(srcs), pmc[key].get("source_sha16"), fp)
+                    continue
+                out["roofline"]["traffic"] = pmc[key]["bytes_per_launch_corrected"]
+                out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % os.path.basename(path)
+                out["roofline"]["algorithmic_bytes"] = pmc[key]["algorithmic_bytes_per_launch"]
+                note = None
+                break
+            if note:
+                out["roofline"]["traffic_note"] = note
+        except Exception as e:      # noqa: BLE001
+            out["roofline"]["traffic_note"] = "%s: %s" % (type(e).__name__, e)
         if world == 1 and not args.no_extras:
             out["extras"] = extras(chain, emu, info, args.sustain, args.only_sustained)
         if uni is not None:

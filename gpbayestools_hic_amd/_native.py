@@ -86,7 +86,6 @@ DEBUG = {
     "gpb_debug_loopback_release": (C.c_int, [VP]),
     "gpb_debug_tile_trace": (C.c_int, [VP, c_i64]),
     "gpb_debug_tile_trace_read": (C.c_int, [VP, VP, c_i64, VP]),
-    "gpb_debug_graph_probe": (C.c_int, [VP, C.c_int, VP, VP, c_i64, c_u64, C.c_double, VP, VP, C.c_double, C.c_double, C.c_int, VP, VP]),
     "gpb_probe_fp64": (C.c_int, [VP, C.c_int, VP]),
 }
 PROTOTYPES = dict(BOUNDARY, **DEBUG)

@@ -141,7 +141,7 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     ctx->ls = ctx->amp = ctx->noise = nullptr; ctx->gpform = ctx->gpmap = nullptr;         // (carved out of thblk)
     if (ctx->h_thblk) (void)hipHostFree(ctx->h_thblk);
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);
-    dev_free(&ctx->Z); dev_free(&ctx->K); dev_free(&ctx->Linv); dev_free(&ctx->LinvT); dev_free(&ctx->T); dev_free(&ctx->yv);
+    dev_free(&ctx->Z); dev_free(&ctx->K); dev_free(&ctx->Linv); dev_free(&ctx->T); dev_free(&ctx->yv);
     gpb::sliced_free(ctx);
     dev_free(&ctx->alpha); dev_free(&ctx->apart); dev_free(&ctx->info); dev_free(&ctx->lmlbuf);
     dev_free(&ctx->gpart); dev_free(&ctx->Xs); dev_free(&ctx->estd); dev_free(&ctx->KsT); dev_free(&ctx->mpart);
@@ -153,8 +153,6 @@ extern "C" int gpb_ctx_destroy(gpb_ctx* ctx) {
     dev_free(&ctx->n_nan); dev_free(&ctx->mc_ws); dev_free(&ctx->bal_ws); dev_free(&ctx->rows_live); dev_free(&ctx->cmp_idx); dev_free(&ctx->cmp_X);
     if (ctx->live_hint) (void)hipHostFree(ctx->live_hint);
     for (hipEvent_t e : ctx->chol_events) (void)hipEventDestroy(e);
-    for (hipEvent_t e : ctx->ov_ev) if (e) (void)hipEventDestroy(e);
-    if (ctx->prof_open) (void)hipEventDestroy(ctx->prof_open);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -235,9 +233,7 @@ static int gp_set_impl(gpb_ctx* ctx, int64_t P, int64_t d, const int64_t* N_p, c
     if ((rc = dev_alloc(ctx, &ctx->Z, P * Np))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->K, P * Np * Np))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->Linv, P * Np * Np))) return rc;
-    dev_free(&ctx->LinvT);                             // the k-major copy follows the new shape on its next use
-    ctx->linvT_valid = false;
-    gpb::sliced_free(ctx);                             // ... and so do the digit planes
+    gpb::sliced_free(ctx);                             // the digit planes follow the new shape on their next use
     // zeroed ONCE: the factorisation writes the diagonal blocks (with zeros above the diagonal) and the blocks below
     // them, never the blocks above — and the 128-wide tiles of the predict / K^-1 products read those as zeros
     GPB_HIP(hipMemsetAsync(ctx->Linv, 0, sizeof(double) * P * Np * Np, ctx->stream));
@@ -1075,24 +1071,15 @@ extern "C" int gpb_debug_has_variants(void) {
 extern "C" int gpb_ctx_option(gpb_ctx* ctx, int key, int value) {
     if (!ctx) return GPB_E_ARG;
 #ifndef GPB_DEBUG_VARIANTS
-    // the product library holds only the kernels its own rules select: the keys that switch to a measured-and-rejected
-    // variant or to a measurement hook (26, 32: one rank's share of a sharded step on a single GPU) exist in the debug build
+    // the measurement hooks (26, 32: one rank's share of a sharded step on a single GPU) exist in the debug build
     // (libgpbayes_debug.so, -DGPB_DEBUG_VARIANTS) and are refused here
-    {
-        const bool variant = (key == 2 && value != 4) || (key == 5 && value == 0) || (key == 26 && value != 0) || (key == 32 && value != 0) ||
-                             (key == 21 && value != 1) || (key == 24 && value != 1) || (key == 37 && value != 1) ||
-                             (key == 38 && value != 0) || (key == 39 && value != 1) || (key == 41 && value != 0) || (key == 48 && value != 0);
-        if (variant) GPB_FAIL(GPB_E_ARG, "gpb_ctx_option: this value selects a kernel variant or hook of the debug build only");
-    }
+    if ((key == 26 && value != 0) || (key == 32 && value != 0))
+        GPB_FAIL(GPB_E_ARG, "gpb_ctx_option: this value selects a hook of the debug build only");
 #endif
     switch (key) {
-        case 0: if (value < -1 || value > 3) return GPB_E_ARG; ctx->force_xcd = value; break;
-        case 1: if (value < 1 || value > 8) return GPB_E_ARG; ctx->wgs_per_cu64 = value; break;
-        case 2: if (value != 4 && value != 8) return GPB_E_ARG; ctx->predict_waves = value; break;
-        case 3: if (value < 1 || value > 4) return GPB_E_ARG; ctx->wgs_per_cu128w8 = value; break;
+        case 0: if (value < -1 || value > 1) return GPB_E_ARG; ctx->force_xcd = value; break;
         case 4: if (value < 0 || value % 64) return GPB_E_ARG; ctx->chol_outer = value; break;
-        case 5: if (value < 0 || value > 3) return GPB_E_ARG; ctx->resident_order = value; break;
-        case 6: if (value < 1 || value > 10) return GPB_E_ARG; ctx->wgs_per_cu32 = value; break;
+        case 5: if (value < 1 || value > 3) return GPB_E_ARG; ctx->resident_order = value; break;
         case 7: if (value < 0) return GPB_E_ARG; ctx->narrow_switch = value; break;
         case 8: if (value < 0) return GPB_E_ARG; ctx->mvn_wg_switch = value; break;
         case 9: if (value != 64 && value != 128) return GPB_E_ARG; ctx->chol_inner_tile = value; break;
@@ -1108,15 +1095,11 @@ extern "C" int gpb_ctx_option(gpb_ctx* ctx, int key, int value) {
             break;
         case 19: if (value < 0 || value > 64) return GPB_E_ARG; ctx->kcross_chunks = value; break;
         case 20: if (value < 1 || value > 2) return GPB_E_ARG; ctx->kcross_wpl = value; break;
-        case 21: if (value < 0 || value > 1) return GPB_E_ARG; ctx->static64 = value; break;
         case 23: if (value < 0 || value > 1) return GPB_E_ARG; ctx->lowrank = value; break;
         case 22: if (value < 0) return GPB_E_ARG; ctx->mid_switch = value; break;
         case 11: if (value < 0 || value > 1) return GPB_E_ARG; ctx->fuse_finalize = value; break;
         case 12: if (value != 0 && value != 64 && value != 128) return GPB_E_ARG; ctx->trtri_tile = value; break;
         case 14: if (value != 0 && value != 64 && value != 128) return GPB_E_ARG; ctx->syrk_tile = value; break;
-        case 16: if (value < 1 || value > 8) return GPB_E_ARG; ctx->wgs_per_cu64x128 = value; break;
-        case 13: if (value < 0 || value > 1024) return GPB_E_ARG; ctx->resident_occ = value; break;
-        case 24: if (value < 0 || value > 1) return GPB_E_ARG; ctx->chol_algo = value; break;
         case 25: if (value < 0 || value > 1) return GPB_E_ARG; ctx->chol_lookahead = value; break;
         case 26: if (value < 0 || value > 64) return GPB_E_ARG; ctx->sim_ranks = value; break;
         case 27: if (value < 0 || value > 1) return GPB_E_ARG; ctx->compact = value; break;
@@ -1125,35 +1108,13 @@ extern "C" int gpb_ctx_option(gpb_ctx* ctx, int key, int value) {
         case 30: if (value < 0 || value > 1) return GPB_E_ARG; ctx->fuse_accept_propose = value; break;
         case 32: if (value < 0 || value > 63) return GPB_E_ARG; ctx->sim_rank = value; break;
         case 36: if (value < 0 || value > 2) return GPB_E_ARG; ctx->balance_shards = value; break;
-        case 37: if (value < 0 || value > 1) return GPB_E_ARG; ctx->mma_pipe = value; break;
-        case 38: if (value < 0 || value > 1) return GPB_E_ARG; ctx->fold_tiles = value; break;
-        case 39: if (value < 0 || value > 1) return GPB_E_ARG; ctx->kmat_mfma = value; break;
         case 40: if (value < 0 || value > 1) return GPB_E_ARG; ctx->chain_batch = value; break;
-        case 41: if (value < 0 || value > 1) return GPB_E_ARG; ctx->predict_dma = value; break;
         case 42:        // force the predict tile: 0 = by rule, 128 / 64 / 32 (= 64 x 32) / 65 (= 64 x 128) — all product shapes, same bits
             if (value != 0 && value != 32 && value != 64 && value != 65 && value != 128) return GPB_E_ARG;
             ctx->force_tile = value;
             break;
         case 43: if (value < 0 || value > 1) return GPB_E_ARG; ctx->force_generic_mvn = value != 0; break;
-#ifdef GPB_DEBUG_VARIANTS
-        case 46: {      // fusion probe (see predict_tile): arms the trace buffer with the probe's sentinel, counters per walker tile
-            if (value < 0 || value > 2) return GPB_E_ARG;      // 1: release + ticket per tile only; 2: and the last tile's tail
-            GPB_HIP(hipSetDevice(ctx->device));
-            GPB_HIP(hipStreamSynchronize(ctx->stream));
-            if (ctx->tile_trace) { pool_free(ctx->tile_trace); ctx->tile_trace = nullptr; }
-            if (value >= 1) {
-                if (ctx->N == 0) GPB_FAIL(GPB_E_STATE, "gpb_ctx_option 46 before gpb_gp_set");
-                const size_t n = 16 + 65536;
-                GPB_HIP(pool_malloc_t(&ctx->tile_trace, n * sizeof(unsigned)));
-                GPB_HIP(hipMemset(ctx->tile_trace, 0, n * sizeof(unsigned)));
-                const unsigned head[5] = {0u, 0xffffffffu, (unsigned)(ctx->P * (ctx->Np / 64)), 0u, (unsigned)value};
-                GPB_HIP(hipMemcpy(ctx->tile_trace, head, sizeof(head), hipMemcpyHostToDevice));
-            }
-            break;
-        }
-#endif
         case 47: if (value < 0 || value > 2) return GPB_E_ARG; ctx->chol_pair = value; break;
-        case 48: if (value < 0 || value > 99) return GPB_E_ARG; ctx->kx_overlap = value; break;
         case 49: if (value < 0 || value > 1) return GPB_E_ARG; ctx->lr_split = value; break;
         case 50: if (value != 0 && value != 64 && value != 128) return GPB_E_ARG; ctx->kinv_tile = value; break;
         case 51:        // V = L^-1 K*^T on the int8 matrix pipe (gpb_sliced.hip): 0 = never (default), 1 = where the rule admits, 2 = rule off

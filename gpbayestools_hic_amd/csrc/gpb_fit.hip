@@ -281,183 +281,17 @@ static void launch_kmat_diff(gpb_ctx* ctx, const int* form) {
 }
 
 int launch_kmat(gpb_ctx* ctx) {
-    if (ctx->kmat_mfma) {                              // each GP in its distance form (gpform); a launch with no GP is left out
-        if (ctx->n_diff < ctx->P) {
-            if (ctx->kind == GPB_KERNEL_RBF) launch_kmat_mfma<GPB_KERNEL_RBF>(ctx);
-            else if (ctx->kind == GPB_KERNEL_MATERN15) launch_kmat_mfma<GPB_KERNEL_MATERN15>(ctx);
-            else launch_kmat_mfma<GPB_KERNEL_MATERN25>(ctx);
-        }
-        if (ctx->n_diff > 0) launch_kmat_diff(ctx, ctx->n_diff < ctx->P ? ctx->gpform : nullptr);
-        GPB_HIP(hipGetLastError());
-        return 0;
+    // each GP in its distance form (gpform); a launch with no GP is left out
+    if (ctx->n_diff < ctx->P) {
+        if (ctx->kind == GPB_KERNEL_RBF) launch_kmat_mfma<GPB_KERNEL_RBF>(ctx);
+        else if (ctx->kind == GPB_KERNEL_MATERN15) launch_kmat_mfma<GPB_KERNEL_MATERN15>(ctx);
+        else launch_kmat_mfma<GPB_KERNEL_MATERN25>(ctx);
     }
-#ifdef GPB_DEBUG_VARIANTS                               // tune key 39 = 0: every GP by k_kmat (A/B against rounds 1-2)
-    launch_kmat_diff(ctx, nullptr);
+    if (ctx->n_diff > 0) launch_kmat_diff(ctx, ctx->n_diff < ctx->P ? ctx->gpform : nullptr);
     GPB_HIP(hipGetLastError());
     return 0;
-#else
-    GPB_FAIL(GPB_E_STATE, "gpb: internal: k_kmat for every GP is a debug-build variant");
-#endif
 }
 
-#ifdef GPB_DEBUG_VARIANTS       // round 1's three-launch schedule (tune key 24 = 0), for A/B
-// ------------------------------------------------------------------ Cholesky: diagonal block
-// Factor the 64x64 diagonal block kb in LDS and invert the factor; write L_kk back (upper zeroed) and
-// L_kk^-1 into the diagonal block of Linv.  This kernel is the serial chain of the blocked
-// factorisation (Np/64 dependent launches), so it is organised for latency: 16-wide sub-blocks, the
-// 16x16 diagonal factor and its inverse held in one wave's registers (lane i = row i, v_readlane
-// broadcasts, no barriers), panel solve / trailing update / inverse assembly as small dense products
-// over all 256 threads — about 20 barriers instead of ~260 for the unblocked form.
-// info[p] = 1-based global index of the first non-positive pivot (LAPACK dpotrf convention).
-__device__ __forceinline__ double rl64(double x, int lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
-    return __hiloint2double(hi, lo);
-}
-
-__global__ __launch_bounds__(256) void k_potf2_inv(double* __restrict__ K, double* __restrict__ Linv,
-                                                   int64_t Np, int64_t kb, int* __restrict__ info) {
-    __shared__ double a[64][65];     // block -> L
-    __shared__ double x[64][65];     // L^-1
-    __shared__ double tm[64][65];    // scratch for the inverse assembly
-    __shared__ double rdg[64];       // reciprocals of the pivots
-    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t c0 = kb * 64;
-    double* Kp = K + (int64_t)p * Np * Np + c0 * Np + c0;
-    double* Lp = Linv + (int64_t)p * Np * Np + c0 * Np + c0;
-    for (int e = tid; e < 64 * 64; e += 256) {
-        const int r = e >> 6, c = e & 63;
-        a[r][c] = Kp[(int64_t)r * Np + c];
-        x[r][c] = 0.0;
-    }
-    __syncthreads();
-    const int ty = tid >> 4, tx = tid & 15;
-    for (int bb = 0; bb < 4; ++bb) {
-        const int o = 16 * bb;
-        if (wave == 0) {
-            // ---- 16x16 diagonal sub-block in registers: lane i (< 16) owns row i
-            const int li = lane & 15;
-            double r[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) r[k] = a[o + li][o + k];
-            int badj = -1;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double ajj = rl64(r[j], j);
-                if (!(ajj > 0.0) && badj < 0) badj = j;
-                const double rinv = rsqrt(ajj);                   // 1 / L_jj
-                const double lj = r[j] * rinv;                    // column j of L (rows >= j; row j: sqrt(a_jj))
-                if (lane == 0) rdg[o + j] = rinv;
-                r[j] = lj;
-#pragma unroll
-                for (int k = j + 1; k < 16; ++k) r[k] = fma(-lj, rl64(lj, k), r[k]);
-            }
-            if (badj >= 0 && lane == 0 && info[p] == 0) info[p] = (int)(c0 + o + badj + 1);
-            if (lane < 16) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) a[o + li][o + k] = (k <= li) ? r[k] : 0.0;
-            }
-        }
-        __syncthreads();
-        const int nrem = 48 - o;                       // rows below this sub-block inside the 64-block
-        if (nrem > 0) {
-            // ---- panel: L21 L11^T = A21 by forward substitution, one row per thread (the 16x16 inverses are
-            //      not needed here and are taken off this serial chain: all four are formed in parallel below)
-            if (tid < nrem) {
-                const int rr = o + 16 + tid;
-                double l[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    double sacc = a[rr][o + j];
-#pragma unroll
-                    for (int k = 0; k < j; ++k) sacc = fma(-l[k], a[o + j][o + k], sacc);
-                    l[j] = sacc * rdg[o + j];
-                }
-#pragma unroll
-                for (int j = 0; j < 16; ++j) a[rr][o + j] = l[j];
-            }
-            __syncthreads();
-            // ---- trailing update of the lower triangle: A22 -= L21 L21^T
-            for (int i = o + 16 + ty; i < 64; i += 16)
-                for (int k = o + 16 + tx; k <= i; k += 16) {
-                    double sacc = a[i][k];
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) sacc = fma(-a[i][o + t], a[k][o + t], sacc);
-                    a[i][k] = sacc;
-                }
-            __syncthreads();
-        }
-    }
-    {
-        // ---- inverses of the four 16x16 diagonal factors, one per wave: lane c (< 16) owns column c of X
-        const int o = 16 * wave, li = lane & 15;
-        double r[16], xc[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            r[k] = a[o + li][o + k];                   // row li of L11 (zeros above the diagonal)
-            xc[k] = 0.0;
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const double rdi = rdg[o + i];
-            double sacc = 0.0;
-#pragma unroll
-            for (int k = 0; k < i; ++k) sacc = fma(rl64(r[k], i), xc[k], sacc);   // l_ik from lane i's row
-            const double v = (i == li) ? rdi : -sacc * rdi;
-            xc[i] = (i >= li) ? v : 0.0;
-        }
-        if (lane < 16) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) x[o + k][o + li] = xc[k];          // column li of the inverse
-        }
-    }
-    __syncthreads();
-    // ---- assemble L^-1 from its 16x16 diagonal blocks by block doubling (hs = 16, then 32):
-    //      X21 = -X22 (L21 X11)
-    for (int hs = 16; hs <= 32; hs *= 2) {
-        const int npair = 32 / hs;                     // 2 pairs of 16-blocks, then 1 pair of 32-blocks
-        for (int e = tid; e < npair * hs * hs; e += 256) {
-            const int pr = e / (hs * hs), rem = e - pr * hs * hs, rr = rem / hs, cc = rem - rr * hs;
-            const int q0 = pr * 2 * hs, q1 = q0 + hs;
-            double sacc = 0.0;
-            for (int k = cc; k < hs; ++k) sacc = fma(a[q1 + rr][q0 + k], x[q0 + k][q0 + cc], sacc);
-            tm[q1 + rr][q0 + cc] = sacc;
-        }
-        __syncthreads();
-        for (int e = tid; e < npair * hs * hs; e += 256) {
-            const int pr = e / (hs * hs), rem = e - pr * hs * hs, rr = rem / hs, cc = rem - rr * hs;
-            const int q0 = pr * 2 * hs, q1 = q0 + hs;
-            double sacc = 0.0;
-            for (int k = 0; k <= rr; ++k) sacc = fma(x[q1 + rr][q1 + k], tm[q1 + k][q0 + cc], sacc);
-            x[q1 + rr][q0 + cc] = -sacc;
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < 64 * 64; e += 256) {
-        const int r = e >> 6, cc = e & 63;
-        Kp[(int64_t)r * Np + cc] = (cc <= r) ? a[r][cc] : 0.0;
-        Lp[(int64_t)r * Np + cc] = (cc <= r) ? x[r][cc] : 0.0;
-    }
-}
-
-// Panel: L_ik = A_ik * L_kk^-T for the 64-row blocks below the diagonal block — one 64x64x64 NT product per
-// workgroup on the MFMA tile engine, in place (every workgroup owns its rows; all of its reads are staged
-// through LDS before the first store).
-__global__ __launch_bounds__(256, 2) void k_trsm_panel(double* __restrict__ K, const double* __restrict__ Linv,
-                                                       int64_t Np, int64_t kb) {
-    __shared__ TileLds<64> lds;
-    const int p = blockIdx.y;
-    const int64_t c0 = kb * 64, r0 = (kb + 1 + blockIdx.x) * 64;
-    double* Ap = K + (int64_t)p * Np * Np + r0 * Np + c0;
-    const double* Xp = Linv + (int64_t)p * Np * Np + c0 * Np + c0;
-    Acc<64> acc;
-    acc_zero<64>(acc);
-    // out[i][j] = sum_k A[i][k] * X[j][k]
-    gemm_tile_loop<64, false, true>(Ap, Np, Xp, Np, 0, 0, 64, 64, 0, 64, lds, acc);
-    tile_store<64>(Ap, Np, 0, 0, 64, 64, 1.0, false, acc);
-}
-#endif  // GPB_DEBUG_VARIANTS
 
 // Trailing update (SYRK on MFMA): A[i][j] -= sum_{k in [c0, c0+kw)} L[i][k] L[j][k] for rows i >= r0 and
 // columns j in [r0, ce), lower part only (tiles entirely above the diagonal exit).  Two-level blocking:
@@ -502,41 +336,7 @@ void launch_syrk_panel(gpb_ctx* ctx, int64_t pb, int64_t pe) { launch_syrk_range
 int launch_potrf_fused(gpb_ctx* ctx);                  // gpb_chol.hip: two launches per 64-column step
 
 int launch_potrf(gpb_ctx* ctx) {
-#ifndef GPB_DEBUG_VARIANTS
     return launch_potrf_fused(ctx);
-#else
-    if (ctx->chol_algo == 1) return launch_potrf_fused(ctx);
-    // round 1's schedule (three launches per step), kept for A/B measurements: tune key 24 = 0
-    const int64_t Np = ctx->Np, nb = Np / 64;
-    const int64_t NBO = ctx->chol_outer > 0 ? ctx->chol_outer : 512;      // outer panel width (multiple of 64)
-    GPB_HIP(hipMemsetAsync(ctx->info, 0, sizeof(int) * ctx->P, ctx->stream));
-    for (int64_t kb = 0; kb < nb; ++kb) {
-        const int64_t c0 = kb * 64, r0 = c0 + 64;
-        const int64_t pb = (c0 / NBO) * NBO, pe = imin64(pb + NBO, Np);     // outer panel [pb, pe)
-        hipLaunchKernelGGL(k_potf2_inv, dim3((unsigned)ctx->P), dim3(256), 0, ctx->stream, ctx->K, ctx->Linv, Np,
-                           kb, ctx->info);
-        const int64_t rem = nb - kb - 1;
-        if (rem <= 0) break;
-        hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)rem, (unsigned)ctx->P), dim3(256), 0, ctx->stream, ctx->K,
-                           ctx->Linv, Np, kb);
-        if (r0 < pe) {
-            // inside the panel: its remaining columns only, K = 64.  Four K-steps per tile: the launch is pure
-            // latency (one wave issues an f64 MFMA every ~138 cycles), so 64x64 tiles — a quarter of the MFMA
-            // chain per wave, four times the workgroups
-            if (ctx->chol_inner_tile == 64) {
-                dim3 grid((unsigned)((pe - r0 + 63) / 64), (unsigned)((Np - r0 + 63) / 64), (unsigned)ctx->P);
-                hipLaunchKernelGGL(k_syrk<64>, grid, dim3(256), 0, ctx->stream, ctx->K, Np, c0, 64, r0, pe);
-            } else {
-                dim3 grid((unsigned)((pe - r0 + 127) / 128), (unsigned)((Np - r0 + 127) / 128), (unsigned)ctx->P);
-                hipLaunchKernelGGL(k_syrk<128>, grid, dim3(256), 0, ctx->stream, ctx->K, Np, c0, 64, r0, pe);
-            }
-        } else {                                        // panel finished: whole trailing matrix, K = panel width
-            launch_syrk_panel(ctx, pb, pe);
-        }
-    }
-    GPB_HIP(hipGetLastError());
-    return 0;
-#endif
 }
 
 // ------------------------------------------------------------------ L^-1 by block doubling
@@ -577,8 +377,7 @@ __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict
 
 int launch_trtri(gpb_ctx* ctx) {
     const int64_t Np = ctx->Np;
-    ctx->linvT_valid = false;                          // the k-major copy (LDS-DMA predict tiles) is rebuilt on its next use
-    ctx->slA_valid = false;                            // the digit planes of L^-1 (gpb_sliced.hip) likewise
+    ctx->slA_valid = false;                            // the digit planes of L^-1 (gpb_sliced.hip) are rebuilt on their next use
     for (int64_t hs = 64; hs < Np; hs *= 2) {
         const int ngroups = (int)((Np + 2 * hs - 1) / (2 * hs));
         // 64-wide tiles while 128-wide ones would leave the chip underfilled or badly quantised (measured faster up

@@ -83,8 +83,6 @@ struct gpb_ctx {
     double* Z = nullptr;           // [P][Np]
     double* K = nullptr;           // [P][Np][Np]  K, overwritten by L (lower) in gp_factor
     double* Linv = nullptr;        // [P][Np][Np]
-    double* LinvT = nullptr;       // [P][Np][Np] k-major copy (LinvT[k][m] = Linv[m][k]) for the LDS-DMA predict tiles, made on first use
-    bool linvT_valid = false;      // ... cleared by every factorisation
     // sliced-integer predict (gpb_sliced.hip, option key 51): int8 digit planes of L^-1 (made on first use after a factorisation)
     // and of the current K*^T batch, row / column scales
     int predict_sliced = 0;        // 0 = fp64 kernel always; 1 = the int8 kernel where its rule admits the context; 2 = rule off (tests)
@@ -95,7 +93,6 @@ struct gpb_ctx {
     int64_t slB_cap = 0;
     bool batch_sliced = false;     // the current batch's K*^T exists as digit planes (launch_kcross), not as fp64
     bool want_kst = false;         // the caller of launch_kcross needs the fp64 K*^T itself (joint covariance)
-    int predict_dma = 0;           // tune key 41: the 64-row predict tiles stage their operands by LDS-DMA (k_predict_static_dma)
     double* T = nullptr;           // [P][Np][Np]  workspace (trtri / K^-1)
     double* yv = nullptr;          // [P][Np]      L^-1 z
     double* alpha = nullptr;       // [P][Np]      K^-1 z
@@ -122,7 +119,6 @@ struct gpb_ctx {
     int balance_shards = 0;        // tune key 36: sharded C loop takes equal slices of the ordered live-row list (1: from 8 ranks on, 2: always; default off)
     int* bal_ws = nullptr;         // its flags / ranks / scatter lists
     int64_t bal_cap = 0;
-    int mma_pipe = 1;              // tune key 37: the 128x128 predict tile reads the next k-group's fragments ahead of the MFMAs
     int sim_rank = 0;              // tune key 32: which rank of sim_ranks the measurement hook plays
     int tile_by_live = 1;          // tune key 28
     int premark = 2;               // tune key 29: the C-driven loop's proposal kernel takes the prior-box test (1) and gathers the rows inside (2)
@@ -169,15 +165,8 @@ struct gpb_ctx {
     int64_t mc_cap = 0;
     int sim_ranks = 0;             // measurement hook: gpb_emcee_run evaluates 1/sim_ranks of every batch (one rank's share)
     int num_cu = 256;               // multiprocessor count of the device
-    int wgs_per_cu64 = 7;           // persistent k_predict<64> workgroups per CU (6 resident at 80 VGPRs; 7 measured 1-2 % better)
-    int wgs_per_cu128w8 = 2;        // ... for the 128-tile, 8-wave variant
-    int wgs_per_cu32 = 4;           // ... for the 64x32 tile
-    int wgs_per_cu64x128 = 5;       // ... for the 64x128 tile (4 resident at 128 VGPRs)
     int64_t narrow_switch = 1280;   // 64x64 tiles when at least this many of them exist per 256 CUs, else 64x32
-    int static64 = 1;               // 64-row predict tiles always launch as k_predict_static
     int chain_batch = 1;            // tune key 40: a chain's emulators of equal padded size share one predict launch
-    int fold_tiles = 0;             // tune key 38: 64x32 / 64x64 predict tiles run as folded row-block pairs (k_predict_fold; measured, not faster)
-    int predict_waves = 4;          // waves per k_predict tile (4 or 8)
     unsigned* tile_counter = nullptr;   // 8 ticket queues (stride 16) + done counter [128]; re-armed by the kernel
     int64_t chol_outer = 0;        // outer panel width of the two-level blocked Cholesky (0 = chosen by size, gpb_chol.hip)
     int chol_pair = 1;             // option key 47: column pairs — every second trailing update by two columns at once (k_chol_update2):
@@ -191,19 +180,12 @@ struct gpb_ctx {
     double* h_res = nullptr;       // page-locked: [lmlbuf doubles | info ints] of an LML evaluation's read-back
     hipStream_t side_stream = nullptr;
     std::vector<hipEvent_t> chol_events;
-    int kx_overlap = 0;            // option key 48: per cent of a batch's GPs in the FIRST of two groups; the second group's K*^T runs on
-                                   // the side stream under the first group's predict launch (0 = one K*^T and one predict launch: default)
-    hipEvent_t ov_ev[2] = {nullptr, nullptr};
-    hipEvent_t prof_open = nullptr;   // profiling: the start event of a predict launch PAIR (kx_overlap) that is still open
-    int kmat_mfma = 1;             // tune key 39: K(X,X) tiles by k_kmat_mfma (dot-product form on the matrix cores, no LDS)
-    int chol_algo = 1;             // 1 = two launches per step, next diagonal block fused into the update (gpb_chol.hip); 0 = round 1
     int syrk_tile = 0;              // tile of the end-of-panel trailing updates (0 = by fill, 64, 128)
     int trtri_tile = 0;            // tile of the triangular-inverse levels (0 = by fill, 64, 128)
     int kinv_tile = 0;             // option key 50: tile of K^-1 = L^-T L^-1 (LML gradient; 0 = by fill, 64, 128)
     int chol_inner_tile = 64;      // tile of the K=64 trailing updates inside an outer panel (64 or 128)
-    int resident_order = 2;         // k_predict with one workgroup per tile: 0 = ticket queues, 1-3 = static orders (2 = snake)
+    int resident_order = 2;         // static 64-row predict launches: order of the tiles over the CUs, 1-3 (2 = snake)
     unsigned* tile_trace = nullptr; // debug hook: [count, capacity, pad x6][capacity][8] records of k_predict tiles
-    int resident_occ = 0;          // tuning hook: co-resident workgroups per CU assumed for the static launch (0 = table)
     int tile_priority = 1;         // k_predict: wave priority by K-loop length (s_setprio)
     int kcross_chunks = 0;         // 64-row chunks of the design per k_kcross workgroup (0 = by grid size)
     int kcross_wpl = 2;            // walkers per lane of k_kcross (1 or 2)
@@ -278,13 +260,7 @@ int launch_predict(gpb_ctx* ctx, const double* Xs_dev, int64_t W, bool need_var,
 int launch_kcross(gpb_ctx* ctx, const double* Xs_dev, int64_t W, const int* nrows_dev, bool allow_planes = true);
 int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, int64_t W, const int* nrows_dev);
 int launch_param_maps(gpb_ctx* const* ctxs, int n, const double* X_dev, int64_t W);      // gpb_pmap.hip
-// p0s / p1s (optional): the launch covers GPs [p0s[e], p1s[e]) of context e instead of all of them (the shared-launch kernels with a
-// table of those GPs: same tiles, same bits).  prof_begin / prof_end: a pair of launches timed as one (ctx->prof_open).
-int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, const int* p0s = nullptr, const int* p1s = nullptr,
-               bool prof_begin = true, bool prof_end = true);
-// K*^T and the mean partials of GPs [p0s[e], p1s[e]) of E contexts (same Np, d; Gram form only) in one launch on `stream`
-int launch_kcross_ranges(gpb_ctx* const* ctxs, const double* const* Xs, int E, const int* p0s, const int* p1s, int64_t W,
-                         const int* nrows_dev, hipStream_t stream);
+int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev);
 int launch_finalize(gpb_ctx* ctx, int64_t W, bool need_var);
 // gpb_sliced.hip: the int8 form of launch_vsq's 128 x 128 launch for ONE context (rule: sliced_applies)
 bool sliced_applies(const gpb_ctx* ctx);

@@ -1604,83 +1604,13 @@ int chain_rows(gpb_ctx* const* ctxs, int E, const double* X_dev, int64_t W, doub
         for (int i = 0; i < nmapped; ++i)
             if ((rc = gpb_param_map(mapped[i], c0->cmp_X, W, mapped[i]->Xs))) { c0->err = mapped[i]->err; return rc; }
     }
-    bool overlap = false;
-#ifdef GPB_DEBUG_VARIANTS
-    // Option key 48 (debug build; c0->kx_overlap = per cent of the batch's GPs in the first group): the GPs of the batch in TWO
-    // groups, in emuList order — K*^T of the second group runs on the side stream while the first group's predict launch has the
-    // matrix pipes.  The kernels are the shared-launch ones over GP ranges: every tile computes what it computes in the one-launch
-    // form (same bits, tested).  MEASURED AND REJECTED (profiles/r05_kcross_overlap.txt): 2-3 % SLOWER at cfg 4, 0.5-2 % slower on
-    // the nine-emulator chain, 15-23 % slower on a rank's share of eight — on this part an fp64 MFMA and fp64 vector work share
-    // the same units, so the cross kernel under the predict launch takes its cycles, and two predict launches have two tails.
-    overlap = c0->kx_overlap > 0 && c0->chain_batch && E + 1 <= 32;
-    int64_t Gall = 0;
-    for (int e = 0; e < E && overlap; ++e) {
-        const gpb_ctx* c = ctxs[e];
-        overlap = c->n_diff == 0 && c->Np == c0->Np && c->dpad == c0->dpad && !c->multi;
-        Gall += c->P;
-    }
-    overlap = overlap && Gall >= 2 && Gall <= GPB_MAX_MULTI_GP;
-    if (overlap) {
-        if (!c0->side_stream) {
-            int lo = 0, hi = 0;
-            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
-                hipStreamCreateWithPriority(&c0->side_stream, hipStreamNonBlocking, lo) != hipSuccess) {
-                c0->err = "gpb: could not create the side stream"; return GPB_E_HIP;
-            }
-        }
-        for (int i = 0; i < 2; ++i)
-            if (!c0->ov_ev[i] && hipEventCreateWithFlags(&c0->ov_ev[i], hipEventDisableTiming) != hipSuccess) {
-                c0->err = "gpb: could not create an event"; return GPB_E_HIP;
-            }
-        int64_t GA = (Gall * c0->kx_overlap + 50) / 100;
-        GA = GA < 1 ? 1 : (GA > Gall - 1 ? Gall - 1 : GA);
-        gpb_ctx* ca[33]; gpb_ctx* cb[33];
-        const double* xa[33]; const double* xb[33];
-        int a0[33], a1[33], b0[33], b1[33], na = 0, nb = 0;
-        int64_t g = 0;
-        for (int e = 0; e < E; ++e) {                  // GPs [0, GA) of the emuList-order list: group A; the rest: group B
-            const int64_t P = ctxs[e]->P, cut = GA - g < 0 ? 0 : (GA - g > P ? P : GA - g);
-            if (cut > 0) { ca[na] = ctxs[e]; xa[na] = Xg[e]; a0[na] = 0; a1[na] = (int)cut; ++na; }
-            if (cut < P) { cb[nb] = ctxs[e]; xb[nb] = Xg[e]; b0[nb] = (int)cut; b1[nb] = (int)P; ++nb; }
-            g += P;
-        }
-        hipError_t he;
-        // the gathered rows (and the parameter maps' outputs) are enqueued on the chain's stream: the side stream starts behind them
-        if ((he = hipEventRecord(c0->ov_ev[0], c0->stream)) != hipSuccess ||
-            (he = hipStreamWaitEvent(c0->side_stream, c0->ov_ev[0], 0)) != hipSuccess) { c0->err = hipGetErrorString(he); return GPB_E_HIP; }
-        if ((rc = launch_kcross_ranges(cb, xb, nb, b0, b1, W, cmpv, c0->side_stream))) { c0->err = cb[0]->err; return rc; }
-        if ((he = hipEventRecord(c0->ov_ev[1], c0->side_stream)) != hipSuccess) { c0->err = hipGetErrorString(he); return GPB_E_HIP; }
-        if ((rc = launch_kcross_ranges(ca, xa, na, a0, a1, W, cmpv, c0->stream))) { c0->err = ca[0]->err; return rc; }
-        ca[0]->hint_from = c0; cb[0]->hint_from = c0;
-        // timing events and unit counts of both launches go to the chain's first context (ca[0] == ctxs[0]); cb[0] borrows its state
-        if ((rc = launch_vsq(ca, na, W, cmpv, a0, a1, true, false))) { c0->err = ca[0]->err; return rc; }
-        if ((he = hipStreamWaitEvent(c0->stream, c0->ov_ev[1], 0)) != hipSuccess) { c0->err = hipGetErrorString(he); return GPB_E_HIP; }
-        if (cb[0] != c0) {                             // the pair is timed as one interval on c0: hand the open event over and back
-            cb[0]->profile = c0->profile; cb[0]->prof_open = c0->prof_open; cb[0]->prof_gps = c0->prof_gps;
-            c0->prof_open = nullptr;
-        }
-        rc = launch_vsq(cb, nb, W, cmpv, b0, b1, false, true);
-        if (cb[0] != c0) {
-            if (c0->profile) {
-                for (auto& ev : cb[0]->prof_events) c0->prof_events.push_back(ev);
-                cb[0]->prof_events.clear();
-                c0->prof_gps = cb[0]->prof_gps;
-                c0->prof_compacted = c0->prof_compacted || cb[0]->prof_compacted;
-                cb[0]->prof_compacted = false;
-                c0->prof_units += cb[0]->prof_units; cb[0]->prof_units = 0.0;
-            }
-            cb[0]->profile = false;
-        }
-        if (rc) { c0->err = cb[0]->err; return rc; }
-    }
-#endif
-    for (int e = 0; e < E && !overlap;) {              // K*^T: one launch per run of emulators of equal padded size and PADDED input
+    for (int e = 0; e < E;) {              // K*^T: one launch per run of emulators of equal padded size and PADDED input
         int n = 1;                                     // count (parameterTrafoPCA emulators keep 17-19 of 20 inputs each: one launch)
         while (c0->chain_batch && e + n < E && ctxs[e + n]->Np == ctxs[e]->Np && ctxs[e + n]->dpad == ctxs[e]->dpad && n < 32) ++n;
         if ((rc = launch_kcross_group(ctxs + e, Xg + e, n, W, cmpv))) { c0->err = ctxs[e]->err; return rc; }
         e += n;
     }
-    for (int e = 0; e < E && !overlap;) {
+    for (int e = 0; e < E;) {
         int n = 1, gps = (int)ctxs[e]->P;
         while (c0->chain_batch && e + n < E && ctxs[e + n]->Np == ctxs[e]->Np && gps + (int)ctxs[e + n]->P <= GPB_MAX_MULTI_GP) {
             gps += (int)ctxs[e + n]->P;
@@ -1953,78 +1883,6 @@ extern "C" int gpb_chain_emcee_run(gpb_ctx* const* ctxs, int E, double* pos_dev,
     return 0;
 }
 
-#ifdef GPB_DEBUG_VARIANTS
-// Measurement hook: the kernels of ONE step of gpb_chain_emcee_run captured into a HIP graph and replayed `reps` times,
-// against `reps` plain calls of one step (both timed with HIP events on the context's stream).  The replay repeats the
-// same step index — the same draws — so it measures launch overhead, it does not sample; pos / lp are scratch copies.
-extern "C" int gpb_debug_graph_probe(gpb_ctx* const* ctxs, int E, const double* pos_dev, const double* lp_dev,
-                                     int64_t nwalkers, uint64_t seed, double a, const double* lo_dev, const double* hi_dev,
-                                     double outside_value, double inside_const, int reps, double* ms_plain, double* ms_graph) {
-    if (!ctxs || E < 1 || !ctxs[0] || !pos_dev || !lp_dev || !ms_plain || !ms_graph || reps < 1) return GPB_E_ARG;
-    gpb_ctx* ctx = ctxs[0];
-    GPB_HIP(hipSetDevice(ctx->device));
-    const int64_t d = chain_ndim(ctx);
-    // the legacy default stream (torch's current stream, usually) cannot be captured: a stream of the probe's own
-    hipStream_t own = nullptr, saved[64];
-    GPB_HIP(hipStreamSynchronize(ctx->stream));
-    GPB_HIP(hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
-    for (int e = 0; e < E && e < 64; ++e) { saved[e] = ctxs[e]->stream; ctxs[e]->stream = own; }
-    struct Restore {
-        gpb_ctx* const* c; int E; hipStream_t* s; hipStream_t own;
-        ~Restore() { (void)hipStreamSynchronize(own); for (int e = 0; e < E && e < 64; ++e) c[e]->stream = s[e]; (void)hipStreamDestroy(own); }
-    } restore{ctxs, E, saved, own};
-    double *pos = nullptr, *lp = nullptr;
-    GPB_HIP(hipMalloc(&pos, sizeof(double) * (size_t)(nwalkers * d)));
-    GPB_HIP(hipMalloc(&lp, sizeof(double) * (size_t)nwalkers));
-    GPB_HIP(hipMemcpyAsync(pos, pos_dev, sizeof(double) * (size_t)(nwalkers * d), hipMemcpyDeviceToDevice, ctx->stream));
-    GPB_HIP(hipMemcpyAsync(lp, lp_dev, sizeof(double) * (size_t)nwalkers, hipMemcpyDeviceToDevice, ctx->stream));
-    auto one_step = [&]() {
-        return gpb_chain_emcee_run(ctxs, E, pos, lp, nwalkers, 1, seed, 0, a, 1, lo_dev, hi_dev, outside_value, inside_const,
-                                   nullptr, nullptr, nullptr);
-    };
-    int rc = 0;
-    for (int i = 0; i < 3 && !rc; ++i) rc = one_step();            // workspaces allocated, clocks up
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    float ms = 0.f;
-    if (!rc) {
-        GPB_HIP(hipEventCreate(&e0));
-        GPB_HIP(hipEventCreate(&e1));
-        GPB_HIP(hipEventRecord(e0, ctx->stream));
-        for (int i = 0; i < reps && !rc; ++i) rc = one_step();
-        GPB_HIP(hipEventRecord(e1, ctx->stream));
-        GPB_HIP(hipEventSynchronize(e1));
-        GPB_HIP(hipEventElapsedTime(&ms, e0, e1));
-        *ms_plain = ms / reps;
-    }
-    if (!rc) {
-        GPB_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        rc = one_step();
-        hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
-        if (!rc && ce != hipSuccess) { ctx->err = std::string("graph capture: ") + hipGetErrorString(ce); rc = GPB_E_HIP; }
-    }
-    if (!rc) {
-        GPB_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        for (int i = 0; i < 3; ++i) GPB_HIP(hipGraphLaunch(exec, ctx->stream));
-        GPB_HIP(hipEventRecord(e0, ctx->stream));
-        for (int i = 0; i < reps; ++i) GPB_HIP(hipGraphLaunch(exec, ctx->stream));
-        GPB_HIP(hipEventRecord(e1, ctx->stream));
-        GPB_HIP(hipEventSynchronize(e1));
-        GPB_HIP(hipEventElapsedTime(&ms, e0, e1));
-        *ms_graph = ms / reps;
-    }
-    if (exec) (void)hipGraphExecDestroy(exec);
-    if (graph) (void)hipGraphDestroy(graph);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(pos);
-    (void)hipFree(lp);
-    return rc;
-}
-
-#endif  // GPB_DEBUG_VARIANTS
 
 extern "C" int gpb_emcee_run(gpb_ctx* ctx, double* pos_dev, double* lp_dev, int64_t nwalkers, int64_t nsteps,
                              uint64_t seed, uint64_t step0, double a, int randomize_split, const double* lo_dev,

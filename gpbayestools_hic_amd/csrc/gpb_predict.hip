@@ -426,36 +426,6 @@ __device__ __forceinline__ void predict_tile(TileLds<T, TN, KB>& lds, int p, int
     } else {                                    // the two wave rows are the halves of one 64-row block
         if (tid < TN) spart[((int64_t)ib * P + p) * Wld + nb + tid] = red[tid] + red[TN + tid];
     }
-#ifdef GPB_DEBUG_VARIANTS
-    if (trace && trace[1] == 0xffffffffu) {
-        // Fusion probe (option key 46, debug build): what folding the block likelihood into this kernel's tail would ADD to it —
-        // every tile releases its partial sums (agent-scope fence) and takes a ticket of its walker tile; the last tile of a
-        // walker tile acquires, reads every partial of its TN walkers (the likelihood's fixed-order sums: nI x P values of
-        // spart and as many of mpart, stood in for by a second pass over spart) and runs a dependent chain as long as the
-        // P x P factorisation of one walker.  Results of the launch are unchanged; profiles/r04_fusion_probe.txt.
-        __shared__ int last_of_walker_tile;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // (a full __threadfence() here — release AND acquire, i.e. an
-        __syncthreads();                                        // L2 invalidate per tile — cost +190 us at 256 rows)
-        if (tid == 0) last_of_walker_tile = atomicAdd(&trace[16 + wt], 1u) == trace[2] - 1u;
-        __syncthreads();
-        if (last_of_walker_tile && trace[4] == 1u) {            // (option value 1: release + ticket only)
-            if (tid == 0) trace[16 + wt] = 0u;
-        } else if (last_of_walker_tile) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            double s = 0.0;
-            const int64_t nblk = Np / 64;
-            for (int pass = 0; pass < 2; ++pass)
-                for (int e = tid; e < (int)nblk * P * TN; e += 64 * NW) {       // (TN walkers fastest: coalesced rows)
-                    const int col = e % TN, bp = e / TN;
-                    s += __builtin_nontemporal_load(&spart[(int64_t)bp * Wld + nb + col]);
-                }
-            for (int it = 0; it < P * P * P / 3 + 2 * P * P; ++it) s = fma(s, 1.0000001, 1e-9);
-            if (s == 12345.678) trace[3] = 1u;
-            if (tid == 0) trace[16 + wt] = 0u;          // re-armed for the next launch
-        }
-        return;
-    }
-#endif
     if (trace && tid == 0) {
         const unsigned slot = atomicAdd(&trace[0], 1u);
         if (slot < trace[1]) {                  // trace[1] = capacity in records
@@ -470,174 +440,10 @@ __device__ __forceinline__ void predict_tile(TileLds<T, TN, KB>& lds, int p, int
     }
 }
 
-#ifdef GPB_DEBUG_VARIANTS
-// ---------------------------------------------------------------------------------------------------------------
-// The 64-row tile with its operands staged by LDS-DMA (global_load_lds_dwordx4: global memory -> LDS without passing
-// through registers; round 3, the variant the round-2 review asked for).  Needs L^-1 k-major (LinvT[k][m] = Linv[m][k],
-// written once per factorisation by k_transpose_linv) so that a K-step's A tile is 16 contiguous 512-byte rows like the
-// K*^T tile; two LDS stages, ONE barrier per K-step: wait for this wave's DMA of step s, barrier (every wave's DMA of
-// step s has landed, every wave is done with the MFMAs of step s - 1), issue the DMA of step s + 1 into the other
-// stage, MFMAs of step s.  No ds_write, no staging registers.  Rows are unpadded: a 16-lane group of the fragment reads
-// covers 128 contiguous bytes whatever the row stride, and nothing is stored to these tiles by ds_write.  Same
-// accumulation order over k, same interleaved m-tile map, same skipped zero products in the diagonal block and the same
-// reduction tree as predict_tile: same bits.
-template <int TN>
-struct __attribute__((aligned(16))) DmaLds {
-    double As[2][16][64];
-    double Bs[2][16][TN];
-};                                                   // TN = 32: 24 KB, 64: 32 KB, 128: 48 KB
-
-template <int TN>
-__device__ __forceinline__ void dma_stage(DmaLds<TN>& L, int buf, const double* __restrict__ At, int64_t Np,
-                                          const double* __restrict__ Bg, int64_t Wld, int64_t k0, int wave, int lane) {
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {                    // A: this wave's rows 4 w .. 4 w + 3, two rows (2 x 32 lanes x 16 B) per instruction
-        const double* src = At + (k0 + 4 * wave + 2 * i + (lane >> 5)) * Np + (lane & 31) * 2;
-        __builtin_amdgcn_global_load_lds((const void*)src, (lds_ptr)&L.As[buf][4 * wave + 2 * i][0], 16, 0, 0);
-    }
-    if (TN == 32) {                                  // B: 256-byte rows, four per instruction
-        const double* src = Bg + (k0 + 4 * wave + (lane >> 4)) * Wld + (lane & 15) * 2;
-        __builtin_amdgcn_global_load_lds((const void*)src, (lds_ptr)&L.Bs[buf][4 * wave][0], 16, 0, 0);
-    } else if (TN == 64) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const double* src = Bg + (k0 + 4 * wave + 2 * i + (lane >> 5)) * Wld + (lane & 31) * 2;
-            __builtin_amdgcn_global_load_lds((const void*)src, (lds_ptr)&L.Bs[buf][4 * wave + 2 * i][0], 16, 0, 0);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const double* src = Bg + (k0 + 4 * wave + i) * Wld + lane * 2;
-            __builtin_amdgcn_global_load_lds((const void*)src, (lds_ptr)&L.Bs[buf][4 * wave + i][0], 16, 0, 0);
-        }
-    }
-}
-
-template <int TN, int IMIN>
-__device__ __forceinline__ void tile_mma_dma(const double (*As)[64], const double (*Bs)[TN], Acc<64, 4, TN>& acc, int lane,
-                                             int m0, int n0) {
-    constexpr int NJ = TN / 32;
-    const int lr = lane & 15, lk = lane >> 4;
-#pragma unroll
-    for (int kk = 0; kk < 16; kk += 4) {
-        double a[2], b[NJ];
-#pragma unroll
-        for (int i = IMIN; i < 2; ++i) a[i] = As[kk + lk][m0 + 32 * i + lr];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) b[j] = Bs[kk + lk][n0 + 16 * j + lr];
-#pragma unroll
-        for (int i = IMIN; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc.v[i][j], 0, 0, 0);
-    }
-}
-
-template <int TN>
-__device__ __forceinline__ void predict_tile_dma(DmaLds<TN>& lds, int p, int ib, int wt, const double* __restrict__ LinvT,
-                                                 const double* __restrict__ KsT, double* __restrict__ spart, int64_t Np,
-                                                 int64_t Wld, int P, int prio_levels) {
-    constexpr int NJ = TN / 32, TNW = TN / 2;
-    const int64_t mb = (int64_t)ib * 64, nb = (int64_t)wt * TN;
-    if (prio_levels > 0) set_wave_prio((4 * ib) / prio_levels);
-    Acc<64, 4, TN> acc;
-    acc_zero<64, 4, TN>(acc);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = wm * 16, n0 = wn * TNW;          // the wave rows own the 16-row m-tiles alternately (as gemm_tile_loop TRI)
-    const double* At = LinvT + (int64_t)p * Np * Np + mb;
-    const double* Bg = KsT + (int64_t)p * Np * Wld + nb;
-    const int nsteps = (int)((mb + 64) / 16);        // k in [0, mb + 64): the last four steps are the diagonal block
-    dma_stage<TN>(lds, 0, At, Np, Bg, Wld, 0, wave, lane);
-    for (int s = 0; s < nsteps; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (s + 1 < nsteps) dma_stage<TN>(lds, (s + 1) & 1, At, Np, Bg, Wld, (int64_t)(s + 1) * 16, wave, lane);
-        if (s + 2 < nsteps) tile_mma_dma<TN, 0>(lds.As[s & 1], lds.Bs[s & 1], acc, lane, m0, n0);
-        else                tile_mma_dma<TN, 1>(lds.As[s & 1], lds.Bs[s & 1], acc, lane, m0, n0);   // m-tiles 0, 1: zeros from k = mb + 32 on
-    }
-    // the reduction tree of predict_tile (TRI form, T = 64): wave row 0 starts the two chains, wave row 1 finishes them
-    double* part = &lds.As[0][0][0];                 // [chain c][j][wn][lane]: 2 NJ 2 64 doubles <= 8 KB of the A stages
-    double* red = &lds.Bs[0][0][0];
-    __syncthreads();
-    if (wm == 0) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                double v = 0.0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v = fma(acc.v[c][j][r], acc.v[c][j][r], v);
-                part[((c * NJ + j) * 2 + wn) * 64 + lane] = v;
-            }
-    }
-    __syncthreads();
-    if (wm == 1) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            double h[2];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                double v = part[((c * NJ + j) * 2 + wn) * 64 + lane];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v = fma(acc.v[c][j][r], acc.v[c][j][r], v);
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 32);
-                h[c] = v;
-            }
-            if (lane < 16) red[wn * TNW + 16 * j + lane] = h[0] + h[1];
-        }
-    }
-    __syncthreads();
-    if (tid < TN) spart[((int64_t)ib * P + p) * Wld + nb + tid] = red[tid];
-}
-#endif  // GPB_DEBUG_VARIANTS
-
-// xcd_mode 3: "super-blocks" = (GP, group of 4 consecutive row blocks) x all walker tiles, heaviest groups first,
-// dealt round-robin to the eight queues.  With 2 x 32 resident 128x128 workgroups an XCD has about one
-// super-block in flight: its tiles share 4 L^-1 row panels and nW K*^T column panels through that XCD's L2.
-__device__ __forceinline__ unsigned superblock_queue_len(unsigned qx, int nI, int nW, int P) {
-    const int nG = (nI + 3) / 4;
-    unsigned n = 0;
-    for (int r = 0; 8 * r < nG * P; ++r) {
-        const int s = 8 * r + ((r & 1) ? 7 - (int)qx : (int)qx);     // snake deal: balanced queue totals
-        if (s >= nG * P) continue;
-        const int c = s / P, rows = (nI - 4 * c < 4) ? nI - 4 * c : 4;
-        n += (unsigned)(rows * nW);
-    }
-    return n;
-}
 
 // ticket t of queue qx -> tile (GP p, row block ib, walker tile wt); false for the padding of xcd_mode 1
 __device__ __forceinline__ bool decode_tile(int xcd_mode, unsigned t, unsigned qx, int nI, int nW, int P, int& p,
                                             int& ib, int& wt) {
-    if (xcd_mode == 3) {
-        const int nG = (nI + 3) / 4;
-        unsigned u = t;
-        for (int r = 0; 8 * r < nG * P; ++r) {
-            const int s = 8 * r + ((r & 1) ? 7 - (int)qx : (int)qx);
-            if (s >= nG * P) continue;
-            const int c = s / P, rows = (nI - 4 * c < 4) ? nI - 4 * c : 4;
-            const unsigned cnt = (unsigned)(rows * nW);
-            if (u < cnt) {
-                p = s - c * P;
-                ib = nI - 1 - 4 * c - (int)(u / (unsigned)nW);
-                wt = (int)(u % (unsigned)nW);
-                return true;
-            }
-            u -= cnt;
-        }
-        return false;
-    }
-    if (xcd_mode == 2) {
-        const int j = (int)t / (nI * nW), rem = (int)t - j * (nI * nW);
-        p = (int)qx + 8 * j;
-        ib = nI - 1 - rem / nW;
-        wt = rem % nW;
-        return true;
-    }
     const int b = (int)(t * 8u + qx);
     int g;
     if (xcd_mode == 1) {
@@ -684,20 +490,13 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (T == 64 && TN 
     // Tile -> queue maps (xcd_mode), all heaviest-row-block-first within a queue:
     //   0: queue = walker tile % 8   (each XCD keeps its own K*^T columns; all GPs interleaved)
     //   1: queue = (row block, GP) group % 8   (small W: each L^-1 row block is fetched by one XCD)
-    //   2: queue = GP % 8: an XCD works through ONE GP at a time, so the ~64 tiles it has in flight share
-    //      4 L^-1 row panels and 16 K*^T column panels instead of ~32 + ~20 (L2 hit rate, fabric traffic)
-    //   3: queue = super-block % 8 (GP x group of 4 row blocks, heaviest groups first): the same sharing, dealt
-    //      out at a quarter of a GP so that the queues stay balanced
-    //   (measured in round 3 and dropped: map 0's queues walked GP by GP, so that an XCD's resident tiles are all row blocks
-    //   of two GPs and a K*^T panel is fetched once for its 16 row blocks: 20 % less fabric traffic, 15 % MORE time — the
-    //   heaviest-first order over all GPs is worth more than the reuse; profiles/r03_xcd_map_ab.txt)
+    //   (maps built for L2 reuse — one GP per XCD at a time, super-blocks of four row blocks — cut the fabric traffic by 20-55 %
+    //   and were 1-15 % SLOWER for this fp64 kernel: the heaviest-first order over all GPs is worth more than the reuse,
+    //   profiles/r03_xcd_map_ab.txt.  The int8 kernel, which IS bound by its operand feed, uses super-blocks: gpb_sliced.hip)
     const int x = blockIdx.x & 7;
     for (int s = 0; s < 8; ++s) {
         const unsigned qx = (unsigned)((x + s) & 7);
-        unsigned nq;
-        if (xcd_mode == 3)      nq = superblock_queue_len(qx, nI, nW, P);
-        else if (xcd_mode == 2) nq = ((unsigned)P > qx) ? (((unsigned)P - qx + 7u) / 8u) * (unsigned)(nI * nW) : 0u;
-        else                    nq = (nblocks > qx) ? (nblocks - qx + 7u) / 8u : 0u;
+        const unsigned nq = (nblocks > qx) ? (nblocks - qx + 7u) / 8u : 0u;
         for (;;) {
             if (threadIdx.x == 0) s_ticket = atomicAdd(&queue[qx * 16], 1u);
             __syncthreads();
@@ -755,51 +554,6 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (KB == 32 ? 3 :
         predict_tile<T, NW, TN, KB, PIPE>(lds, p, ib, wt, Linv, KsT, spart, Np, Wld, P, prio_levels, trace, tri_skip);
 }
 
-#ifdef GPB_DEBUG_VARIANTS
-// k_predict_static with the LDS-DMA tile (same tile list and order; map 0 / 1)
-template <int TN>
-__global__ __launch_bounds__(256, (TN == 128 ? 3 : 4)) void k_predict_static_dma(
-    const double* __restrict__ LinvT, const double* __restrict__ KsT, double* __restrict__ spart, int64_t Np, int64_t Wld,
-    int P, int nI, int nW, int xcd_mode, unsigned nblocks, int order, unsigned ncu_x, int prio_levels,
-    const int* __restrict__ nrows) {
-    __shared__ DmaLds<TN> lds;
-    if (nrows) {
-        nW = (*nrows + TN - 1) / TN;
-        nblocks = (unsigned)((xcd_mode == 1 ? ((P * nI + 7) / 8) * 8 : P * nI) * nW);
-    }
-    const unsigned qx = blockIdx.x & 7u;
-    const unsigned nq = (nblocks > qx) ? (nblocks - qx + 7u) / 8u : 0u;
-    unsigned t = blockIdx.x >> 3;
-    if (t >= nq) return;
-    const unsigned k = t / ncu_x, c = t - k * ncu_x;
-    if (order == 2) {
-        if ((k & 1u) && (k + 1u) * ncu_x <= nq) t = k * ncu_x + (ncu_x - 1u - c);
-    } else if (order == 3) {
-        const unsigned n2 = (nq / (2u * ncu_x)) * (2u * ncu_x);
-        if (t < n2) {
-            const unsigned kp = k >> 1;
-            const unsigned pi = kp * ncu_x + ((kp & 1u) ? (ncu_x - 1u - c) : c);
-            t = 2u * pi + (k & 1u);
-        }
-    }
-    int p, ib, wt;
-    if (decode_tile(xcd_mode, t, qx, nI, nW, P, p, ib, wt))
-        predict_tile_dma<TN>(lds, p, ib, wt, LinvT, KsT, spart, Np, Wld, P, prio_levels);
-}
-
-// LinvT[p][k][m] = Linv[p][m][k] (the k-major copy the LDS-DMA tiles read), 64x64 blocks through LDS
-__global__ __launch_bounds__(256) void k_transpose_linv(const double* __restrict__ Linv, double* __restrict__ LinvT,
-                                                        int64_t Np) {
-    __shared__ double s[64][65];
-    const int64_t off = (int64_t)blockIdx.z * Np * Np, r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) s[ty + 4 * j][tx] = Linv[off + (r0 + ty + 4 * j) * Np + c0 + tx];
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 16; ++j) LinvT[off + (c0 + ty + 4 * j) * Np + r0 + tx] = s[tx][ty + 4 * j];
-}
-#endif  // GPB_DEBUG_VARIANTS
 
 // ---------------------------------------------------------------------------------------------------------------
 // Chains of several emulators (Chain.emuList: nine emulators, 63 GPs in the reference's analyses): ONE launch over the GPs
@@ -829,10 +583,7 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (T == 64 && TN 
     const int x = blockIdx.x & 7;
     for (int s = 0; s < 8; ++s) {                      // as k_predict: eight XCD-affine ticket queues, LPT order, stealing
         const unsigned qx = (unsigned)((x + s) & 7);
-        unsigned nq;
-        if (xcd_mode == 3)      nq = superblock_queue_len(qx, nI, nW, G);
-        else if (xcd_mode == 2) nq = ((unsigned)G > qx) ? (((unsigned)G - qx + 7u) / 8u) * (unsigned)(nI * nW) : 0u;
-        else                    nq = (nblocks > qx) ? (nblocks - qx + 7u) / 8u : 0u;
+        const unsigned nq = (nblocks > qx) ? (nblocks - qx + 7u) / 8u : 0u;
         for (;;) {
             if (threadIdx.x == 0) s_ticket = atomicAdd(&queue[qx * 16], 1u);
             __syncthreads();
@@ -884,152 +635,6 @@ __global__ __launch_bounds__(64 * NW, (T == 128 && NW == 4 ? 2 : (KB == 32 ? 3 :
     }
 }
 
-#ifdef GPB_DEBUG_VARIANTS
-// ---------------------------------------------------------------------------------------------------------------
-// Folded tiles for small walker batches (a rank's share of a sharded ensemble: 128 - 512 rows).
-// L^-1 is lower triangular, so the K loop of row block ib is 64 (ib + 1) long: one tile per workgroup leaves a CU with
-// tiles of K = 2048 ... 64, its matrix pipe shared by five, four, ... and finally ONE wave per SIMD (one wave alone
-// issues an fp64 MFMA every ~138 cycles against the pipe's 64: profiles/r01_mfma_f64_issue_rate.txt) — the heaviest
-// tile alone ran 208 of the 64x32 launch's 232 us.  Here the triangle is folded into a rectangle: a workgroup owns the
-// row blocks a AND nI - 1 - a of one (GP, walker tile) — together always nI + 1 blocks of K — and runs them as ONE
-// K loop: over k < 64 (a + 1) both blocks multiply the same staged K*^T tile (twice the MFMAs per barrier and per byte
-// of K*^T), beyond it only the heavy block goes on.  Every workgroup of the launch has the same length, five of them
-// are resident per CU from the first cycle to the last, and nothing is left to balance.  A (row block, walker) sum
-// sees exactly the MFMA sequence and the reduction tree of the one-tile kernels: same bits.
-// MEASURED, NOT FASTER (profiles/r03_small_batch_notes.txt: 198 vs 189 us at 256 rows, 125 vs 106 us at ~120): the one-tile
-// launch already keeps the matrix pipe 80 % busy (PMC), its tail is not what the time goes to.  Debug builds only.
-// Units are dealt to the XCDs in contiguous ranges of (GP, a) groups (blockIdx % 8 = XCD under round-robin dispatch): the
-// nW units of a group read the same two L^-1 row panels at the same time, and an XCD sees the K*^T panels of one or two
-// GPs only — each L^-1 block leaves HBM / the Infinity Cache once.
-template <int TN>
-struct __attribute__((aligned(16))) FoldLds {
-    double Ah[BK][64 + 16];      // heavy row block  nI - 1 - a, k-major
-    double Al[BK][64 + 16];      // light row block  a
-    double Bs[BK][TN + 16];      // K*^T tile
-};
-
-template <int TN>
-__global__ __launch_bounds__(256, (TN == 32 ? 5 : 4)) void k_predict_fold(
-    const double* __restrict__ Linv, const double* __restrict__ KsT, double* __restrict__ spart, int64_t Np, int64_t Wld,
-    int P, int nI, int nW, const int* __restrict__ nrows) {
-    __shared__ FoldLds<TN> lds;
-    if (nrows) nW = (*nrows + TN - 1) / TN;            // compacted batch: the walker tiles that hold rows
-    const int nF = (nI + 1) / 2, G = P * nF;
-    const int x = blockIdx.x & 7, t = blockIdx.x >> 3;
-    const int g0 = (int)(((int64_t)x * G) / 8), g1 = (int)(((int64_t)(x + 1) * G) / 8);
-    if (nW <= 0) return;
-    const int gl = t / nW, wt = t - gl * nW;
-    const int g = g0 + gl;
-    if (g >= g1) return;                               // uniform: the whole workgroup leaves
-    const int p = g / nF, a = g - p * nF;
-    const int ibh = nI - 1 - a, ibl = a;
-    const bool fold = ibl < ibh;                       // an odd number of row blocks leaves the middle one alone
-    constexpr int NJ = TN / 32;                        // wave tile: 32 rows of each block x TN / 2 walkers
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = wm * 32, n0 = wn * (TN / 2);
-    const int lr = lane & 15, lk = lane >> 4;
-    const double* Ag = Linv + (int64_t)p * Np * Np;
-    const double* Bg = KsT + (int64_t)p * Np * Wld;
-    const int64_t mbh = (int64_t)ibh * 64, mbl = (int64_t)ibl * 64, nb = (int64_t)wt * TN;
-    const int64_t k_joint = fold ? mbl + 64 : 0, k_end = mbh + 64;
-    d4 acch[2][NJ], accl[2][NJ];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) { acch[i][j] = d4{0.0, 0.0, 0.0, 0.0}; accl[i][j] = d4{0.0, 0.0, 0.0, 0.0}; }
-    Frag<64, 4, BK> fah, fal;
-    Frag<TN, 4, BK> fb;
-    gload_trans<64, 4, BK, true>(Ag, Np, 0, mbh, 64, fah, tid);
-    if (fold) gload_trans<64, 4, BK, true>(Ag, Np, 0, mbl, 64, fal, tid);
-    gload_direct<TN, 4, BK, true>(Bg, Wld, 0, nb, TN, fb, tid);
-    int64_t k0 = 0;
-    for (; k0 < k_joint; k0 += BK) {                   // both row blocks against the same K*^T tile
-        __syncthreads();
-        lstore_trans<64, 4, BK>(lds.Ah, fah, tid);
-        lstore_trans<64, 4, BK>(lds.Al, fal, tid);
-        lstore_direct<TN, 4, BK>(lds.Bs, fb, tid);
-        __syncthreads();
-        const int64_t kn = k0 + BK;                    // (k_end > k_joint: there is always a next step here)
-        gload_trans<64, 4, BK, true>(Ag, Np, kn, mbh, 64, fah, tid);
-        if (kn < k_joint) gload_trans<64, 4, BK, true>(Ag, Np, kn, mbl, 64, fal, tid);
-        gload_direct<TN, 4, BK, true>(Bg, Wld, kn, nb, TN, fb, tid);
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 4) {
-            double ah[2], al[2], b[NJ];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = lds.Ah[kk + lk][m0 + 16 * i + lr + lds_skew(kk)];
-                al[i] = lds.Al[kk + lk][m0 + 16 * i + lr + lds_skew(kk)];
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) b[j] = lds.Bs[kk + lk][n0 + 16 * j + lr + lds_skew(kk)];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    acch[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[i], b[j], acch[i][j], 0, 0, 0);
-                    accl[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(al[i], b[j], accl[i][j], 0, 0, 0);
-                }
-        }
-    }
-    for (; k0 < k_end; k0 += BK) {                     // the heavy block alone
-        __syncthreads();
-        lstore_trans<64, 4, BK>(lds.Ah, fah, tid);
-        lstore_direct<TN, 4, BK>(lds.Bs, fb, tid);
-        __syncthreads();
-        const int64_t kn = k0 + BK;
-        if (kn < k_end) {
-            gload_trans<64, 4, BK, true>(Ag, Np, kn, mbh, 64, fah, tid);
-            gload_direct<TN, 4, BK, true>(Bg, Wld, kn, nb, TN, fb, tid);
-        }
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 4) {
-            double ah[2], b[NJ];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) ah[i] = lds.Ah[kk + lk][m0 + 16 * i + lr + lds_skew(kk)];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) b[j] = lds.Bs[kk + lk][n0 + 16 * j + lr + lds_skew(kk)];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acch[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[i], b[j], acch[i][j], 0, 0, 0);
-        }
-    }
-    // sum of squares over the rows: predict_tile's tree for a 64-row block held by two wave rows (one chain over a wave's
-    // two m-tiles = 32 rows, the lane groups, then rows 0-31 + rows 32-63)
-    double* red = &lds.Bs[0][0];                       // [2 wave rows][TN]: BK * (TN + 16) doubles are plenty
-    double sh_[NJ], sl_[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        double v = 0.0, u = 0.0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { v = fma(acch[i][j][r], acch[i][j][r], v); u = fma(accl[i][j][r], accl[i][j][r], u); }
-        v += __shfl_xor(v, 16); u += __shfl_xor(u, 16);
-        v += __shfl_xor(v, 32); u += __shfl_xor(u, 32);
-        sh_[j] = v; sl_[j] = u;
-    }
-    __syncthreads();                                   // all waves are done reading the operand tiles
-    if (lane < 16) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) red[wm * TN + n0 + 16 * j + lane] = sh_[j];
-    }
-    __syncthreads();
-    if (tid < TN) spart[((int64_t)ibh * P + p) * Wld + nb + tid] = red[tid] + red[TN + tid];
-    if (!fold) return;
-    __syncthreads();
-    if (lane < 16) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) red[wm * TN + n0 + 16 * j + lane] = sl_[j];
-    }
-    __syncthreads();
-    if (tid < TN) spart[((int64_t)ibl * P + p) * Wld + nb + tid] = red[tid] + red[TN + tid];
-}
-
-#endif  // GPB_DEBUG_VARIANTS
 
 __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ mpart, const double* __restrict__ spart,
                                                   const double* __restrict__ amp, const double* __restrict__ noise,
@@ -1238,68 +843,10 @@ int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, in
     return 0;
 }
 
-// The same launch for GP RANGES of the contexts, on a stream of the caller's choice (option key 48: a batch's GPs in two groups, the
-// second group's K*^T under the first group's predict launch).  The caller has checked that every context qualifies for the shared
-// launch (Gram form throughout, equal Np / d / dpad).  A GP's workgroups compute what they compute in any other launch: same bits.
-int launch_kcross_ranges(gpb_ctx* const* ctxs, const double* const* Xs, int E, const int* p0s, const int* p1s, int64_t W,
-                         const int* nrows_dev, hipStream_t stream) {
-    gpb_ctx* ctx = ctxs[0];
-    if (E < 1 || E > MAX_KX_CTX) GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_kcross_ranges: table size");
-    const int64_t Wuse = round_up(W, WPAD);
-    KxTable tab;
-    int G = 0;
-    for (int e = 0; e < E; ++e) {
-        gpb_ctx* c = ctxs[e];
-        if (c->multi || !c->factored || W > c->Wcap || c->n_diff != 0 || c->Np != ctx->Np || c->dpad != ctx->dpad ||
-            p0s[e] < 0 || p1s[e] > c->P || p0s[e] >= p1s[e])
-            GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_kcross_ranges over a context that does not qualify");
-        c->Wld = Wuse;
-        c->last_W = W;
-        c->batch_sliced = false;
-        tab.c[e] = KxCtx{Xs[e], c->Xc, c->ls, c->amp, c->alpha, c->dnorm, c->muS, c->KsT, c->mpart, (int)c->N, (int)c->P,
-                         c->kind, G, p0s[e], (int)c->d};
-        G += p1s[e] - p0s[e];
-    }
-    tab.E = E;
-    const int nchunk = (int)((ctx->Np + KX_CHUNK - 1) / KX_CHUNK);
-    const int wpl = (ctx->kcross_wpl == 2 && ctx->dpad <= 32 && Wuse >= 256 && Wuse % 128 == 0) ? 2 : 1;
-    int cpw = ctx->kcross_chunks;
-    if (cpw <= 0) {
-        const int64_t Wgeo = nrows_dev ? round_up(Wuse / 2, 64 * wpl) : Wuse;
-        const int64_t wgs1 = (Wgeo / (64 * wpl)) * nchunk * G;
-        cpw = 1;
-        while (cpw < 8 && wgs1 / (2 * cpw) >= 4 * (int64_t)ctx->num_cu) cpw *= 2;
-    }
-    if (Wuse / (64 * wpl) > 65535) GPB_FAIL(GPB_E_ARG, "gpb: more than 65535 walker tiles (4 million rows) in one batch: split it");
-    dim3 grid((unsigned)((nchunk + cpw - 1) / cpw), (unsigned)G, (unsigned)(Wuse / (64 * wpl)));
-#define GPB_KXM(DP)                                                                                              \
-    do {                                                                                                         \
-        if (wpl == 2)                                                                                            \
-            hipLaunchKernelGGL((k_kcross_multi<DP, (DP <= 32 ? 2 : 1)>), grid, dim3(256), 0, stream, tab, W,      \
-                               (int)ctx->d, ctx->Np, Wuse, cpw, nrows_dev);                                       \
-        else                                                                                                     \
-            hipLaunchKernelGGL((k_kcross_multi<DP, 1>), grid, dim3(256), 0, stream, tab, W, (int)ctx->d,         \
-                               ctx->Np, Wuse, cpw, nrows_dev);                                                   \
-    } while (0)
-    switch (ctx->dpad) {
-        case 8: GPB_KXM(8); break;
-        case 16: GPB_KXM(16); break;
-        case 20: GPB_KXM(20); break;
-        case 24: GPB_KXM(24); break;
-        case 32: GPB_KXM(32); break;
-        case 48: GPB_KXM(48); break;
-        default: GPB_KXM(64); break;
-    }
-#undef GPB_KXM
-    GPB_HIP(hipGetLastError());
-    return 0;
-}
-
 // V = L^-1 K*^T with the fused sum of squares for the GPs of E contexts in one launch (E = 1: an emulator's own launch;
 // E > 1: the emulators of a chain whose designs pad to the same Np — see k_predict_multi).  All contexts: same Np, same
 // batch (launch_kcross done), same stream.  Timing events and the unit count go to ctxs[0].
-int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, const int* p0s, const int* p1s, bool prof_begin,
-               bool prof_end) {
+int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev) {
     gpb_ctx* ctx = ctxs[0];
     const int64_t Wuse = round_up(W, WPAD);
     if (E > 1) {
@@ -1308,12 +855,11 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, con
         bool any_sliced = false;
         for (int e = 0; e < E; ++e) any_sliced = any_sliced || ctxs[e]->batch_sliced;
         if (any_sliced) {
-            if (p0s) GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_vsq: GP ranges over a sliced batch");
             for (int e = 0; e < E; ++e) {
                 gpb_ctx* one[1] = {ctxs[e]};
                 const bool prof = ctxs[e]->profile;
                 ctxs[e]->profile = ctx->profile;
-                const int rc = launch_vsq(one, 1, W, nrows_dev, nullptr, nullptr, true, true);
+                const int rc = launch_vsq(one, 1, W, nrows_dev);
                 if (ctxs[e] != ctx) {
                     for (auto& ev : ctxs[e]->prof_events) ctx->prof_events.push_back(ev);
                     ctxs[e]->prof_events.clear();
@@ -1330,11 +876,9 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, con
     for (int e = 0; e < E; ++e) {
         if (ctxs[e]->Np != ctx->Np || ctxs[e]->Wld != Wuse || ctxs[e]->stream != ctx->stream)
             GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_vsq over contexts of different shape");
-        if (p0s && (p0s[e] < 0 || p1s[e] > ctxs[e]->P || p0s[e] >= p1s[e]))
-            GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_vsq: GP range");
-        Gsum += p0s ? p1s[e] - p0s[e] : ctxs[e]->P;
+        Gsum += ctxs[e]->P;
     }
-    const bool multi = E > 1 || p0s != nullptr;        // a GP range of one context: the table form of the same tiles
+    const bool multi = E > 1;
     // leading all-zero rows of K*^T (the designs' padding, in front: gp_set_impl) common to every context of the launch, in whole
     // 16-deep K-steps: the tiles start their K loops behind them
     int64_t kskip = ctx->Np;
@@ -1394,41 +938,21 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, con
         if (ctx->force_tile == 65) { T = 64; TN = 128; }        // 64 rows x 128 walkers
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (ctx->profile) {                    // live HIP-event timing of the dominant kernel (bench.py)
-            if (prof_begin) {
-                GPB_HIP(hipEventCreate(&e0));
-                GPB_HIP(hipEventRecord(e0, ctx->stream));
-                if (!prof_end) ctx->prof_open = e0;            // the first launch of a pair: its partner closes the interval
-            } else {
-                e0 = ctx->prof_open;
-                ctx->prof_open = nullptr;
-            }
-            if (prof_end) GPB_HIP(hipEventCreate(&e1));
+            GPB_HIP(hipEventCreate(&e0));
+            GPB_HIP(hipEventRecord(e0, ctx->stream));
+            GPB_HIP(hipEventCreate(&e1));
         }
         const int nI = (T == 128) ? (int)((ctx->Np + 127) / 128) : nI64, nW = (int)(Wuse / TN);
         // which operand is larger decides the XCD affinity: L^-1 (P Np^2/2) or K*^T (P Np W)
         int xcd_rows = (2 * Wuse < ctx->Np) ? 1 : 0;
-        if (ctx->force_xcd >= 0) xcd_rows = ctx->force_xcd;      // 0, 1 or 2 (GP-affine)
+        if (ctx->force_xcd >= 0) xcd_rows = ctx->force_xcd;      // 0 or 1
         const int64_t ngroups = GP * nI;
         const int64_t nblocks = (xcd_rows == 1) ? ((ngroups + 7) / 8) * 8 * nW : ngroups * nW;
-        const int nwv = ctx->predict_waves;             // 4 or 8 waves per tile
-        const int per_cu = (T == 128) ? (nwv == 8 ? ctx->wgs_per_cu128w8 : 2)
-                                      : (TN == 32 ? ctx->wgs_per_cu32 : (TN == 128 ? ctx->wgs_per_cu64x128 : ctx->wgs_per_cu64));
-        const int64_t slots = (int64_t)ctx->num_cu * per_cu;
-        // one workgroup per tile and all of them co-resident: nothing is left to balance dynamically, so a static
-        // kernel deals the tiles out instead.  Co-residency per CU of k_predict_static (its VGPRs / LDS):
-        // 128x128: 2, 64x128: 4, 64x64: 6 (80 VGPRs), 64x32: 8.
-        int occ = (T == 128) ? 2 : (TN == 32 ? 8 : (TN == 128 ? 4 : 6));
-        if (ctx->resident_occ > 0) occ = ctx->resident_occ;
-        // The 64-row shapes always launch static, co-resident or not: beyond co-residency the hardware dispatcher
-        // hands the next workgroup (= next tile in weight order) to whichever CU frees a slot, which balances as
-        // well as the ticket queues do, and the static kernel is the lighter one (7-12 % faster at 384-768
-        // walkers than the persistent form of the same tile shape).
-        const bool all_resident = nblocks <= (int64_t)ctx->num_cu * occ;
-        const int resident = (nwv == 4 && xcd_rows < 2 && (all_resident || (T == 64 && ctx->static64)))
-                                 ? ctx->resident_order : 0;      // order 0 = ticket queues on request
-        const unsigned grid = (unsigned)((resident || nblocks < slots) ? nblocks : slots);
-        const unsigned grid128 = (unsigned)(nblocks < slots ? nblocks : slots);      // the persistent 128x128 launch
-        (void)grid; (void)grid128;
+        // the persistent 128 x 128 launch: two workgroups per CU (their registers), or one per tile when fewer tiles exist; the
+        // 64-row shapes launch static, one workgroup per tile in weight order — beyond co-residency the hardware dispatcher hands the
+        // next workgroup to whichever CU frees a slot, which balances as well as ticket queues do (7-12 % faster at 384-768 walkers)
+        const int64_t slots = (int64_t)ctx->num_cu * 2;
+        const unsigned grid128 = (unsigned)(nblocks < slots ? nblocks : slots);
         if (ctx->batch_sliced) {
             // the int8 kernel (option key 51, gpb_sliced.hip) on the digit planes k_kcross left: same partials' layout and meaning
             if (multi) GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_vsq: a sliced batch in a shared launch");
@@ -1439,13 +963,13 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, con
             PredTable tab;
             int g = 0;
             for (int e = 0; e < E; ++e)
-                for (int pp = p0s ? p0s[e] : 0; pp < (p0s ? p1s[e] : (int)ctxs[e]->P); ++pp, ++g)
+                for (int pp = 0; pp < (int)ctxs[e]->P; ++pp, ++g)
                     tab.gp[g] = PredGP{ctxs[e]->Linv, ctxs[e]->KsT, ctxs[e]->spart, (int)ctxs[e]->P, pp};
             const int order = ctx->resident_order ? ctx->resident_order : 2;
-            const int xr = xcd_rows < 2 ? xcd_rows : 0;
-            const unsigned nb_s = (unsigned)(xr == 1 ? ((ngroups + 7) / 8) * 8 * nW : ngroups * nW);
+            const int xr = xcd_rows;
+            const unsigned nb_s = (unsigned)nblocks;
             if (T == 128)
-                hipLaunchKernelGGL((k_predict_multi<128, 4, 128, 16, true>), dim3((unsigned)(nblocks < slots ? nblocks : slots)),
+                hipLaunchKernelGGL((k_predict_multi<128, 4, 128, 16, true>), dim3(grid128),
                                    dim3(256), 0, ctx->stream, tab, ctx->Np, ctx->Wld, (int)GP, nI, nW, xcd_rows,
                                    ctx->tile_counter, (unsigned)nblocks, ctx->tile_trace, tri_arg, nrows_dev);
             else if (TN == 32)
@@ -1461,76 +985,15 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, con
                                    ctx->Wld, (int)GP, nI, nW, xr, nb_s, order, (unsigned)(ctx->num_cu / 8),
                                    ctx->tile_priority ? nI : 0, ctx->tile_trace, tri_arg, nrows_dev);
         } else {
-#ifdef GPB_DEBUG_VARIANTS
-#define GPB_PRED(TT, WW, NN, KK)                                                                                 \
-    do {                                                                                                         \
-        if (resident)                                                                                            \
-            hipLaunchKernelGGL((k_predict_static<TT, WW, NN, KK>), dim3(grid), dim3(64 * WW), 0, ctx->stream,     \
-                               ctx->Linv, ctx->KsT, ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xcd_rows, \
-                               (unsigned)nblocks, resident, (unsigned)(ctx->num_cu / 8),                          \
-                               ctx->tile_priority ? nI : 0, ctx->tile_trace, tri_arg, nrows_dev);           \
-        else                                                                                                     \
-            hipLaunchKernelGGL((k_predict<TT, WW, NN, KK>), dim3(grid), dim3(64 * WW), 0, ctx->stream, ctx->Linv,  \
-                               ctx->KsT, ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xcd_rows,            \
-                               ctx->tile_counter, (unsigned)nblocks, ctx->tile_trace, tri_arg, nrows_dev);   \
-    } while (0)
-        // the measured-and-rejected variants (tools, A/B sweeps and the variant tests; built with -DGPB_DEBUG_VARIANTS into
-        // libgpbayes_debug.so): persistent 64-row tiles, 8-wave tiles, the 128x128 tile without the fragment read-ahead or
-        // as a static launch, folded row-block pairs.  (32-deep K-steps for the 64-row tiles were measured: within 2.5 %
-        // either way, not kept.)
-        if (ctx->predict_dma && T == 64 && nwv == 4) {
-            // LDS-DMA tiles (tune key 41; measured, 0-5 % slower: profiles/r03_small_batch_notes.txt): need the k-major copy of
-            // L^-1, made here after a new factorisation
-            if (!ctx->LinvT) GPB_HIP(pool_malloc_t(&ctx->LinvT, sizeof(double) * (size_t)(ctx->P * ctx->Np * ctx->Np)));
-            if (!ctx->linvT_valid) {
-                hipLaunchKernelGGL(k_transpose_linv, dim3((unsigned)(ctx->Np / 64), (unsigned)(ctx->Np / 64), (unsigned)ctx->P),
-                                   dim3(256), 0, ctx->stream, ctx->Linv, ctx->LinvT, ctx->Np);
-                ctx->linvT_valid = true;
-            }
-            const int order = ctx->resident_order ? ctx->resident_order : 2;
-            const int xr = xcd_rows < 2 ? xcd_rows : 0;
-            const unsigned nb_s = (unsigned)(xr == 1 ? ((ngroups + 7) / 8) * 8 * nW : ngroups * nW);
-#define GPB_PRED_DMA(NN)                                                                                            \
-    hipLaunchKernelGGL((k_predict_static_dma<NN>), dim3(nb_s), dim3(256), 0, ctx->stream, ctx->LinvT, ctx->KsT, ctx->spart, \
-                       ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xr, nb_s, order, (unsigned)(ctx->num_cu / 8),         \
-                       ctx->tile_priority ? nI : 0, nrows_dev)
-            if (TN == 32) GPB_PRED_DMA(32);
-            else if (TN == 128) GPB_PRED_DMA(128);
-            else GPB_PRED_DMA(64);
-#undef GPB_PRED_DMA
-        }
-        else if (ctx->mma_pipe && T == 128 && nwv == 4 && !resident)
-            hipLaunchKernelGGL((k_predict<128, 4, 128, 16, true>), dim3(grid), dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT,
-                               ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xcd_rows, ctx->tile_counter,
-                               (unsigned)nblocks, ctx->tile_trace, tri_arg, nrows_dev);
-
-        else if (ctx->fold_tiles && T == 64 && TN <= 64 && nwv == 4 && !ctx->tile_trace) {
-            // folded row-block pairs (k_predict_fold): P * ceil(nI / 2) groups in contiguous ranges per XCD, nW units each
-            const int64_t G = (int64_t)ctx->P * ((nI + 1) / 2);
-            const unsigned fgrid = (unsigned)(8 * ((G + 7) / 8) * nW);
-            if (TN == 32)
-                hipLaunchKernelGGL((k_predict_fold<32>), dim3(fgrid), dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT,
-                                   ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, nrows_dev);
-            else
-                hipLaunchKernelGGL((k_predict_fold<64>), dim3(fgrid), dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT,
-                                   ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, nrows_dev);
-        }
-        else if (T == 128) { if (nwv == 8) GPB_PRED(128, 8, 128, 16); else GPB_PRED(128, 4, 128, 16); }
-        else if (TN == 32) GPB_PRED(64, 4, 32, 16);
-        else if (TN == 128) GPB_PRED(64, 4, 128, 16);
-        else if (nwv == 8) GPB_PRED(64, 8, 64, 16);
-        else               GPB_PRED(64, 4, 64, 16);
-#else
-        // The product library holds the shapes the rule can select: the persistent 128x128 tile with the fragment
-        // read-ahead (ticket queues) and the static 64-row tiles (64x128, 64x64, 64x32; order 1-3, XCD map 0/1).
-        (void)slots;
+        // the shapes the rule can select: the persistent 128x128 tile with the fragment read-ahead (ticket queues) and the static
+        // 64-row tiles (64x128, 64x64, 64x32; order 1-3, XCD map 0/1)
         if (T == 128) {
             hipLaunchKernelGGL((k_predict<128, 4, 128, 16, true>), dim3(grid128), dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT,
                                ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xcd_rows, ctx->tile_counter,
                                (unsigned)nblocks, ctx->tile_trace, tri_arg, nrows_dev);
         } else {
             const int order = ctx->resident_order ? ctx->resident_order : 2;
-            const int xr = xcd_rows < 2 ? xcd_rows : 0;
+            const int xr = xcd_rows;
 #define GPB_PRED(NN)                                                                                                \
     hipLaunchKernelGGL((k_predict_static<64, 4, NN, 16>), dim3((unsigned)(xr == 1 ? ((ngroups + 7) / 8) * 8 * nW : ngroups * nW)), \
                        dim3(256), 0, ctx->stream, ctx->Linv, ctx->KsT, ctx->spart, ctx->Np, ctx->Wld, (int)ctx->P, nI, nW, xr, \
@@ -1540,16 +1003,13 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, con
             else if (TN == 128) GPB_PRED(128);
             else GPB_PRED(64);
         }
-#endif
         }
 #undef GPB_PRED
         if (ctx->profile) {
-            if (prof_end && e0) {
-                GPB_HIP(hipEventRecord(e1, ctx->stream));
-                ctx->prof_events.push_back({e0, e1});
-            }
+            GPB_HIP(hipEventRecord(e1, ctx->stream));
+            ctx->prof_events.push_back({e0, e1});
             // GPs per timed interval (a chain: all of them; a pair of launches: both groups')
-            ctx->prof_gps = prof_begin ? (double)GP : ctx->prof_gps + (double)GP;
+            ctx->prof_gps = (double)GP;
             if (!nrows_dev) ctx->prof_units += (double)GP * (double)W;          // compacted: counted on the device
             else ctx->prof_compacted = true;
         }

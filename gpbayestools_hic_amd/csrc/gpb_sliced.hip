@@ -243,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void k_predict_sliced(const int8_t* __restr
 // The rule (theta alone): every GP of the context has 1 + c / sn2 <= SL_RULE.  theta = [log c, log l_1..l_d, log sn2].
 bool sliced_applies(const gpb_ctx* ctx) {
     if (!ctx->predict_sliced || ctx->multi || !ctx->h_theta || !ctx->have_theta) return false;
-    if (ctx->tile_trace || ctx->kx_overlap) return false;               // hooks / variants of the fp64 kernel (debug library)
+    if (ctx->tile_trace) return false;                                  // the tile trace is a hook of the fp64 kernel (debug library)
     if (ctx->predict_sliced == 2) return true;                          // test hook: the rule off (accuracy probes)
     const int64_t stride = ctx->d + 2;
     for (int64_t p = 0; p < ctx->P; ++p) {

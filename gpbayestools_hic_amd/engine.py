@@ -471,8 +471,13 @@ class GPEngine:
             self.tune("tile_switch", int(switch_tiles))
 
     def tune(self, key, value):
-        """launch-geometry hook of the predict kernel: 'xcd', 'wgs64', 'waves', 'wgs128w8'."""
-        k = {"xcd": 0, "wgs64": 1, "waves": 2, "wgs128w8": 3, "chol_outer": 4, "resident": 5, "wgs32": 6, "narrow_switch": 7, "mvn_wg_switch": 8, "chol_inner_tile": 9, "tile_priority": 10, "fuse_finalize": 11, "trtri_tile": 12, "resident_occ": 13, "syrk_tile": 14, "wgs64x128": 16, "tri_skip": 17, "kcross_dot": 18, "kcross_chunks": 19, "kcross_wpl": 20, "static64": 21, "mid_switch": 22, "lowrank": 23, "chol_algo": 24, "chol_lookahead": 25, "sim_ranks": 26, "compact": 27, "tile_by_live": 28, "premark": 29, "fuse_accept_propose": 30, "sim_rank": 32, "tile_switch_c": 33, "mid_switch_c": 34, "narrow_switch_c": 35, "balance_shards": 36, "mma_pipe": 37, "fold_tiles": 38, "kmat_mfma": 39, "chain_batch": 40, "predict_dma": 41, "force_tile": 42, "generic_mvn": 43, "tile_switch": 44, "fuse_probe": 46, "chol_pair": 47, "kx_overlap": 48, "lr_split": 49, "kinv_tile": 50, "predict_sliced": 51}[key]
+        """option keys of gpb_ctx_option by name (launch geometry, tile rules, test hooks; 'predict_sliced': the int8 predict kernel)"""
+        k = {"xcd": 0, "chol_outer": 4, "resident": 5, "narrow_switch": 7, "mvn_wg_switch": 8, "chol_inner_tile": 9,
+             "tile_priority": 10, "fuse_finalize": 11, "trtri_tile": 12, "syrk_tile": 14, "tri_skip": 17, "kcross_dot": 18,
+             "kcross_chunks": 19, "kcross_wpl": 20, "mid_switch": 22, "lowrank": 23, "chol_lookahead": 25, "sim_ranks": 26,
+             "compact": 27, "tile_by_live": 28, "premark": 29, "fuse_accept_propose": 30, "sim_rank": 32, "tile_switch_c": 33,
+             "mid_switch_c": 34, "narrow_switch_c": 35, "balance_shards": 36, "chain_batch": 40, "force_tile": 42, "generic_mvn": 43,
+             "tile_switch": 44, "chol_pair": 47, "lr_split": 49, "kinv_tile": 50, "predict_sliced": 51}[key]
         self._ck(self.lib.gpb_ctx_option(self.h, k, int(value)))
 
     @property

@@ -10,13 +10,16 @@ import numpy as np
 from . import synth
 
 
-def build_chain(cfg, workdir=None, device=0, N=None, W=None):
-    """Returns (chain, emulator, info) for BASELINE config `cfg` on `device`."""
+def build_chain(cfg, workdir=None, device=0, N=None, W=None, no_pca=False):
+    """Returns (chain, emulator, info) for BASELINE config `cfg` on `device`.  no_pca: the emulator with perform_no_PCA (one GP
+    per observable, src/emulator.py:562-565,589-592: SURVEY 8a's "cfg 4, also P = 64"); info["P"] is then the observable count."""
     from .emulator import Emulator
     from .mcmc import Chain
     c = dict(synth.CONFIGS[cfg])
     if N is not None:
         c["N"] = N
+    if no_pca:
+        c["P"] = c["M"]
     Nn, d, M, P = c["N"], c["d"], c["M"], c["P"]
     workdir = workdir or tempfile.mkdtemp(prefix="gpb_bench_")
     lo, hi = np.zeros(d), np.ones(d)
@@ -25,7 +28,7 @@ def build_chain(cfg, workdir=None, device=0, N=None, W=None):
     tp, pf, ep = (os.path.join(workdir, n) for n in ("train.pkl", "par.txt", "exp.pkl"))
     synth.write_training_pickle(tp, X, Y, 0.01)
     synth.write_parameter_file(pf, lo, hi)
-    emu = Emulator(training_set_path=tp, parameter_file=pf, npc=P, device=device)
+    emu = Emulator(training_set_path=tp, parameter_file=pf, npc=P, device=device, perform_no_PCA=bool(no_pca))
     ktype = {"RBF": "RBF", "Matern15": "Matern", "Matern25": "Matern25"}[c["kernel"]]
     emu.trainEmulator([True] * emu.nev, kernel_type=ktype, thetas=synth.fixed_theta(d, P))
     xstar = synth.truth_point(d)
@@ -34,7 +37,7 @@ def build_chain(cfg, workdir=None, device=0, N=None, W=None):
     chain = Chain(mcmc_path=os.path.join(workdir, "mcmc", "chain.pkl"), expdata_path=ep, model_parafile=pf,
                   device=device)
     chain.emuList = [emu]
-    info = dict(c, X=X, Y=Y, lo=lo, hi=hi, xstar=xstar, yexp=yexp, workdir=workdir, kernel_type=ktype)
+    info = dict(c, X=X, Y=Y, lo=lo, hi=hi, xstar=xstar, yexp=yexp, workdir=workdir, kernel_type=ktype, no_pca=bool(no_pca))
     return chain, emu, info
 
 

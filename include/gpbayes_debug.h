@@ -55,12 +55,6 @@ GPB_API int gpb_debug_loopback_release(gpb_ctx* ctx);
  * GP, row block, walker tile, start, end (100 MHz ticks), blockIdx} to the host and re-arms. */
 GPB_API int gpb_debug_tile_trace(gpb_ctx* ctx, int64_t capacity);
 GPB_API int gpb_debug_tile_trace_read(gpb_ctx* ctx, uint32_t* records_host, int64_t max_records, int64_t* n_out);
-/* measurement hook: one step of gpb_chain_emcee_run (same arguments; pos / lp are copied, not advanced) as `reps` plain
- * calls and as `reps` replays of its HIP graph; milliseconds per step each.  The replay repeats one step index: it
- * measures launch overhead, it does not sample. */
-GPB_API int gpb_debug_graph_probe(gpb_ctx* const* ctxs, int E, const double* pos_dev, const double* lp_dev, int64_t nwalkers,
-                          uint64_t seed, double a, const double* lo_dev, const double* hi_dev, double outside_value,
-                          double inside_const, int reps, double* ms_plain, double* ms_graph);
 /* issue-rate probe: returns measured TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64
  * (mode 0), v_fma_f64 (mode 1) or both co-issued (mode 2); mode 3: shader cycles per MFMA (one wave
  * per SIMD); mode 4: shader clock in GHz held during the dense MFMA loop. */

@@ -345,54 +345,27 @@ def test_predict_tile_sizes_are_bit_identical(request, library):
         eng.set_theta(synth.fixed_theta(d, P)); eng.factor()
         Xs = rng.random((300, d))
         eng.force_tile(128); m1, v1 = eng.predict(Xs)
-        # The product library holds the shapes its rule selects (128x128 on ticket queues; 64x128, 64x64, 64x32 as static
-        # launches in three orders, two XCD maps).  The debug build (library = "debug") adds the measured-and-rejected
-        # variants: 8-wave tiles, ticket queues for the 64-row tiles, two more XCD maps, folded row-block pairs.
-        full = eng.has_variants
-        for tile, waves in ((64, 4), (64, 8), (128, 8)) if full else ((64, 4),):
-            eng.force_tile(tile); eng.tune("waves", waves)
-            m2, v2 = eng.predict(Xs)
-            assert np.array_equal(m1, m2) and np.array_equal(v1, v2), (tile, waves)
-        eng.tune("waves", 4)
-        for xcd in (0, 1, 2, 3):                          # tile -> XCD queue maps only reorder the work (64-row static tiles: 0 / 1)
+        # the shapes the rule selects: 128x128 on ticket queues; 64x128, 64x64, 64x32 as static launches in three orders, two XCD
+        # maps (the measured-and-rejected variants — 8-wave tiles, ticket queues for the 64-row tiles, folded row-block pairs,
+        # LDS-DMA staging of the fp64 tiles, two more XCD maps — were deleted in round 6: profiles/HISTORY.md)
+        for xcd in (0, 1):                                # tile -> XCD queue maps only reorder the work
             eng.tune("xcd", xcd)
             for tile in (64, 128, 32, 65):                # 32 = 64 rows x 32 walkers, 65 = 64 x 128
                 eng.force_tile(tile)
-                for order in (0, 1, 2, 3) if full else (1, 2, 3):      # ticket queues / static orders of a resident grid
+                for order in (1, 2, 3):                   # static orders of the 64-row launches
                     eng.tune("resident", order)
                     m2, v2 = eng.predict(Xs)
                     assert np.array_equal(m1, m2) and np.array_equal(v1, v2), (tile, xcd, order)
         eng.tune("xcd", -1); eng.tune("resident", 2)
-        if not full:
-            from gpbayestools_hic_amd._native import GPBError
-            for key, val in (("waves", 8), ("resident", 0), ("fold_tiles", 1), ("mma_pipe", 0),
-                             ("chol_algo", 0), ("kmat_mfma", 0), ("predict_dma", 1)):
-                with pytest.raises(GPBError, match="debug build"):
-                    eng.tune(key, val)                    # refused, not silently ignored
-        # folded pairs of row blocks (k_predict_fold) against one tile per workgroup: same MFMA sequence per (row block,
-        # walker), same tree; 7 row blocks leave the middle one unpaired
-        for tile in (32, 64) if full else ():
-            eng.force_tile(tile)
-            for fold in (0, 1):
-                eng.tune("fold_tiles", fold)
-                for W in (300, 32, 1):
-                    m2, v2 = eng.predict(Xs[:W])
-                    assert np.array_equal(m1[:W], m2) and np.array_equal(v1[:W], v2), (tile, fold, W)
-        if full:
-            eng.tune("fold_tiles", 0)
-        # 64-row tiles staged by LDS-DMA from the k-major copy of L^-1 (k_predict_static_dma): same MFMA sequence, same tree
-        for tile in (32, 64, 65) if full else ():
-            eng.force_tile(tile)
-            eng.tune("predict_dma", 1)
-            for W in (300, 32):
-                m2, v2 = eng.predict(Xs[:W])
-                assert np.array_equal(m1[:W], m2) and np.array_equal(v1[:W], v2), ("dma", tile, W)
-            eng.tune("predict_dma", 0)
+        from gpbayestools_hic_amd._native import GPBError
+        for key, val in (("xcd", 2), ("resident", 0)):
+            with pytest.raises(GPBError):
+                eng.tune(key, val)                        # a deleted variant's value is refused, not silently ignored
         eng.force_tile(0)
 
 
 def test_predict_tile_trace_covers_every_tile_once(deng):
-    """debug hook: one record per (GP, row block, walker tile), for the static and the ticket-queue launch"""
+    """debug hook: one record per (GP, row block, walker tile) of the static 64-row launch and of the 128 x 128 ticket-queue launch"""
     eng = deng
     from gpbayestools_hic_amd import synth
     rng = np.random.default_rng(21)
@@ -400,16 +373,15 @@ def test_predict_tile_trace_covers_every_tile_once(deng):
     eng.set_data(synth.lhs(N, d, seed=3), rng.standard_normal((P, N)), "RBF", 0.1)
     eng.set_theta(synth.fixed_theta(d, P)); eng.factor()
     Xs = rng.random((W, d))
-    eng.force_tile(64)
-    for order in (2, 0) if eng.has_variants else (2,):     # static snake launch / persistent ticket queues (debug build)
-        eng.tune("resident", order)
-        eng.tile_trace(4096)                               # (an armed trace selects the one-tile-per-workgroup kernels)
+    for T in (64, 128):
+        eng.force_tile(T)
+        eng.tile_trace(4096)
         eng.predict(Xs)
         rec = eng.tile_trace_read()
         eng.tile_trace(0)
         tiles = {(int(r[2]), int(r[3]), int(r[4])) for r in rec}
-        assert len(rec) == P * (N // 64) * (W // 64) == len(tiles)
-        assert tiles == {(p, ib, wt) for p in range(P) for ib in range(N // 64) for wt in range(W // 64)}
+        assert len(rec) == P * (N // T) * (W // T) == len(tiles)
+        assert tiles == {(p, ib, wt) for p in range(P) for ib in range(N // T) for wt in range(W // T)}
         assert np.all((rec[:, 6].astype(np.int64) - rec[:, 5].astype(np.int64)) % (1 << 32) < 10_000_000)   # < 0.1 s
     eng.force_tile(0); eng.tune("resident", 2)
 

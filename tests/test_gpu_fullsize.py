@@ -96,10 +96,39 @@ def test_fullsize_log_posterior_cfg4_against_oracle_sample():
     assert np.max(np.abs(got[ins] - ref[ins]) / np.abs(ref[ins])) < 1e-10
 
 
+def test_fullsize_log_posterior_cfg4_without_pca_p64_against_oracle_sample():
+    """SURVEY 8(a)'s second shape of cfg 4: perform_no_PCA, one GP per observable (P = 64 GPs of N = 2048), the covariance left
+    in standardized units as the reference leaves it (src/emulator.py:562-565,589-592), the dense 64 x 64 likelihood kernels
+    instead of the low-rank form: 48 rows against the oracle (its 64 factorisations: about a minute on the host)."""
+    from gpbayestools_hic_amd import synth
+    from gpbayestools_hic_amd.workload import build_chain
+    from oracle import gp_oracle as O
+    chain, emu, info = build_chain(4, no_pca=True)
+    d, P = info["d"], info["P"]
+    assert P == info["M"] == 64 and emu.perform_no_PCA_ and len(emu.gps) == 64
+    oe = O.OracleEmulator(info["X"], info["Y"], info["lo"], info["hi"], P, mode=O.MODE_NO_PCA).fit(synth.fixed_theta(d, P))
+    Xw = synth.walkers(48, d, seed=78)
+    Xw[5, 3] = 1.5; Xw[9, 0] = 0.0                                   # outside / on the boundary
+    yexp = info["yexp"]; cexp = np.diag((0.05 * np.abs(yexp)) ** 2)
+    ref = O.log_prob(Xw, info["lo"], info["hi"], lambda x, e: oe.predict(x, True, e), yexp, cexp)
+    got = chain.log_posterior(Xw)
+    ins = np.isfinite(ref)
+    assert np.array_equal(np.isneginf(got), ~ins) and ins.sum() == 46
+    assert np.max(np.abs(got[ins] - ref[ins]) / np.abs(ref[ins])) < 1e-10
+    # the emulator's own outputs in this mode: mean in data units, covariance = diag(gp variance), NOT rescaled
+    m, c = emu.predict(Xw[:6], return_cov=True, extra_std=0.0)
+    mo, co = oe.predict(Xw[:6], True, 0.0)
+    assert np.max(np.abs(m - mo) / np.abs(mo)) < 1e-11 and np.max(np.abs(c - co)) < 1e-10 * np.max(np.abs(co))
+    # a 2048-row batch gives the same bits as its rows in small batches (the dense likelihood kernels, the 64-GP predict launch)
+    Xb = synth.walkers(2048, d, seed=79)
+    lp = chain.log_posterior(Xb)
+    assert np.array_equal(chain.log_posterior(Xb[100:164]), lp[100:164]) and np.all(np.isfinite(lp))
+
+
 @pytest.mark.parametrize("N,library", [(1024, "product"), (2048, "product"), (1024, "debug")])
 def test_cholesky_schedules_agree(N, library):
     """the blocked Cholesky's schedules — two launches per step with the next diagonal block fused into the update
-    (default), with and without the lookahead side stream, and round 1's three-launch form — give the same factor bit
+    (default), with and without the lookahead side stream — give the same factor bit
     for bit at equal outer panel width (the side stream only touches tiles nobody else touches at that time; the pivot
     arithmetic is round 1's), run to run; another panel width groups the trailing updates differently and agrees to
     rounding; and the factor is correct"""
@@ -118,11 +147,8 @@ def test_cholesky_schedules_agree(N, library):
     ref_L, ref_X = eng.get("L"), eng.get("Linv")
     assert np.max(np.abs(auto_L - ref_L)) < 1e-12 * np.max(np.abs(ref_L))
     assert np.max(np.abs(auto_X - ref_X)) < 1e-11 * np.max(np.abs(ref_X))
-    for algo, outer, look in ((1, 512, 1), (1, 512, 0), (0, 512, 0), (1, 512, 1), (1, 256, 1), (1, 256, 0), (1, 128, 1),
-                              (1, 0, 1)):
-        if algo == 0 and not eng.has_variants:             # round 1's three-launch schedule: debug build (library = "debug")
-            continue
-        eng.tune("chol_algo", algo); eng.tune("chol_outer", outer); eng.tune("chol_lookahead", look)
+    for algo, outer, look in ((1, 512, 1), (1, 512, 0), (1, 512, 1), (1, 256, 1), (1, 256, 0), (1, 128, 1), (1, 0, 1)):
+        eng.tune("chol_outer", outer); eng.tune("chol_lookahead", look)
         eng.factor()
         L, Xi = eng.get("L"), eng.get("Linv")
         if outer == 0:
@@ -136,7 +162,7 @@ def test_cholesky_schedules_agree(N, library):
             L256 = L
         if outer == 256 and look == 0:
             assert np.array_equal(L, L256)
-    eng.tune("chol_algo", 1); eng.tune("chol_outer", 0); eng.tune("chol_lookahead", 1)
+    eng.tune("chol_outer", 0); eng.tune("chol_lookahead", 1)
     # column pairs (every second trailing update by two block columns at once: another grouping of the same sums) on and off
     pair = {}
     for mode in (2, 0, 2):

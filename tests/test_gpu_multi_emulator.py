@@ -241,43 +241,6 @@ def test_chain_with_more_than_64_parameters(tmp_path):
         assert c.acceptance_fraction.mean() > 0.0
 
 
-@pytest.mark.parametrize("specs", [[(100, 20, 4, "RBF"), (120, 24, 6, "Matern25"), (128, 16, 3, "RBF")], [(200, 30, 10, "RBF")]])
-def test_cross_kernel_of_the_second_gp_group_under_the_first_groups_predict_launch(tmp_path, specs, debug_lib):
-    """option key 48 (debug build: measured and rejected, profiles/r05_kcross_overlap.txt): the batch's GPs in two groups, the
-    second group's K*^T on the side stream while the first group's predict launch runs (two streams, two events per batch).
-    Every tile computes what it computes in the one-launch form: log-posterior batches and the resident step loop give the same
-    bits for any split — also one that cuts an emulator's GPs in two."""
-    from gpbayestools_hic_amd import StretchSampler, synth
-    from gpbayestools_hic_amd.workload import build_multi_chain
-    chain, emus, info = build_multi_chain(specs, D, workdir=str(tmp_path))
-    e0 = emus[0]._engine_ready()
-    X = synth.walkers(900, D, seed=11)
-    X[::9, 2] = 1.5                                           # rows outside the box: the compacted path
-    ref = chain.log_posterior(X)
-    s = StretchSampler(chain, 256, seed=3)
-    X0 = synth.walkers(256, D, seed=2)
-    ref_pos = s.run(X0, 6, status=10 ** 9)
-    ref_chain, ref_lp = s.chain, s.lnprobability
-    for pct in (50, 25, 80, 1, 99):
-        e0.tune("kx_overlap", pct)
-        assert np.array_equal(chain.log_posterior(X), ref), pct
-        assert np.array_equal(chain.log_posterior(X[:70]), ref[:70]), pct
-        s2 = StretchSampler(chain, 256, seed=3)
-        assert np.array_equal(s2.run(X0, 6, status=10 ** 9), ref_pos), pct
-        assert np.array_equal(s2.chain, ref_chain) and np.array_equal(s2.lnprobability, ref_lp), pct
-    # the HIP-event record of a launch pair is ONE interval that counts the GPs of both groups
-    e0.tune("kx_overlap", 40)
-    import torch
-    Xd = torch.as_tensor(synth.walkers(512, D, seed=5), device="cuda")
-    e0.profile(True)
-    chain.log_prob_device(Xd)
-    n, ms, units = e0.profile_read()
-    e0.profile(False)
-    assert n == 1 and ms > 0 and units == sum(sp[2] for sp in specs) * 512
-    e0.tune("kx_overlap", 0)
-    assert np.array_equal(chain.log_posterior(X), ref)
-
-
 def test_chain_block_likelihoods_split_over_workgroups_give_the_walks_bits(tmp_path):
     """option key 49: the block log-likelihoods of a chain's emulators as one workgroup per (walker tile, emulator) + an ordered sum
     (default) against one workgroup per walker tile walking the emulators: the same additions in the same order, bit for bit — on

@@ -1,6 +1,7 @@
 # rocprofv3 kernel trace of LML + gradient evaluations: bash tools/micro/prof_lml.sh N reps P  -> gpurun_out/prof_lml_<N>_<P>_summary.csv
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 N=${1:-1024}; reps=${2:-20}; P=${3:-10}
 D=$R/gpurun_out/prof_lml_${N}_${P}
 rm -rf $D

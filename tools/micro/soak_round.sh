@@ -1,5 +1,6 @@
 # the randomised parity soaks of tools/gpu_*_soak.py with this round's seeds; one JSON line each into gpurun_out/soak_<tag>.txt
-R=$GRAFT_REPO_ROOT
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 tag=${1:-r05}; s0=${2:-10}
 out=$R/gpurun_out/soak_$tag.txt
 : > $out
