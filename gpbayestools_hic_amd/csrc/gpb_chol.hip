@@ -260,6 +260,9 @@ static int launch_potrf_pairs(gpb_ctx* ctx) {
 int launch_potrf_fused(gpb_ctx* ctx) {
     // (the rule reads Np alone — never the number of GPs of the launch: a GP's bits must not depend on its neighbours, which is what
     // keeps train_emulators' batched searches identical to the one-emulator ones)
+    // (round 6: the first 256-1536 columns in panels of 256 with the panel-wide SYRK, K = 256, and the pairs behind them: -0.5 % at
+    // N = 2048 with 256 columns, slower beyond; -2.3 % at N = 3072, -1.5 % for 63 GPs at N = 1024: below the 8 % it had to bring,
+    // removed — profiles/r06_fit_notes.txt)
     if (ctx->chol_outer == 0 && (ctx->chol_pair == 2 || (ctx->chol_pair == 1 && ctx->Np >= 1024 && ctx->Np <= 3072)))
         return launch_potrf_pairs(ctx);
     const int64_t Np = ctx->Np, nb = Np / 64;

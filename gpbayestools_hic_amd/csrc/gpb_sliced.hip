@@ -1,7 +1,7 @@
 // gpb_sliced.hip — V = L^-1 K*^T with the fused sum of squares on the INT8 matrix pipe (option key 51; round 6).
 //
-// What it replaces: the 128 x 128 fp64 tiles of k_predict (gpb_predict.hip; sk:_gpr.py:454-460, src/emulator.py:553,573-575) for
-// the contexts the rule below admits.  Scheme, accuracy and costs: profiles/r06_sliced_model.txt, tools/ozaki_probe.py,
+// What it replaces: k_predict's fp64 tiles (gpb_predict.hip; sk:_gpr.py:454-460, src/emulator.py:553,573-575) for the contexts
+// the rule below admits, at every batch size (a walker's bits must not depend on the batch it arrives in).  Scheme, accuracy and costs: profiles/r06_sliced_model.txt, tools/ozaki_probe.py,
 // tools/micro/sliced_probe.hip (the micro-kernel this file grew from).
 //
 //   * row j of L^-1 is scaled by 2^-e_j (max|row| <= 0.99 2^e_j) and rounded ONCE to a 47-bit integer, K*^T (in (0, c]) by ONE
@@ -20,10 +20,10 @@
 // LDS-DMA (global_load_lds_dwordx4) moves without staging registers into the same layout in LDS, from where ds_read_b128
 // delivers fragments with no transposition and no bank conflict.
 //
-// Kernel: 128 x 128 block tile, 8 waves (two per SIMD) of 32 rows x 64 walkers (6 x 2 x 16 = 192 accumulator registers),
-// K-step 32, three LDS stages of 48 KB with two DMA stages in flight across raw s_barriers (counted vmcnt: a __syncthreads()
-// would drain them), tiles in super-blocks (one GP x 8 row blocks x 4 walker tiles = the 32 workgroups of an XCD) dealt
-// round-robin to the XCDs, heaviest first.
+// Kernel: 128 x 128 block tile (128 x 64 for small batches), 8 waves (two per SIMD) of 32 rows x 64 (32) walkers (6 x 2 x 16 = 192
+// accumulator registers), K-step 32, three LDS stages of 48 (36) KB with two DMA stages in flight across raw s_barriers (counted
+// vmcnt: a __syncthreads() would drain them), the DMA of a step issued BEHIND its MFMAs, tiles in super-blocks (one GP x 8 row
+// blocks x 4 walker tiles = the 32 workgroups of an XCD) dealt round-robin to the XCDs, heaviest first.
 #include "gpb_internal.h"
 
 namespace gpb {
@@ -33,12 +33,18 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* sl_lds_ptr;
 
 constexpr int SL_D = 6, SL_LOW = 5, SL_NLEV = 2 * SL_D - 1 - SL_LOW;            // 6 digits, levels 5..10, 21 products
-constexpr int SL_BM = 128, SL_BN = 128;
-constexpr int SL_A_CHUNKS = SL_D * 2 * (SL_BM / 64), SL_B_CHUNKS = SL_D * 2 * (SL_BN / 64), SL_CHUNKS = SL_A_CHUNKS + SL_B_CHUNKS;
-constexpr int SL_STAGE = SL_CHUNKS * 1024, SL_NSTAGE = 3;
-constexpr int SL_LDS = SL_NSTAGE * SL_STAGE + SL_BM * 8;                        // + the tile's row scales
-constexpr int SL_NPW = SL_CHUNKS / 8;                                          // DMA instructions per wave and stage (48 / 8)
-static_assert(SL_CHUNKS % 8 == 0, "every wave issues the same number of DMAs per stage");
+constexpr int SL_BM = 128;
+// block tile 128 rows x (64 WTN) walkers: WTN = 2 for batches that fill the chip with 128 x 128 tiles, WTN = 1 (half the
+// accumulators, 3/4 of the bytes per K-step for half the MFMAs: bound by the operand feed) for smaller ones — a rank's share of a
+// sharded ensemble.  The shape never changes a bit: integer sums are exact and the epilogue's order is the row's.
+template <int WTN>
+struct SlGeo {
+    static constexpr int BN = 64 * WTN;
+    static constexpr int A_CHUNKS = SL_D * 2 * (SL_BM / 64), B_CHUNKS = SL_D * 2 * WTN, CHUNKS = A_CHUNKS + B_CHUNKS;   // 1-KB pieces per stage
+    static constexpr int STAGE = CHUNKS * 1024, NSTAGE = 3;
+    static constexpr int LDS = NSTAGE * STAGE + SL_BM * 8;                   // + the tile's row scales
+    static constexpr int NPW = (CHUNKS + 7) / 8, REM = CHUNKS % 8;           // DMAs per wave and stage: NPW for waves < REM (all if REM = 0), else NPW - 1
+};
 constexpr int SL_RG = 8, SL_CG = 4;                                            // super-block: 8 row blocks x 4 walker tiles
 constexpr double SL_RULE = 128.0;                                              // 1 + c / sn2 above this: fp64 kernel
 
@@ -110,16 +116,19 @@ __global__ __launch_bounds__(256) void k_sl_slice_linv(const double* __restrict_
 
 // ---------------------------------------------------------------------------------------------------------------- the tile kernel
 // wave-uniform: this wave's share of the DMA of one K-step (k-blocks kb0, kb0 + 1) into stage buffer `buf`
+template <int WTN>
 __device__ __forceinline__ void sl_dma_stage(char* lds, int buf, const int8_t* __restrict__ Ap, const int8_t* __restrict__ Bp,
                                              int64_t a_plane, int64_t b_plane, int64_t Np128, int64_t Wld, int64_t mb, int64_t nb,
                                              int64_t kb0, int wave, int lane) {
-    char* base = lds + buf * SL_STAGE;
+    typedef SlGeo<WTN> G;
+    char* base = lds + buf * G::STAGE;
 #pragma unroll
-    for (int c = 0; c < SL_NPW; ++c) {
+    for (int c = 0; c < G::NPW; ++c) {
         const int ch = 8 * c + wave;                                    // wave-uniform
-        const bool is_a = ch < SL_A_CHUNKS;
-        const int cb = is_a ? ch : ch - SL_A_CHUNKS;
-        constexpr int per = SL_BM / 64;                                 // (= SL_BN / 64) 1-KB pieces per (plane, k-block)
+        if (c == G::NPW - 1 && G::REM != 0 && wave >= G::REM) break;
+        const bool is_a = ch < G::A_CHUNKS;
+        const int cb = is_a ? ch : ch - G::A_CHUNKS;
+        const int per = is_a ? SL_BM / 64 : WTN;                        // 1-KB pieces per (plane, k-block)
         const int t = cb / (2 * per), q = (cb / per) & 1, h = cb % per;
         const int64_t ld = is_a ? Np128 : Wld, off = is_a ? mb : nb;
         const int8_t* plane = is_a ? Ap + t * a_plane : Bp + t * b_plane;
@@ -128,19 +137,33 @@ __device__ __forceinline__ void sl_dma_stage(char* lds, int buf, const int8_t* _
     }
 }
 
+template <int N>
+__device__ __forceinline__ void sl_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// all of this wave's DMAs but those of its newest stage have landed (more: every one)
+template <int WTN>
+__device__ __forceinline__ void sl_wait_stage(bool more, bool full_count) {
+    typedef SlGeo<WTN> G;
+    if (!more) sl_wait_vm<0>();
+    else if (full_count) sl_wait_vm<G::NPW>();
+    else sl_wait_vm<G::NPW - 1>();
+}
+
 // fragments are read where they are used (the SIMD's other wave covers the LDS latency): A once, B per 32-walker n-tile
-__device__ __forceinline__ void sl_mma_step(const char* lds, int buf, int wm, int wn, int lane, v16i (&acc)[SL_NLEV][2]) {
-    const char* base = lds + buf * SL_STAGE;
+template <int WTN>
+__device__ __forceinline__ void sl_mma_step(const char* lds, int buf, int wm, int wn, int lane, v16i (&acc)[SL_NLEV][WTN]) {
+    typedef SlGeo<WTN> G;
+    const char* base = lds + buf * G::STAGE;
     const int q = lane >> 5, r = lane & 31;
     v4i a[SL_D];
 #pragma unroll
     for (int t = 0; t < SL_D; ++t) a[t] = *reinterpret_cast<const v4i*>(base + ((t * 2 + q) * SL_BM + wm * 32 + r) * 16);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < WTN; ++j) {
         v4i b[SL_D];
 #pragma unroll
         for (int t = 0; t < SL_D; ++t)
-            b[t] = *reinterpret_cast<const v4i*>(base + SL_A_CHUNKS * 1024 + ((t * 2 + q) * SL_BN + wn * 64 + 32 * j + r) * 16);
+            b[t] = *reinterpret_cast<const v4i*>(base + G::A_CHUNKS * 1024 + ((t * 2 + q) * G::BN + wn * 32 * WTN + 32 * j + r) * 16);
 #pragma unroll
         for (int tb = 0; tb < SL_D; ++tb)
 #pragma unroll
@@ -154,12 +177,14 @@ __device__ __forceinline__ void sl_mma_step(const char* lds, int buf, int wm, in
 // Static launch, one workgroup per tile slot.  Block b belongs to XCD label b % 8 (round-robin dispatch: speed only); the m-th
 // block of a label works on super-block (m / 32) * 8 + label, tile m % 32 of it.  Super-blocks in order: row groups heaviest
 // first, then GP, then walker group.  Slots of a ragged super-block (row blocks or walker tiles that do not exist) return at once.
+template <int WTN>
 __global__ __launch_bounds__(512, 2) void k_predict_sliced(const int8_t* __restrict__ A, const int8_t* __restrict__ B,
                                                            const double* __restrict__ rowscale, const double* __restrict__ colscale,
                                                            double* __restrict__ spart, int64_t Np, int64_t Np128, int64_t Wld, int P,
                                                            int nI, int nW, int kskip, const int* __restrict__ nrows) {
+    typedef SlGeo<WTN> G;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    if (nrows) nW = (*nrows + SL_BN - 1) / SL_BN;                       // compacted batch: the live walker tiles only
+    if (nrows) nW = (*nrows + G::BN - 1) / G::BN;                       // compacted batch: the live walker tiles only
     const int nG = (nI + SL_RG - 1) / SL_RG, nWG = (nW + SL_CG - 1) / SL_CG;
     const unsigned label = blockIdx.x & 7u, m = blockIdx.x >> 3;
     const unsigned sb = (m / (SL_RG * SL_CG)) * 8u + label, local = m % (SL_RG * SL_CG);
@@ -170,12 +195,13 @@ __global__ __launch_bounds__(512, 2) void k_predict_sliced(const int8_t* __restr
     if (ib >= nI || wt >= nW) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;                            // 4 x 2 waves of 32 rows x 64 walkers
-    const int64_t mb = (int64_t)ib * SL_BM, nb = (int64_t)wt * SL_BN;
+    const int wm = wave >> 1, wn = wave & 1;                            // 4 x 2 waves of 32 rows x (32 WTN) walkers
+    const int64_t mb = (int64_t)ib * SL_BM, nb = (int64_t)wt * G::BN;
+    const bool fullc = G::REM == 0 || wave < G::REM;
     const int64_t a_plane = (Np / 16) * Np128 * 16, b_plane = (Np / 16) * Wld * 16;
     const int8_t* Ap = A + (int64_t)p * SL_D * a_plane;
     const int8_t* Bp = B + (int64_t)p * SL_D * b_plane;
-    double* rs = reinterpret_cast<double*>(lds + SL_NSTAGE * SL_STAGE);
+    double* rs = reinterpret_cast<double*>(lds + G::NSTAGE * G::STAGE);
     if (tid < SL_BM) rs[tid] = rowscale[(int64_t)p * Np128 + mb + tid];
     // k in [k_begin, k_end): the row block's part of the triangle; the design's padding in front (all-zero rows of K*^T, whole
     // 32-deep steps of it) is left out when the row block lies behind it — the products it skips are exact zeros
@@ -184,38 +210,37 @@ __global__ __launch_bounds__(512, 2) void k_predict_sliced(const int8_t* __restr
     const int64_t k_begin = ks <= mb ? ks : 0;
     const int nsteps = (int)((k_end - k_begin) / 32);
     const int64_t kb_first = k_begin / 16;
-    v16i acc[SL_NLEV][2];
+    v16i acc[SL_NLEV][WTN];
 #pragma unroll
     for (int l = 0; l < SL_NLEV; ++l)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WTN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[l][j][r] = 0;
-    sl_dma_stage(lds, 0, Ap, Bp, a_plane, b_plane, Np128, Wld, mb, nb, kb_first, wave, lane);
-    if (nsteps > 1) sl_dma_stage(lds, 1, Ap, Bp, a_plane, b_plane, Np128, Wld, mb, nb, kb_first + 2, wave, lane);
+    sl_dma_stage<WTN>(lds, 0, Ap, Bp, a_plane, b_plane, Np128, Wld, mb, nb, kb_first, wave, lane);
+    if (nsteps > 1) sl_dma_stage<WTN>(lds, 1, Ap, Bp, a_plane, b_plane, Np128, Wld, mb, nb, kb_first + 2, wave, lane);
     for (int s = 0; s < nsteps; ++s) {
         // stage s has landed for this wave (its own DMAs of stage s + 1 may still fly), every wave says so at the barrier, and
         // every wave has finished reading buffer (s + 2) % 3 = (s - 1) % 3 (its reads were consumed by the MFMAs of step s - 1)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SL_NPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sl_wait_stage<WTN>(s + 1 < nsteps, fullc);
         __builtin_amdgcn_s_barrier();
-        sl_mma_step(lds, s % 3, wm, wn, lane, acc);
+        sl_mma_step<WTN>(lds, s % 3, wm, wn, lane, acc);
         // the DMA of stage s + 2 BEHIND the step's MFMAs: a global_load_lds costs its wave ~60 cycles of issue, which then fall
         // into the time its 42 queued MFMAs drain (issued first: 0.95 -> 0.74 ms on the micro-kernel, profiles/r06_sliced_model.txt);
         // buffer (s + 2) % 3 was last read in step s - 1, which every wave has left (the barrier above)
         if (s + 2 < nsteps)
-            sl_dma_stage(lds, (s + 2) % 3, Ap, Bp, a_plane, b_plane, Np128, Wld, mb, nb, kb_first + 2 * (int64_t)(s + 2), wave, lane);
+            sl_dma_stage<WTN>(lds, (s + 2) % 3, Ap, Bp, a_plane, b_plane, Np128, Wld, mb, nb, kb_first + 2 * (int64_t)(s + 2), wave, lane);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // epilogue: levels -> fp64 (Horner from the least significant one), scale, square; a wave sums its 32 rows in the order
     // (register, lane half), the odd wave row hands its sum to the even one: one partial per 64-row block, order fixed by the row
     const double cs = colscale[p];
-    double* hand = reinterpret_cast<double*>(lds);                     // [wave][2][32] (the stage buffers are free now)
-    double sums[2];
+    double* hand = reinterpret_cast<double*>(lds);                     // [wave][WTN][32] (the stage buffers are free now)
+    double sums[WTN];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < WTN; ++j) {
         double sum = 0.0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -228,14 +253,14 @@ __global__ __launch_bounds__(512, 2) void k_predict_sliced(const int8_t* __restr
         }
         sum += __shfl_xor(sum, 32);
         sums[j] = sum;
-        if ((wm & 1) && lane < 32) hand[(wave * 2 + j) * 32 + lane] = sum;
+        if ((wm & 1) && lane < 32) hand[(wave * WTN + j) * 32 + lane] = sum;
     }
     __syncthreads();
     const int64_t blk = (int64_t)ib * 2 + (wm >> 1);
     if (!(wm & 1) && lane < 32 && blk * 64 < Np) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            spart[(blk * P + p) * Wld + nb + wn * 64 + 32 * j + lane] = sums[j] + hand[((wave + 2) * 2 + j) * 32 + lane];
+        for (int j = 0; j < WTN; ++j)
+            spart[(blk * P + p) * Wld + nb + wn * 32 * WTN + 32 * j + lane] = sums[j] + hand[((wave + 2) * WTN + j) * 32 + lane];
     }
 }
 
@@ -319,17 +344,36 @@ int launch_vsq_sliced(gpb_ctx* ctx, int64_t W, const int* nrows_dev, int kskip) 
     if (!ctx->slA || !ctx->slA_valid || !ctx->slB) GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_vsq_sliced before sliced_prepare");
     const double* rowscale = reinterpret_cast<const double*>(ctx->sl_scale);
     const double* colscale = rowscale + P * Np128;
-    const int nI = (int)(Np128 / SL_BM), nW = (int)(Wld / SL_BN);
+    // 128 x 128 tiles when enough of them exist to fill the chip (three per CU of the rows that are live, as far as the host
+    // knows), 128 x 64 below that (cfg 4, one MI355X, launch us at 2048 / 1024 / 512 / 256 rows: 653 / 344 / 220 / 217 against
+    // 757 / 375 / 206 / 136: gpurun_out r6_share8_e); either shape gives the same bits
+    const int nI = (int)(Np128 / SL_BM);
+    int64_t Wsel = Wld;
+    if (nrows_dev && ctx->tile_by_live && ctx->hint_from && ctx->hint_from->live_hint) {
+        const unsigned long long h = __atomic_load_n(ctx->hint_from->live_hint, __ATOMIC_RELAXED);
+        const int64_t cnt = (int64_t)(h & 0xffffffffull), of = (int64_t)(h >> 32);
+        if (of > 0 && cnt <= of) Wsel = imin64(Wld, (int64_t)((double)cnt / (double)of * (double)W * 1.03) + 8);
+    }
+    const int64_t tiles128 = P * nI * ((Wsel + 127) / 128);
+    int wtn = tiles128 >= 3 * (int64_t)ctx->num_cu ? 2 : 1;
+    if (ctx->force_tile == 128) wtn = 2;
+    if (ctx->force_tile == 64 || ctx->force_tile == 32 || ctx->force_tile == 65) wtn = 1;
+    const int nW = (int)(Wld / (64 * wtn));
     const int nG = (nI + SL_RG - 1) / SL_RG, nWG = (nW + SL_CG - 1) / SL_CG;
     const int64_t nSB = (int64_t)nG * P * nWG;
     const unsigned grid = (unsigned)(((nSB + 7) / 8) * 8 * SL_RG * SL_CG);
     static bool attr_set = false;
     if (!attr_set) {
-        GPB_HIP(hipFuncSetAttribute((const void*)k_predict_sliced, hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS));
+        GPB_HIP(hipFuncSetAttribute((const void*)k_predict_sliced<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SlGeo<2>::LDS));
+        GPB_HIP(hipFuncSetAttribute((const void*)k_predict_sliced<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SlGeo<1>::LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_predict_sliced, dim3(grid), dim3(512), SL_LDS, ctx->stream, ctx->slA, ctx->slB, rowscale, colscale,
-                       ctx->spart, Np, Np128, Wld, (int)P, nI, nW, kskip, nrows_dev);
+    if (wtn == 2)
+        hipLaunchKernelGGL(k_predict_sliced<2>, dim3(grid), dim3(512), SlGeo<2>::LDS, ctx->stream, ctx->slA, ctx->slB, rowscale, colscale,
+                           ctx->spart, Np, Np128, Wld, (int)P, nI, nW, kskip, nrows_dev);
+    else
+        hipLaunchKernelGGL(k_predict_sliced<1>, dim3(grid), dim3(512), SlGeo<1>::LDS, ctx->stream, ctx->slA, ctx->slB, rowscale, colscale,
+                           ctx->spart, Np, Np128, Wld, (int)P, nI, nW, kskip, nrows_dev);
     (void)W;
     return 0;
 }
