@@ -651,7 +651,9 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ mpa
         double s = 0.0;
 #pragma unroll 8
         for (int i = 0; i < nI64; ++i) s += spart[((int64_t)i * P + p) * Wld + w];
-        var_pc[(int64_t)p * Wld + w] = (amp[p] + noise[p]) - s;
+        // (a NaN input row makes the mean NaN; the int8 kernel's integer sums cannot carry a NaN, so the variance takes it from there:
+        // on the fp64 kernel s is NaN whenever m is, and nothing changes)
+        var_pc[(int64_t)p * Wld + w] = m != m ? m : (amp[p] + noise[p]) - s;
     }
 }
 

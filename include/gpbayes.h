@@ -261,31 +261,36 @@ GPB_API int gpb_dist_finalize(gpb_ctx* ctx);
 
 /* ---- options and measurement ------------------------------------------------------- *
  * gpb_ctx_option: launch-geometry and behaviour options of a context (no reference counterpart; the defaults are what the
- * numbers in DESIGN.md were measured with).  None changes a result except key 18, which moves a GP between two
- * distance forms that agree to ~1e-13.  Keys (value ranges are checked; GPB_E_ARG otherwise):
- *   0 XCD affinity of the predict kernel (-1 auto, 0 by walker tile, 1 by row block, 2 by GP, 3 by (GP, four row blocks));
- *   1 / 3 / 6 / 16 persistent predict workgroups per CU (64x64 / 128x128 8-wave / 64x32 / 64x128 tiles); 4 outer panel width
- *   of the blocked Cholesky (0: by size); 5 tile order of a co-resident predict grid (1 sorted, 2 snake, 3 snake of pairs);
+ * numbers in DESIGN.md were measured with).  None changes a result except key 18, which moves a GP between two distance forms
+ * that agree to ~1e-13, and key 51, which evaluates V = L^-1 K*^T in another arithmetic.  Keys (value ranges are checked;
+ * GPB_E_ARG otherwise):
+ *   0 XCD affinity of the predict kernel (-1 auto, 0 by walker tile, 1 by row block); 4 outer panel width of the blocked
+ *   Cholesky (0: by size); 5 tile order of the static 64-row predict launches (1 sorted, 2 snake, 3 snake of pairs);
  *   7 / 22 switch points of the tile-shape rule (64x64 / 64x128 tiles per 256 CUs), 33 / 34 / 35 the same for compacted
  *   batches; 8 largest batch whose dense block log-likelihood runs one workgroup per walker; 9 / 12 / 14 / 50 tile (64, 128; 0 = by
  *   fill) of the in-panel Cholesky updates / the triangular-inverse levels / the end-of-panel updates / K^-1 of the LML gradient; 10 wave priority of
- *   predict tiles by K-loop length; 11 the block log-likelihood kernels sum the predict partials themselves; 13 co-resident
- *   workgroups per CU assumed by the static predict launch (0: table); 17 skip the all-zero m-tiles of the predict kernel's
- *   diagonal blocks; 18 distance form of the kernel matrices (1: per GP from theta, see GPB_GET_FORM; 0: difference form for
- *   every GP; 2: Gram form for every GP); 19 / 20 design chunks per cross-kernel workgroup / walkers per lane there;
- *   23 low-rank form of the block log-likelihood when it applies; 25 Cholesky lookahead on a side stream; 27 evaluate only the
- *   rows inside the prior box; 28 size the tile rule of a compacted batch by its live rows; 29 / 30 fusions of the resident
- *   step loop (box test and gather in the proposal kernel; accept + next proposal in one launch); 36 balanced row shares of a
- *   sharded step loop (0 off: default, 1 from 8 ranks on, 2 always); 40 the emulators of a chain share one launch per kernel kind;
- *   42 force the predict tile (0: by rule; 128, 64, 32 = 64 rows x 32 walkers, 65 = 64 x 128: every shape gives the same bits);
- *   43 route the block log-likelihood through the generic LDS / HBM Cholesky kernel (what M > 64 takes) whatever M;
+ *   predict tiles by K-loop length; 11 the block log-likelihood kernels sum the predict partials themselves; 17 skip the all-zero
+ *   m-tiles of the predict kernel's diagonal blocks; 18 distance form of the kernel matrices (1: per GP from theta, see
+ *   GPB_GET_FORM; 0: difference form for every GP; 2: Gram form for every GP); 19 / 20 design chunks per cross-kernel workgroup /
+ *   walkers per lane there; 23 low-rank form of the block log-likelihood when it applies; 25 Cholesky lookahead on a side stream;
+ *   27 evaluate only the rows inside the prior box; 28 size the tile rule of a compacted batch by its live rows; 29 / 30 fusions
+ *   of the resident step loop (box test and gather in the proposal kernel; accept + next proposal in one launch); 36 balanced
+ *   row shares of a sharded step loop (0 off: default, 1 from 8 ranks on, 2 always); 40 the emulators of a chain share one launch
+ *   per kernel kind; 42 force the predict tile (0: by rule; 128, 64, 32 = 64 rows x 32 walkers, 65 = 64 x 128: every shape gives
+ *   the same bits); 43 route the block log-likelihood through the generic LDS / HBM Cholesky kernel (what M > 64 takes) whatever M;
  *   44 the number of 128x128 predict tiles per 256 CUs from which the rule takes them (0: default 960);
  *   47 Cholesky by column pairs (every second trailing update takes two block columns at once, K = 128): 1 where it is the faster
  *   schedule (default: 1024 <= N <= 3072), 2 always, 0 never; results agree to rounding (another order of the same sums);
  *   49 the block log-likelihoods of a chain of emulators as one workgroup per (walker tile, emulator) and an ordered sum (1,
- *   default) or as one workgroup per walker tile that walks the emulators (0); same bits.
- *   Keys and values that select a measured-and-rejected kernel variant or a measurement hook (2, 21, 24, 26, 32, 37, 38, 39, 41, 48
- *   and 5 = 0) exist in the debug build only (libgpbayes_debug.so: include/gpbayes_debug.h) and return GPB_E_ARG here.
+ *   default) or as one workgroup per walker tile that walks the emulators (0); same bits;
+ *   51 V = L^-1 K*^T (sk:_gpr.py:454-460, src/emulator.py:573-575) on the INT8 matrix pipe (csrc/gpb_sliced.hip): 0 never
+ *   (default), 1 for every batch of a context whose GPs all have 1 + c / sigma_n^2 <= 128 (the rule reads theta alone; other
+ *   contexts keep the fp64 kernel), 2 the rule off (accuracy probes).  Operands as six signed 8-bit digit planes, the 21 digit
+ *   products of the upper levels summed exactly in int32, combined in fp64: the variance within ~2e-11 relative of the fp64
+ *   kernel's (1e-10 bar kept), a log-posterior within ~1e-11 .. 2e-9 depending on how far its two terms cancel; a walker's bits
+ *   still do not depend on batch, tile, compaction or rank count.  1.8-2.1x the fp64 kernel at cfg 4.
+ *   Keys 26 / 32 (one rank's share of a sharded step on a single GPU: a measurement hook) take non-zero values in the debug build
+ *   only (libgpbayes_debug.so: include/gpbayes_debug.h) and return GPB_E_ARG here.
  * gpb_debug_has_variants: 1 when the loaded library is that debug build (-DGPB_DEBUG_VARIANTS), 0 for the product library.
  * gpb_profile_enable / _read: HIP-event timing of the dominant kernel (k_predict: V = L^-1 K*^T + sum of squares) on the
  *   context's stream — number of timed launches, their summed duration, the (GP, walker) pairs they processed; read resets.
