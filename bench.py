@@ -543,6 +543,26 @@ def extras(chain4, emu4, info4, sustain_s=5.5, only_sustained=False):
                      "k_predict_tflops": units / (kms * 1e-3) / 1e12 if kms else None,
                      "k_predict_frac_of_peak": units / (kms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS if kms else None}
         del sm
+    # the same chain with the int8 predict kernel switched on (option key 51; every emulator here is inside its rule and takes
+    # its own K*^T and predict launches: the shared launches are fp64's)
+    try:
+        for e in memus:
+            e._engine_ready().tune("predict_sliced", 1)
+        X0m = synth.walkers_ball(nwm, minfo["xstar"], 1e-8)
+        sm = StretchSampler(mchain, nwm, seed=5)
+        sm.run(X0m, 3, status=10 ** 9, store=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sm.run(None, nst, status=10 ** 9, store=False)
+        torch.cuda.synchronize()
+        dts = (time.perf_counter() - t0) / nst
+        del sm
+        nine["burnt_in_int8_predict"] = {"ms_per_step": dts * 1e3, "walker_evals_per_s": nwm / dts,
+                                         "speedup_vs_fp64_path": nine["burnt_in"]["ms_per_step"] / (dts * 1e3)}
+        for e in memus:
+            e._engine_ready().tune("predict_sliced", 0)
+    except Exception as e:      # noqa: BLE001
+        nine["burnt_in_int8_predict"] = {"error": "%s: %s" % (type(e).__name__, e)}
     nine["what"] = ("stretch-move steps of a nine-emulator chain through gpb_chain_emcee_run; k_predict figures: algorithmic "
                     "flops N^2 = 1000^2 per evaluated (GP, row) over the HIP-event times of the predict launches (one per half-step for all nine "
                     "emulators: k_predict_multi)")

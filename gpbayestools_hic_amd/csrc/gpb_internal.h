@@ -267,6 +267,7 @@ bool sliced_applies(const gpb_ctx* ctx);
 int sliced_prepare(gpb_ctx* ctx);                    // buffers, and the planes of L^-1 after a new factorisation
 const double* sliced_colscale(const gpb_ctx* ctx);   // device [P]: the power-of-two scale of each GP's K*^T digits
 int launch_vsq_sliced(gpb_ctx* ctx, int64_t W, const int* nrows_dev, int kskip);
+int launch_vsq_sliced_multi(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, int kskip);   // the GPs of E contexts, one launch
 void sliced_free(gpb_ctx* ctx);
 int sliced_read_kstar(gpb_ctx* ctx, int64_t p, int64_t pad, int64_t N, int64_t W, double* out);
 constexpr int GPB_MAX_MULTI_GP = 96;      // GPs one batched launch can address (its table is a kernel argument)

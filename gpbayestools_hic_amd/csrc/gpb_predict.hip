@@ -284,11 +284,13 @@ constexpr int MAX_KX_CTX = 32;
 struct KxCtx {
     const double *Xs, *Xc, *ls, *amp, *alpha, *dnorm, *muS;
     double *KsT, *mpart;
+    int8_t* planes;              // SLICE form (option key 51): the context's digit planes of K*^T and their per-GP scales
+    const double* colscale;
     int N, P, kind, g0, p0, d;   // g0: index of the entry's first GP in the launch; p0: that GP's index in its context;
 };                               // d: the context's own input count (contexts of one launch share the padded count only)
 struct KxTable { KxCtx c[MAX_KX_CTX]; int E; };
 
-template <int DPAD, int WPL>
+template <int DPAD, int WPL, bool SLICE = false>
 __global__ __launch_bounds__(256) void k_kcross_multi(const KxTable tab, int64_t W, int d, int64_t Np, int64_t Wld,
                                                       int chunks_per_wg, const int* __restrict__ nrows) {
     __shared__ KxLds<DPAD, WPL> lds;
@@ -298,14 +300,14 @@ __global__ __launch_bounds__(256) void k_kcross_multi(const KxTable tab, int64_t
     const KxCtx& c = tab.c[e];
     const int p = g - c.g0 + c.p0;
     if (c.kind == GPB_KERNEL_RBF)
-        kcross_body<GPB_KERNEL_RBF, DPAD, true, WPL>(lds, c.Xs, W, c.d, c.Xc, c.ls, c.amp, c.alpha, c.KsT, c.mpart, c.N, Np, Wld,
-                                                     c.P, c.dnorm, c.muS, chunks_per_wg, nrows, p);
+        kcross_body<GPB_KERNEL_RBF, DPAD, true, WPL, SLICE>(lds, c.Xs, W, c.d, c.Xc, c.ls, c.amp, c.alpha, c.KsT, c.mpart, c.N, Np, Wld,
+                                                            c.P, c.dnorm, c.muS, chunks_per_wg, nrows, p, c.planes, c.colscale);
     else if (c.kind == GPB_KERNEL_MATERN15)
-        kcross_body<GPB_KERNEL_MATERN15, DPAD, true, WPL>(lds, c.Xs, W, c.d, c.Xc, c.ls, c.amp, c.alpha, c.KsT, c.mpart, c.N, Np,
-                                                          Wld, c.P, c.dnorm, c.muS, chunks_per_wg, nrows, p);
+        kcross_body<GPB_KERNEL_MATERN15, DPAD, true, WPL, SLICE>(lds, c.Xs, W, c.d, c.Xc, c.ls, c.amp, c.alpha, c.KsT, c.mpart, c.N, Np,
+                                                                 Wld, c.P, c.dnorm, c.muS, chunks_per_wg, nrows, p, c.planes, c.colscale);
     else
-        kcross_body<GPB_KERNEL_MATERN25, DPAD, true, WPL>(lds, c.Xs, W, c.d, c.Xc, c.ls, c.amp, c.alpha, c.KsT, c.mpart, c.N, Np,
-                                                          Wld, c.P, c.dnorm, c.muS, chunks_per_wg, nrows, p);
+        kcross_body<GPB_KERNEL_MATERN25, DPAD, true, WPL, SLICE>(lds, c.Xs, W, c.d, c.Xc, c.ls, c.amp, c.alpha, c.KsT, c.mpart, c.N, Np,
+                                                                 Wld, c.P, c.dnorm, c.muS, chunks_per_wg, nrows, p, c.planes, c.colscale);
 }
 
 // 1-D grid of P * nI * nW tiles (T x T, T = 128 or 64), heaviest row blocks first; consecutive blocks
@@ -786,9 +788,13 @@ int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, in
         if (ctxs[e]->multi) GPB_FAIL(GPB_E_STATE, "gpb: a gpb_gp_set_multi context is fit-only (its GPs have different designs)");
     for (int e = 0; e < E && ok; ++e)           // (the shared launch is the Gram form's: a context with a difference-form GP takes its own)
         ok = ctxs[e]->n_diff == 0 && ctxs[e]->Np == ctx->Np && ctxs[e]->dpad == ctx->dpad && ctxs[e]->stream == ctx->stream;
-    // option key 51: an emulator's bits must not depend on the company it is evaluated in, so a context the int8 rule admits
-    // takes its own launches (digit planes out, int8 predict kernel: launch_vsq) inside a chain too
-    for (int e = 0; e < E && ok; ++e) ok = !sliced_applies(ctxs[e]);
+    // option key 51: an emulator's bits must not depend on the company it is evaluated in.  A group whose contexts the int8 rule ALL
+    // admits shares the SLICE form of this launch (digit planes out) and the int8 predict launch (launch_vsq); a mixed group falls
+    // back to one launch per context, each in its own form
+    int nsl = 0;
+    for (int e = 0; e < E; ++e) nsl += (!ctxs[e]->want_kst && sliced_applies(ctxs[e])) ? 1 : 0;
+    const bool planes = ok && nsl == E;
+    if (nsl > 0 && !planes) ok = false;
     if (!ok) {
         for (int e = 0; e < E; ++e) {
             const int rc = launch_kcross(ctxs[e], Xs[e], W, nrows_dev);
@@ -805,9 +811,13 @@ int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, in
         if (W > c->Wcap) GPB_FAIL(GPB_E_STATE, "gpb: internal: W exceeds workspace");
         c->Wld = Wuse;
         c->last_W = W;
-        c->batch_sliced = false;
-        tab.c[e] = KxCtx{Xs[e], c->Xc, c->ls, c->amp, c->alpha, c->dnorm, c->muS, c->KsT, c->mpart, (int)c->N, (int)c->P,
-                         c->kind, G, 0, (int)c->d};
+        c->batch_sliced = planes;
+        if (planes) {
+            const int rc = sliced_prepare(c);
+            if (rc) { ctx->err = c->err; return rc; }
+        }
+        tab.c[e] = KxCtx{Xs[e], c->Xc, c->ls, c->amp, c->alpha, c->dnorm, c->muS, c->KsT, c->mpart, planes ? c->slB : nullptr,
+                         planes ? sliced_colscale(c) : nullptr, (int)c->N, (int)c->P, c->kind, G, 0, (int)c->d};
         G += (int)c->P;
     }
     tab.E = E;
@@ -824,9 +834,15 @@ int launch_kcross_group(gpb_ctx* const* ctxs, const double* const* Xs, int E, in
     dim3 grid((unsigned)((nchunk + cpw - 1) / cpw), (unsigned)G, (unsigned)(Wuse / (64 * wpl)));
 #define GPB_KXM(DP)                                                                                              \
     do {                                                                                                         \
-        if (wpl == 2)                                                                                            \
+        if (wpl == 2 && planes)                                                                                  \
+            hipLaunchKernelGGL((k_kcross_multi<DP, (DP <= 32 ? 2 : 1), true>), grid, dim3(256), 0, ctx->stream, tab, W, \
+                               (int)ctx->d, ctx->Np, Wuse, cpw, nrows_dev);                                       \
+        else if (wpl == 2)                                                                                       \
             hipLaunchKernelGGL((k_kcross_multi<DP, (DP <= 32 ? 2 : 1)>), grid, dim3(256), 0, ctx->stream, tab, W, \
                                (int)ctx->d, ctx->Np, Wuse, cpw, nrows_dev);                                       \
+        else if (planes)                                                                                         \
+            hipLaunchKernelGGL((k_kcross_multi<DP, 1, true>), grid, dim3(256), 0, ctx->stream, tab, W, (int)ctx->d, \
+                               ctx->Np, Wuse, cpw, nrows_dev);                                                   \
         else                                                                                                     \
             hipLaunchKernelGGL((k_kcross_multi<DP, 1>), grid, dim3(256), 0, ctx->stream, tab, W, (int)ctx->d,    \
                                ctx->Np, Wuse, cpw, nrows_dev);                                                   \
@@ -854,8 +870,33 @@ int launch_vsq(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev) {
     if (E > 1) {
         // option key 51: contexts whose batch exists as int8 digit planes take their own launches (see launch_kcross_group);
         // the timing events of the whole group still go to ctxs[0]
-        bool any_sliced = false;
-        for (int e = 0; e < E; ++e) any_sliced = any_sliced || ctxs[e]->batch_sliced;
+        bool any_sliced = false, all_sliced = true;
+        int gsum = 0;
+        for (int e = 0; e < E; ++e) {
+            any_sliced = any_sliced || ctxs[e]->batch_sliced;
+            all_sliced = all_sliced && ctxs[e]->batch_sliced && ctxs[e]->Np == ctx->Np && ctxs[e]->Wld == Wuse && ctxs[e]->stream == ctx->stream;
+            gsum += (int)ctxs[e]->P;
+        }
+        if (all_sliced && gsum <= MAX_MULTI_GP) {       // one int8 launch over the GPs of all the emulators
+            int64_t ks = ctx->Np;
+            for (int e = 0; e < E; ++e) ks = imin64(ks, pad_front(ctxs[e]->Np, ctxs[e]->N));
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (ctx->profile) {
+                GPB_HIP(hipEventCreate(&e0)); GPB_HIP(hipEventCreate(&e1));
+                GPB_HIP(hipEventRecord(e0, ctx->stream));
+            }
+            const int rc = launch_vsq_sliced_multi(ctxs, E, W, nrows_dev, (int)ks);
+            if (rc) return rc;
+            if (ctx->profile) {
+                GPB_HIP(hipEventRecord(e1, ctx->stream));
+                ctx->prof_events.push_back({e0, e1});
+                ctx->prof_gps = (double)gsum;
+                if (!nrows_dev) ctx->prof_units += (double)gsum * (double)W;
+                else ctx->prof_compacted = true;
+            }
+            GPB_HIP(hipGetLastError());
+            return 0;
+        }
         if (any_sliced) {
             for (int e = 0; e < E; ++e) {
                 gpb_ctx* one[1] = {ctxs[e]};

@@ -174,14 +174,23 @@ __device__ __forceinline__ void sl_mma_step(const char* lds, int buf, int wm, in
     }
 }
 
+// one GP of a launch: its context's planes and scales, where its partials go, its index inside the context
+struct SlGP {
+    const int8_t *A, *B;
+    const double *rowscale, *colscale;
+    double* spart;
+    int P, p;
+};
+constexpr int SL_MAX_GP = GPB_MAX_MULTI_GP;
+struct SlTable { SlGP gp[SL_MAX_GP]; };
+
 // Static launch, one workgroup per tile slot.  Block b belongs to XCD label b % 8 (round-robin dispatch: speed only); the m-th
 // block of a label works on super-block (m / 32) * 8 + label, tile m % 32 of it.  Super-blocks in order: row groups heaviest
 // first, then GP, then walker group.  Slots of a ragged super-block (row blocks or walker tiles that do not exist) return at once.
-template <int WTN>
-__global__ __launch_bounds__(512, 2) void k_predict_sliced(const int8_t* __restrict__ A, const int8_t* __restrict__ B,
-                                                           const double* __restrict__ rowscale, const double* __restrict__ colscale,
-                                                           double* __restrict__ spart, int64_t Np, int64_t Np128, int64_t Wld, int P,
-                                                           int nI, int nW, int kskip, const int* __restrict__ nrows) {
+// MULTI: the launch's GPs come from a table (the emulators of a chain: every GP with its own context's planes), else from ONE context.
+template <int WTN, bool MULTI>
+__device__ __forceinline__ void predict_sliced_body(const SlGP& G0, const SlTable* __restrict__ tab, int64_t Np, int64_t Np128, int64_t Wld,
+                                                    int P, int nI, int nW, int kskip, const int* __restrict__ nrows) {
     typedef SlGeo<WTN> G;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     if (nrows) nW = (*nrows + G::BN - 1) / G::BN;                       // compacted batch: the live walker tiles only
@@ -190,7 +199,15 @@ __global__ __launch_bounds__(512, 2) void k_predict_sliced(const int8_t* __restr
     const unsigned sb = (m / (SL_RG * SL_CG)) * 8u + label, local = m % (SL_RG * SL_CG);
     if (sb >= (unsigned)(nG * P * nWG)) return;
     const int g = (int)(sb / (unsigned)(P * nWG)), rem = (int)(sb % (unsigned)(P * nWG));
-    const int p = rem / nWG, wg = rem % nWG;
+    const int pg = rem / nWG, wg = rem % nWG;           // pg: the GP's index in the launch
+    const SlGP gp = MULTI ? tab->gp[pg] : G0;
+    const int p = MULTI ? gp.p : pg;                    // ... and in its context
+    const int8_t* __restrict__ A = gp.A;
+    const int8_t* __restrict__ B = gp.B;
+    const double* __restrict__ rowscale = gp.rowscale;
+    const double* __restrict__ colscale = gp.colscale;
+    double* __restrict__ spart = gp.spart;
+    const int Pc = MULTI ? gp.P : P;                    // GPs of the GP's own context (the stride of its partials)
     const int ib = (nG - 1 - g) * SL_RG + (SL_RG - 1 - (int)(local / SL_CG)), wt = wg * SL_CG + (int)(local % SL_CG);
     if (ib >= nI || wt >= nW) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -260,8 +277,21 @@ __global__ __launch_bounds__(512, 2) void k_predict_sliced(const int8_t* __restr
     if (!(wm & 1) && lane < 32 && blk * 64 < Np) {
 #pragma unroll
         for (int j = 0; j < WTN; ++j)
-            spart[(blk * P + p) * Wld + nb + wn * 32 * WTN + 32 * j + lane] = sums[j] + hand[((wave + 2) * WTN + j) * 32 + lane];
+            spart[(blk * Pc + p) * Wld + nb + wn * 32 * WTN + 32 * j + lane] = sums[j] + hand[((wave + 2) * WTN + j) * 32 + lane];
     }
+}
+
+template <int WTN>
+__global__ __launch_bounds__(512, 2) void k_predict_sliced(const SlGP gp, int64_t Np, int64_t Np128, int64_t Wld, int P, int nI, int nW,
+                                                           int kskip, const int* __restrict__ nrows) {
+    predict_sliced_body<WTN, false>(gp, nullptr, Np, Np128, Wld, P, nI, nW, kskip, nrows);
+}
+
+// the GPs of ALL emulators of a chain in one launch (same Np, same batch): P = their number, the table says whose planes each reads
+template <int WTN>
+__global__ __launch_bounds__(512, 2) void k_predict_sliced_multi(const SlTable tab, int64_t Np, int64_t Np128, int64_t Wld, int P, int nI,
+                                                                 int nW, int kskip, const int* __restrict__ nrows) {
+    predict_sliced_body<WTN, true>(tab.gp[0], &tab, Np, Np128, Wld, P, nI, nW, kskip, nrows);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- host side
@@ -366,15 +396,68 @@ int launch_vsq_sliced(gpb_ctx* ctx, int64_t W, const int* nrows_dev, int kskip) 
     if (!attr_set) {
         GPB_HIP(hipFuncSetAttribute((const void*)k_predict_sliced<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SlGeo<2>::LDS));
         GPB_HIP(hipFuncSetAttribute((const void*)k_predict_sliced<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SlGeo<1>::LDS));
+        GPB_HIP(hipFuncSetAttribute((const void*)k_predict_sliced_multi<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SlGeo<2>::LDS));
+        GPB_HIP(hipFuncSetAttribute((const void*)k_predict_sliced_multi<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SlGeo<1>::LDS));
+        attr_set = true;
+    }
+    const SlGP gp{ctx->slA, ctx->slB, rowscale, colscale, ctx->spart, (int)P, 0};
+    if (wtn == 2)
+        hipLaunchKernelGGL(k_predict_sliced<2>, dim3(grid), dim3(512), SlGeo<2>::LDS, ctx->stream, gp, Np, Np128, Wld, (int)P, nI, nW,
+                           kskip, nrows_dev);
+    else
+        hipLaunchKernelGGL(k_predict_sliced<1>, dim3(grid), dim3(512), SlGeo<1>::LDS, ctx->stream, gp, Np, Np128, Wld, (int)P, nI, nW,
+                           kskip, nrows_dev);
+    (void)W;
+    return 0;
+}
+
+// The same for the GPs of E contexts (a chain's emulators of equal padded size, every one admitted by the rule and its batch left
+// as digit planes by the shared SLICE cross launch): one table, one launch.
+int launch_vsq_sliced_multi(gpb_ctx* const* ctxs, int E, int64_t W, const int* nrows_dev, int kskip) {
+    gpb_ctx* ctx = ctxs[0];
+    const int64_t Np = ctx->Np, Np128 = round_up(Np, 128), Wld = ctx->Wld;
+    SlTable tab;
+    int G = 0;
+    for (int e = 0; e < E; ++e) {
+        gpb_ctx* c = ctxs[e];
+        if (!c->slA || !c->slA_valid || !c->slB || c->Np != Np || c->Wld != Wld)
+            GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_vsq_sliced_multi over a context that is not prepared");
+        const double* rowscale = reinterpret_cast<const double*>(c->sl_scale);
+        const double* colscale = rowscale + c->P * Np128;
+        for (int p = 0; p < (int)c->P; ++p, ++G) {
+            if (G >= SL_MAX_GP) GPB_FAIL(GPB_E_STATE, "gpb: internal: launch_vsq_sliced_multi: too many GPs for one table");
+            const int64_t a_plane = (Np / 16) * Np128 * 16, b_plane = (Np / 16) * Wld * 16;
+            (void)a_plane; (void)b_plane;
+            tab.gp[G] = SlGP{c->slA, c->slB, rowscale, colscale, c->spart, (int)c->P, p};
+        }
+    }
+    const int nI = (int)(Np128 / SL_BM);
+    int64_t Wsel = Wld;
+    if (nrows_dev && ctx->tile_by_live && ctx->hint_from && ctx->hint_from->live_hint) {
+        const unsigned long long h = __atomic_load_n(ctx->hint_from->live_hint, __ATOMIC_RELAXED);
+        const int64_t cnt = (int64_t)(h & 0xffffffffull), of = (int64_t)(h >> 32);
+        if (of > 0 && cnt <= of) Wsel = imin64(Wld, (int64_t)((double)cnt / (double)of * (double)W * 1.03) + 8);
+    }
+    const int64_t tiles128 = (int64_t)G * nI * ((Wsel + 127) / 128);
+    int wtn = tiles128 >= 3 * (int64_t)ctx->num_cu ? 2 : 1;
+    if (ctx->force_tile == 128) wtn = 2;
+    if (ctx->force_tile == 64 || ctx->force_tile == 32 || ctx->force_tile == 65) wtn = 1;
+    const int nW = (int)(Wld / (64 * wtn));
+    const int nG = (nI + SL_RG - 1) / SL_RG, nWG = (nW + SL_CG - 1) / SL_CG;
+    const int64_t nSB = (int64_t)nG * G * nWG;
+    const unsigned grid = (unsigned)(((nSB + 7) / 8) * 8 * SL_RG * SL_CG);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GPB_HIP(hipFuncSetAttribute((const void*)k_predict_sliced_multi<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SlGeo<2>::LDS));
+        GPB_HIP(hipFuncSetAttribute((const void*)k_predict_sliced_multi<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SlGeo<1>::LDS));
         attr_set = true;
     }
     if (wtn == 2)
-        hipLaunchKernelGGL(k_predict_sliced<2>, dim3(grid), dim3(512), SlGeo<2>::LDS, ctx->stream, ctx->slA, ctx->slB, rowscale, colscale,
-                           ctx->spart, Np, Np128, Wld, (int)P, nI, nW, kskip, nrows_dev);
+        hipLaunchKernelGGL(k_predict_sliced_multi<2>, dim3(grid), dim3(512), SlGeo<2>::LDS, ctx->stream, tab, Np, Np128, Wld, G, nI, nW,
+                           kskip, nrows_dev);
     else
-        hipLaunchKernelGGL(k_predict_sliced<1>, dim3(grid), dim3(512), SlGeo<1>::LDS, ctx->stream, ctx->slA, ctx->slB, rowscale, colscale,
-                           ctx->spart, Np, Np128, Wld, (int)P, nI, nW, kskip, nrows_dev);
-    (void)W;
+        hipLaunchKernelGGL(k_predict_sliced_multi<1>, dim3(grid), dim3(512), SlGeo<1>::LDS, ctx->stream, tab, Np, Np128, Wld, G, nI, nW,
+                           kskip, nrows_dev);
     return 0;
 }
 

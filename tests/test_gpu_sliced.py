@@ -30,6 +30,8 @@ def _problem(N, d, P, kind, W, seed, sn2=0.05, c=1.0):
     (1000, 15, 4, "RBF", 515),          # Np = 1024: 16 + 8 rows of padding in front and behind; ragged batch
     (320, 20, 3, "Matern15", 130),      # Np = 320: the last 128-row block is half empty
     (65, 3, 2, "Matern25", 1),          # Np = 128, one walker
+    (40, 4, 2, "RBF", 70),              # Np = 64: half a row block, the K loop two steps long
+    (900, 12, 3, "RBF", 300),           # Np = 960: 48 rows of padding in front, a whole 32-deep K-step of it skipped
     (2048, 20, 10, "RBF", 256),         # cfg 4's GPs on a rank's share of eight
     (640, 8, 9, "RBF", 1024),           # nine GPs: more than one super-block per row group
 ])
