@@ -141,6 +141,56 @@ __device__ __forceinline__ v4i rnd_frag(int tid, int k) {
     return v4i{(int)(h * 0xC2B2AE35u), (int)((h ^ (h >> 15)) * 0x27D4EB2Fu), (int)(h * 77u + 12345u), (int)~(h * 0x165667B1u)};
 }
 
+template <int N>
+__device__ __forceinline__ void sgb_n() {
+    __builtin_amdgcn_sched_group_barrier(0x008, N, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+}
+__device__ __forceinline__ void sgb_mfma_then_read(int n) {          // n is a constant after unrolling
+    switch (n) {
+        case 1: sgb_n<1>(); break; case 2: sgb_n<2>(); break; case 3: sgb_n<3>(); break; case 4: sgb_n<4>(); break;
+        case 5: sgb_n<5>(); break; case 6: sgb_n<6>(); break; case 7: sgb_n<7>(); break; default: break;
+    }
+}
+
+// The streamed step with the fragment reads placed by hand (WTN = 2): all of a and of the first n-tile's b issued back to back in
+// the order of their first use (the first MFMA waits for two reads, not twelve), the second n-tile's b[t] read into the registers
+// b0[t] leaves as soon as b0[t]'s MFMAs are issued, so the second half starts with its fragments there.
+template <int D, int LOW, class F>
+__device__ __forceinline__ void mma_step8_ordered(const char* lds, int buf, int wm, int wn, int lane, v16i (&acc)[2 * D - 1 - LOW][2], F dma) {
+    typedef Geo<D, 2, 2> G;
+    const char* base = lds + buf * G::STAGE_BYTES;
+    const int q = lane >> 5, r = lane & 31;
+    const char* pa = base + (q * G::BM + wm * 32 + r) * 16;
+    const char* pb = base + G::A_CHUNKS * 1024 + (q * G::BN + wn * 64 + r) * 16;
+    v4i a[D], b[D], c[D];
+#pragma unroll
+    for (int t = 0; t < D; ++t) {                                       // first use: MFMA group tb = t needs a[D - 1 - t .. D - 1] and b[t]
+        a[D - 1 - t] = *reinterpret_cast<const v4i*>(pa + (D - 1 - t) * 2 * G::BM * 16);
+        b[t] = *reinterpret_cast<const v4i*>(pb + t * 2 * G::BN * 16);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * D, 0);
+#pragma unroll
+    for (int tb = 0; tb < D; ++tb) {
+#pragma unroll
+        for (int ta = D - 1; ta >= 0; --ta) {
+            if (ta + tb < LOW) continue;
+            acc[ta + tb - LOW][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ta], b[tb], acc[ta + tb - LOW][0], 0, 0, 0);
+        }
+        c[tb] = *reinterpret_cast<const v4i*>(pb + 32 * 16 + tb * 2 * G::BN * 16);      // the second n-tile's plane tb
+        sgb_mfma_then_read(tb + 1 - (LOW - (D - 1)));
+    }
+    __builtin_amdgcn_sched_barrier(0);                                  // the second n-tile's MFMAs stay behind the first's
+#pragma unroll
+    for (int tb = 0; tb < D; ++tb)
+#pragma unroll
+        for (int ta = D - 1; ta >= 0; --ta) {
+            if (ta + tb < LOW) continue;
+            acc[ta + tb - LOW][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ta], c[tb], acc[ta + tb - LOW][1], 0, 0, 0);
+        }
+    dma();
+}
+
 // MODE bits: 1 = DMA, 2 = fragment reads, 4 = MFMAs (7 = the real loop; the others isolate one limiter each)
 template <int D, int LOW, int WTM, int WTN, int MODE, bool PF, bool SCHED>
 __global__ __launch_bounds__(256, 1) void k_sliced(const int8_t* __restrict__ A, const int8_t* __restrict__ B,
@@ -483,7 +533,8 @@ __global__ __launch_bounds__(512, 2) void k_sliced8(const int8_t* __restrict__ A
                 if ((MODE & 1) && s + 2 < nsteps) dma_stage8<D, WTN>(lds, (s + 2) % 3, Ap, Bp, Np, Wld, mb, nb, 2 * (int64_t)(s + 2), wave, lane);
             };
             if ((MODE & 6) != 6) dma();
-            if ((MODE & 6) == 6) mma_step8_streamed<D, LOW, WTN, POS>(lds, s % 3, wm, wn, lane, wave, acc, dma);
+            if constexpr (POS == 8 && WTN == 2) { if ((MODE & 6) == 6) mma_step8_ordered<D, LOW>(lds, s % 3, wm, wn, lane, acc, dma); }
+            else if ((MODE & 6) == 6) mma_step8_streamed<D, LOW, WTN, POS>(lds, s % 3, wm, wn, lane, wave, acc, dma);
             else if (MODE & 4) {
                 Frags8<D, WTN> f;
 #pragma unroll
@@ -719,11 +770,11 @@ static double run8(Problem& pr, int map, int RG, int CG, int reps, const char* n
     return ms;
 }
 
-template <int D, int LOW, bool PF, int WTN = 1>
+template <int D, int LOW, bool PF, int WTN = 1, int POS = 0>
 static int check8() {
     constexpr int NLEV = 2 * D - 1 - LOW;
     Problem pr; make_problem(pr, 2, 256, 256, D, true);
-    run8<D, LOW, 7, PF, WTN>(pr, 0, 1, 1, 1, "check", false);
+    run8<D, LOW, 7, PF, WTN, POS>(pr, 0, 1, 1, 1, "check", false);
     std::vector<double> sp((size_t)(pr.Np / 64) * pr.P * pr.W);
     CK(hipMemcpy(sp.data(), pr.dsp, sp.size() * 8, hipMemcpyDeviceToHost));
     int bad = 0; double worst = 0;
@@ -770,6 +821,7 @@ int main(int argc, char** argv) {
     bad += check<6, 5, 2, 1>();
     bad += check8<7, 6, true>();
     bad += check8<6, 5, false, 2>();
+    bad += check8<6, 5, false, 2, 8>();
     if (bad) { printf("layout or loop error: timings not taken\n"); return 1; }
     if (all) {
         Problem pr; make_problem(pr, 10, 2048, 2048, 7, false);
@@ -801,7 +853,9 @@ int main(int argc, char** argv) {
         run8<6, 5, 7, false, 2, 5>(pr, 1, 8, 4, reps, "D6 8w 128x128 pos 5 (mid / end)");
         run8<6, 5, 7, false, 2, 6>(pr, 1, 8, 4, reps, "D6 8w 128x128 pos 6 (3 + setprio)");
         run8<6, 5, 7, false, 2, 7>(pr, 1, 8, 4, reps, "D6 8w 128x128 pos 7 (all at the end)");
-        run8<6, 5, 7, false, 2, 3>(pr, 1, 8, 4, reps, "D6 8w 128x128 pos 3 again");
+        run8<6, 5, 7, false, 2, 8>(pr, 1, 8, 4, reps, "D6 8w 128x128 pos 8 (reads by hand)");
+        run8<6, 5, 7, false, 2, 7>(pr, 1, 8, 4, reps, "D6 8w 128x128 pos 7 again");
+        run8<6, 5, 7, false, 2, 8>(pr, 1, 8, 4, reps, "D6 8w 128x128 pos 8 again");
         run8<6, 5, 7, false, 2, 3>(pr, 1, 4, 8, reps, "D6 8w 128x128 pos 3 superblk 4x8");
         run8<6, 5, 4, false, 2>(pr, 1, 8, 4, reps, "D6 8w 128x128 MFMA only (random regs)");
         run8<6, 5, 1, false, 2>(pr, 1, 8, 4, reps, "D6 8w 128x128 DMA only");
