@@ -164,6 +164,16 @@ class Chain:
             self.emuList.append(emu)
         log.info("Number of Emulators: %d", len(self.emuList))
 
+    def set_predict_arithmetic(self, which="fp64"):
+        """the same choice for every drop-in emulator of the chain (Emulator.set_predict_arithmetic): "fp64" (default) or "int8" —
+        foreign emulators are left alone; an emulator outside the int8 rule keeps the fp64 kernel by itself"""
+        from .emulator import Emulator
+        for e in self.emuList:
+            if isinstance(e, Emulator):
+                e.set_predict_arithmetic(which)
+        self.__dict__.pop("_digest_cache", None)
+        return self
+
     def random_pos(self, n=1):
         return np.random.uniform(self.min, self.max, (n, self.ndim))
 

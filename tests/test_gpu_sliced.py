@@ -146,3 +146,28 @@ def test_chain_log_posterior_with_the_int8_kernel(tmp_path):
     pb = b.run(X0, 6, status=10 ** 9, store=False)
     assert np.array_equal(pa, pb)
     eng.tune("predict_sliced", 0)
+
+
+def test_the_public_choice_of_arithmetic_survives_pickling_and_a_new_engine(tmp_path):
+    """Emulator.set_predict_arithmetic / Chain.set_predict_arithmetic: the int8 kernel through the drop-in classes, kept by a
+    pickled emulator (whose engine is rebuilt on load) and part of the state digest the replicas of a sharded run compare"""
+    import dill
+    from gpbayestools_hic_amd import synth
+    from gpbayestools_hic_amd.workload import build_chain
+    chain, emu, info = build_chain(4, workdir=str(tmp_path), N=320)
+    emu._engine_ready().tune("predict_sliced", 0)              # (whatever GPB_PREDICT_SLICED says)
+    X = synth.walkers(64, info["d"], seed=3)
+    lp64, d64 = chain.log_posterior(X), emu.state_digest()
+    assert chain.set_predict_arithmetic("int8") is chain and emu.predict_arithmetic == "int8"
+    lp8, d8 = chain.log_posterior(X), emu.state_digest()
+    assert d8 != d64 and not np.array_equal(lp8, lp64) and relerr(lp8, lp64) < 1e-10
+    again = dill.loads(dill.dumps(emu))
+    assert again.predict_arithmetic == "int8" and again.state_digest() == d8
+    m8, c8 = emu.predict(X, return_cov=True)
+    ma, ca = again.predict(X, return_cov=True)
+    for k in m8:
+        assert np.array_equal(ma[k], m8[k])
+    chain.set_predict_arithmetic("fp64")
+    assert emu.state_digest() == d64 and np.array_equal(chain.log_posterior(X), lp64)
+    with pytest.raises(ValueError):
+        emu.set_predict_arithmetic("bf16")
