@@ -165,8 +165,7 @@ def test_the_public_choice_of_arithmetic_survives_pickling_and_a_new_engine(tmp_
     assert again.predict_arithmetic == "int8" and again.state_digest() == d8
     m8, c8 = emu.predict(X, return_cov=True)
     ma, ca = again.predict(X, return_cov=True)
-    for k in m8:
-        assert np.array_equal(ma[k], m8[k])
+    assert np.array_equal(np.asarray(ma), np.asarray(m8)) and np.array_equal(np.asarray(ca), np.asarray(c8))
     chain.set_predict_arithmetic("fp64")
     assert emu.state_digest() == d64 and np.array_equal(chain.log_posterior(X), lp64)
     with pytest.raises(ValueError):
