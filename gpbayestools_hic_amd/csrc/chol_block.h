@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "gemm_tile.h"
 
 namespace gpb {
@@ -14,6 +15,9 @@ constexpr int LDP = 65;            // row stride (doubles) of a 64x64 block in L
                                    // = 2 (mod 32) apart are conflict-free; at 66 (132 = 4 mod 32) rows r and r + 8 met on a bank:
                                    // SQ_LDS_BANK_CONFLICT was 43 % of the step kernels' LDS cycles (profiles/r04_fit_pmc.json).
                                    // Rows are 8-byte aligned only: tiles are stored with ds_write_b64 (load_tile)
+#ifndef POTF2_AHEAD
+#define POTF2_AHEAD 4              // columns whose scalar multipliers are in flight ahead of their fma (potf2_inv_64)
+#endif
 constexpr int CHOL_THREADS = 512;  // 8 waves: two per SIMD, what it takes to keep the f64 MFMA pipe issuing back to back
 
 struct CholLds {
@@ -62,6 +66,29 @@ __device__ __forceinline__ void fmac_bc16v(double& acc, double src, double mul, 
     }
 }
 __device__ __forceinline__ void hazard_dpp_src(double& src) { asm volatile("s_nop 1" : "+v"(src)); }
+// lane K's value in a scalar register pair (uniform): two v_readlane_b32, volatile so that the pass keeps them where they are
+// written (hoisted by the scheduler, the scalars of a whole pivot lived at once and spilled: round 1's version)
+template <int K>
+__device__ __forceinline__ double readlane_f64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    int slo, shi;
+    asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(slo) : "v"(lo), "n"(K));
+    asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(shi) : "v"(hi), "n"(K));
+    return __hiloint2double(shi, slo);
+}
+// acc += s * mul with the uniform s in scalar registers (plain v_fmac_f64: full rate)
+__device__ __forceinline__ void fmac_s(double& acc, double s, double mul) {
+    asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(acc) : "s"(s), "v"(mul));
+}
+// pins the place of a value's definition among the volatile asm statements around it (no instruction)
+__device__ __forceinline__ void pin(double& v) { asm volatile("" : "+v"(v)); }
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 // 1/sqrt(a) to full precision: v_rsq_f64 (about 2^-26) and one third-order correction y (1 + e/2 + 3 e^2/8),
 // e = 1 - a y^2.  No special cases: a <= 0 gives NaN / inf, which is what a failed pivot has to propagate.
@@ -147,57 +174,99 @@ __device__ __forceinline__ void potf2_inv_64(CholLds& s, unsigned long long* sta
         const int o = 16 * bb;
         const int nrem = 48 - o;                       // rows below this sub-block inside the 64-block
         if (wave == 0) {
-            // ---- 16x16 diagonal sub-block AND the panel below it in one pass of one wave.  Lane l holds row l & 15 of
-            //      the diagonal sub-block (rd: every row of 16 lanes factors its own copy) and panel row o + 16 + l
-            //      (rp, lanes < nrem).  Per pivot: 1/sqrt from a row broadcast, then for every later column ONE
-            //      broadcast of the multiplier feeds both the factor's and the panel's fma.
-            const int li = lane & 15;
-            const bool has_row = lane < nrem;
-            double rd[16], rp[16];
+            // ---- 16x16 diagonal sub-block AND the panel below it in one pass of one wave: lane l holds row o + l of the block
+            //      column (lanes 0-15 the diagonal sub-block, lanes 16 .. 15 + nrem the panel), ONE register row per lane.
+            //      Per pivot: a_jj from lane j, 1/sqrt (uniform), the column scaled in all rows at once; for every later
+            //      column k the multiplier L_kj = lane k's l goes through a scalar register pair (two v_readlane_b32) into ONE
+            //      v_fmac_f64 for the factor's and the panel's rows together.
+            //      (Rounds 2-5 broadcast by DPP inside the 16-lane rows — v_fmac_f64_dpp row_newbcast, every row of 16 lanes
+            //      factoring its own copy of the diagonal block, a second fma for the panel rows, the whole chain of a pivot
+            //      behind the previous pivot's updates: 4.86 k cycles per pass; this form 4.34 k.  Neither is bound by the
+            //      updates' issue alone (a lone wave issues v_fmac_f64 every 4.6 cycles, with a DPP operand every 4.8,
+            //      v_readlane_b32 and v_mov_b64_dpp every 8: tools/micro/issue_rate_probe.hip): a pivot's skeleton — pivot to a
+            //      scalar, v_rsq_f64 + correction, scaling, the first update — is ~230 cycles of mostly dependent
+            //      instructions, 16 times per pass: profiles/r06_fit_notes.txt.  The same products on the same operands in
+            //      the same order per accumulator as before: the same bits.)
+            const bool has_row = lane < 16 + nrem;
+            double a[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                rd[k] = s.a[o + li][o + k];
-                rp[k] = has_row ? s.a[o + 16 + lane][o + k] : 0.0;
-            }
+            for (int k = 0; k < 16; ++k) a[k] = s.a[o + (has_row ? lane : 0)][o + k];      // (lanes without a row: a copy of row o, never stored)
             int badj = -1;
             double myrinv = 0.0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                // rd[j] may have been written by the inline-asm fma just before (pivot 15: one instruction earlier):
-                // the same two wait states before a DPP read, which the compiler cannot know it owes
-                double piv = rd[j];
-                hazard_dpp_src(piv);
-                const double ajj = bc16v(piv, j);
-                if (!(ajj > 0.0) && badj < 0) badj = j;
-                const double rinv = rsqrt_nr(ajj);                 // 1 / L_jj
-                const double ld = rd[j] * rinv, lp = rp[j] * rinv; // column j of L: factor rows, panel rows
-                myrinv = (li == j) ? rinv : myrinv;                // lane j keeps 1 / L_jj (no branch inside the chain)
-                rd[j] = ld;
-                rp[j] = lp;
-                double src = ld;
-                const double nld = -ld, nlp = -lp;
-                hazard_dpp_src(src);
-                // a[.][k] -= l_.j * L_kj, L_kj = lane k's ld: the broadcast rides on the fma.  (With separate
-                // v_mov_b64_dpp broadcasts the scheduler ran ahead along the pivot chain and kept every broadcast of every
-                // pivot alive for the deferred updates: 256 VGPRs, 600 bytes of scratch per lane, 45,000 cycles per pass;
-                // pinned in order they cost 4,500; the volatile asm fmas are in order by construction: 3,000.)
-#pragma unroll
-                for (int k = j + 1; k < 16; ++k) {
-                    fmac_bc16v(rd[k], src, nld, k);
-                    fmac_bc16v(rp[k], src, nlp, k);
-                }
+            // The pass is a software pipeline: one wave issues in order, and pivot j + 1's chain — a_(j+1)(j+1) to a scalar,
+            // v_rsq_f64, the five dependent operations of its correction, the column's scaling — needs nothing but column
+            // j + 1, which is final after the FIRST update of pivot j: its seven stages are dealt out between the remaining
+            // updates (volatile asm statements keep their order; pin() places the compiler's own instructions among them).
+            double l, nl;
+            {
+                const double ajj = readlane_f64<0>(a[0]);
+                if (!(ajj > 0.0)) badj = 0;
+                const double rinv = rsqrt_nr(ajj);                 // 1 / L_00
+                l = a[0] * rinv;                                   // column 0 of L, factor and panel rows
+                myrinv = (lane == 0) ? rinv : myrinv;              // lane j keeps 1 / L_jj (no branch inside the chain)
+                a[0] = l;
+                nl = -l;
+                pin(l); pin(nl);
             }
+            static_for<0, 15>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                // a[.][k] -= l_.j * L_kj for k = j + 1 .. 15; the scalar of column k + AH is fetched before column k's fma
+                // (a scalar written by v_readlane_b32 reaches a vector instruction only after the scalar write-back)
+                constexpr int AH = POTF2_AHEAD;
+                double sm[16 + AH];                               // the multipliers L_kj, uniform: scalar register pairs
+                static_for<0, AH>([&](auto ac) {
+                    constexpr int k = j + 1 + decltype(ac)::value;
+                    if constexpr (k < 16) sm[k] = readlane_f64<(k < 16 ? k : 15)>(l);
+                });
+                if constexpr (j + 1 + AH < 16) sm[j + 1 + AH] = readlane_f64<(j + 1 + AH < 16 ? j + 1 + AH : 15)>(l);
+                fmac_s(a[j + 1], sm[j + 1], nl);                   // column j + 1 is final: pivot j + 1 can start
+                constexpr int rest = 14 - j;                       // updates left, dealt over the seven gaps in front of the stages
+                double ajj = 0.0, y = 0.0, t = 0.0, e = 0.0, v = 0.0, u = 0.0, rinv = 0.0;
+                static_for<0, 7>([&](auto sc) {
+                    constexpr int st = decltype(sc)::value;
+                    constexpr int nf = rest / 7 + (st < rest % 7 ? 1 : 0);                        // 0, 1 or 2
+                    constexpr int k0 = j + 2 + st * (rest / 7) + (st < rest % 7 ? st : rest % 7);
+                    static_for<0, nf>([&](auto fc) {
+                        constexpr int k = k0 + decltype(fc)::value;
+                        if constexpr (k + AH < 16) sm[k + AH] = readlane_f64<(k + AH < 16 ? k + AH : 15)>(l);
+                        fmac_s(a[k], sm[k], nl);
+                    });
+                    if constexpr (st == 0) {
+                        ajj = readlane_f64<j + 1>(a[j + 1]);
+                    } else if constexpr (st == 1) {
+                        y = __builtin_amdgcn_rsq(ajj);             // rsqrt_nr(ajj), stage by stage
+                        if (!(ajj > 0.0) && badj < 0) badj = j + 1;
+                        pin(y);
+                    } else if constexpr (st == 2) {
+                        t = ajj * y;
+                        pin(t);
+                    } else if constexpr (st == 3) {
+                        e = fma(-t, y, 1.0);
+                        pin(e);
+                    } else if constexpr (st == 4) {
+                        v = y * e;
+                        u = fma(e, 0.375, 0.5);
+                        pin(v); pin(u);
+                    } else if constexpr (st == 5) {
+                        rinv = fma(v, u, y);
+                        pin(rinv);
+                    } else {
+                        const double l2 = a[j + 1] * rinv;
+                        myrinv = (lane == j + 1) ? rinv : myrinv;
+                        a[j + 1] = l2;
+                        // (pivot j's l / nl are dead here: every update of pivot j has been issued above)
+                        l = l2; nl = -l2;
+                        pin(l); pin(nl);
+                    }
+                });
+            });
             if (badj >= 0 && lane == 0 && s.bad < 0) s.bad = o + badj;
-            if (lane < 16) {
-                s.rdg[o + li] = myrinv;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) s.a[o + li][o + k] = (k <= li) ? rd[k] : 0.0;
-            }
+            if (lane < 16) s.rdg[o + lane] = myrinv;
             if (has_row) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) s.a[o + 16 + lane][o + k] = rp[k];
+                for (int k = 0; k < 16; ++k) s.a[o + lane][o + k] = (lane >= 16 || k <= lane) ? a[k] : 0.0;
             }
-        }
+                }
         __syncthreads();
 stamp();
         if (nrem > 0) {
@@ -227,18 +296,31 @@ stamp();
         //      the row owns column c of X (solve L x = e_c) and holds row c of L; right-looking: once x_i is known every
         //      later partial sum takes its term, L_mi coming from lane m of the row by broadcast
         const int o = 16 * (lane >> 4), li = lane & 15;
-        double r[16], x[16];
+        double r[16], x[16], rg[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             r[k] = s.a[o + li][o + k];                 // row li of L11 (zeros above the diagonal)
             x[k] = (k == li) ? 1.0 : 0.0;
+            rg[k] = s.rdg[o + k];
+        }
+        // x_m -= L_mi x_i with the broadcast of L_mi folded into the fma (v_fmac_f64_dpp: (-a) b + c = a (-b) + c, bit for bit;
+        // half the instructions of v_mov_b64_dpp + v_fma_f64), and x_(i+1) scaled right behind the one update it waits for
+        double nxi;
+        {
+            const double xi = x[0] * rg[0];
+            x[0] = xi;
+            nxi = -xi;
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const double xi = x[i] * s.rdg[o + i];
-            x[i] = xi;
+        for (int i = 0; i < 15; ++i) {
+            fmac_bc16v(x[i + 1], r[i], nxi, i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const double xn = x[i + 1] * rg[i + 1];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int m = i + 1; m < 16; ++m) x[m] = fma(-bc16v(r[i], m), xi, x[m]);      // L_mi x_i
+            for (int m = i + 2; m < 16; ++m) fmac_bc16v(x[m], r[i], nxi, m);      // L_mi x_i
+            x[i + 1] = xn;
+            nxi = -xn;
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) s.x[o + k][o + li] = (k >= li) ? x[k] : 0.0;        // column li of the inverse
