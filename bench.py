@@ -424,6 +424,25 @@ def extras(chain4, emu4, info4, sustain_s=5.5, only_sustained=False):
                                 "gpb_chain_emcee_run, burnt-in ensemble, behind 100 untimed pre-heat steps; algorithmic flops per SURVEY "
                                 "8(d) (11.05 MF per walker); roofline = k_predict's N^2 per (GP, row) over its HIP-event times"}
     del s3
+    # the same steps with the int8 predict kernel (option key 51; 512-row batches: its 128x64 tiles)
+    try:
+        emu3.set_predict_arithmetic("int8")
+        s3 = StretchSampler(chain3, nw3, seed=12345)
+        s3.run(X03, warm3, status=10 ** 9, store=False)
+        eng3.profile(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s3.run(None, nst3, status=10 ** 9, store=False)
+        torch.cuda.synchronize()
+        dt3s = (time.perf_counter() - t0) / nst3
+        n_s, ms_s, _u = eng3.profile_read()
+        eng3.profile(False)
+        del s3
+        out["cfg3_step"]["int8_predict"] = {"ms_per_step": dt3s * 1e3, "walker_evals_per_s": nw3 / dt3s,
+                                            "speedup_vs_fp64_path": dt3 / dt3s, "k_predict_sliced_avg_launch_ms": ms_s / max(n_s, 1)}
+        emu3.set_predict_arithmetic("fp64")
+    except Exception as e:      # noqa: BLE001
+        out["cfg3_step"]["int8_predict"] = {"error": "%s: %s" % (type(e).__name__, e)}
     emu3._engine.close()
 
     # BASELINE config 5 (pocoMC: 8192 particles, Matern-5/2, 4096-pt design): the call pocoMC makes,
@@ -462,6 +481,20 @@ def extras(chain4, emu4, info4, sustain_s=5.5, only_sustained=False):
                                  "(vectorize=True), every row inside the prior box; ms_per_batch: rows and results resident in HBM; "
                                  "host_call: numpy in, numpy out (PCIe inclusive, median of three); algorithmic flops per SURVEY 8(d) "
                                  "(171.0 MF per row)"}
+    # the same batches with the int8 predict kernel (option key 51)
+    try:
+        emu5.set_predict_arithmetic("int8")
+        lp5s = torch.empty(W5, dtype=torch.float64, device="cuda")
+        for _ in range(2):
+            chain5.log_prob_device(Xd5, lp5s, outside=-1e300)
+        torch.cuda.synchronize()
+        t5s = timed(lambda: chain5.log_prob_device(Xd5, lp5s, outside=-1e300), 5)
+        dev5 = float(torch.max(torch.abs(lp5s - lp5) / torch.abs(lp5)).item())
+        out["cfg5_batch"]["int8_predict"] = {"ms_per_batch": t5s * 1e3, "rows_per_s": W5 / t5s, "speedup_vs_fp64_path": t5 / t5s,
+                                             "max_rel_dev_log_posterior_vs_fp64_path": dev5}
+        emu5.set_predict_arithmetic("fp64")
+    except Exception as e:      # noqa: BLE001
+        out["cfg5_batch"]["int8_predict"] = {"error": "%s: %s" % (type(e).__name__, e)}
     emu5._engine.close()
 
     # training of the emulators of such a chain with their full hyper-parameter searches (src/emulator.py:286-315 for each of the

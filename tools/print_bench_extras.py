@@ -17,10 +17,14 @@ print("uniform start", round(e["uniform_start"]["value"]), round(e["uniform_star
 if "cfg3_step" in e:
     c = e["cfg3_step"]
     print("cfg3_step ms/step", round(c["ms_per_step"], 4), "M walker-evals/s", round(c["walker_evals_per_s"] / 1e6, 3), "k_predict frac", round(c["roofline"]["frac"], 3))
+    if "int8_predict" in c:
+        print("  cfg3 int8:", c["int8_predict"])
 if "cfg5_batch" in e:
     c = e["cfg5_batch"]
     print("cfg5_batch ms/batch", round(c["ms_per_batch"], 3), "rows/s", round(c["rows_per_s"]), "whole-batch frac", round(c["frac_of_peak_whole_batch"], 3),
           "k_predict frac", round(c["roofline"]["frac"], 3))
+    if "int8_predict" in c:
+        print("  cfg5 int8:", c["int8_predict"])
 if "train_nine_emulators" in e:
     c = e["train_nine_emulators"]
     print("train nine emulators: one after the other", round(c["one_after_the_other_s"], 3), "s, together", round(c["train_emulators_s"], 3), "s, theta identical", c["theta_identical"])
